@@ -1,0 +1,280 @@
+/*
+ * ppenv.h — C ABI of the MI355X-native vectorised HumanoidPingpong environment.
+ *
+ * This is the drop-in boundary for the one hot path of mjmj531/isaacgym that
+ * BASELINE.json names: the VecTask step of the HumanoidPingpong tasks
+ *     pre_physics_step -> gym.simulate -> post_physics_step
+ * (reference: tasks/humanoid_pingpong_3_actor_tilt.py:1002-1052 "TT", and the
+ * same hooks in the T3 / TN variants).  The reference drives that path through
+ * two foreign interfaces, neither of which lives in the reference repo:
+ *   - upward, isaacgymenvs' VecTask buffer surface (obs_buf / rew_buf /
+ *     reset_buf / progress_buf, TT:118,1023-1037), and
+ *   - downward, Isaac Gym's gymapi/gymtorch tensor API (acquire_*_tensor,
+ *     refresh_*, set_*_indexed, simulate; TT:131-134,801-807,881-888,1014).
+ * Each entry point below names the reference call it replaces.
+ *
+ * Conventions: plain C, no torch types.  Every function returns 0 on success
+ * or a negative PPENV_E* code and never throws; ppenv_last_error() gives a
+ * thread-local message.  All pointers named *_dev are device (HBM) pointers.
+ * Launches are enqueued on the caller's HIP stream (`stream`, a hipStream_t
+ * passed as void*; NULL = the null stream) and never synchronise.  A handle is
+ * bound to one GPU and is not re-entrant.
+ *
+ * Quaternions are xyzw everywhere (Isaac Gym layout, TT:173-183).
+ */
+#ifndef PPENV_H
+#define PPENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPENV_ABI_VERSION 1
+
+struct ppenv; /* opaque handle */
+typedef struct ppenv ppenv;
+
+#define PPENV_NUM_DOF 7          /* right-arm chain (TT:427-431) */
+#define PPENV_NUM_OBS_BODIES 10  /* bodyStatesId, cfg/task/HumanoidPingpongTiltG1.yaml:47 */
+#define PPENV_NUM_OBS 80         /* TT:98 : 30 + 30 + 7 + 7 + 3 + 3 */
+#define PPENV_NUM_HUMANOID_BODIES 40 /* tasks/pingpong_note.txt:33 */
+#define PPENV_NUM_BODIES 42      /* humanoid 40 + table + ball, TT:127 */
+#define PPENV_NUM_ACTORS 3       /* humanoid, table, ball, TT:125 */
+#define PPENV_MAX_SHAPES 8       /* capsule/sphere collision shapes on the humanoid */
+
+/* error codes */
+#define PPENV_OK 0
+#define PPENV_EINVAL (-1)   /* bad argument / inconsistent config */
+#define PPENV_ENOMEM (-2)   /* allocation failed */
+#define PPENV_EHIP (-3)     /* a HIP runtime call failed */
+#define PPENV_ESTATE (-4)   /* blob size / version mismatch in get/set_state */
+
+/* Task variants (reward / reset semantics). */
+enum {
+    PPENV_VARIANT_T3 = 0, /* HumanoidPingpongG1: tasks/humanoid_interos_edit_pingpong_only_3_actor.py */
+    PPENV_VARIANT_TT = 1, /* HumanoidPingpongTiltG1: tasks/humanoid_pingpong_3_actor_tilt.py */
+    PPENV_VARIANT_TN = 2  /* HumanoidPingpongTiltNoEarlyStopG1: ..._tilt_no_earlystop.py */
+};
+
+/* Sticky per-env flag bits (one uint32 per env).
+ * TT: reward_calculated / condition_calculated / no_bounce_before_half_mask (TT:241-243)
+ * TN: paddle_condition_calculated / missed_ball_calculated (TN:245-246) */
+#define PPENV_FLAG_REWARD_CALC 1u     /* TT reward_calculated */
+#define PPENV_FLAG_COND_CALC 2u       /* TT condition_calculated, TN paddle_condition_calculated */
+#define PPENV_FLAG_NO_BOUNCE 4u       /* TT no_bounce_before_half_mask (initially set) */
+#define PPENV_FLAG_MISSED_CALC 8u     /* TN missed_ball_calculated */
+
+/* One revolute joint + the link it moves.  Link i's frame sits at the joint;
+ * E_i(q) = origin_rot * Rot(axis, q) maps child coordinates to parent coordinates. */
+typedef struct ppenv_joint {
+    float origin_xyz[3];  /* child origin in parent coordinates */
+    float origin_rot[9];  /* row-major, parent <- child at q = 0 */
+    int32_t axis;         /* 0 = x, 1 = y, 2 = z */
+    float lower, upper;   /* position limits [rad] */
+    float kp, kd;         /* PD drive gains (TT:694-711) */
+    float effort;         /* drive torque limit [N m] */
+    float vel_limit;      /* |qd| limit [rad/s] */
+    float armature;       /* added joint-space inertia */
+    float mass;           /* link mass (composite of everything rigidly attached) */
+    float com[3];         /* centre of mass, link coordinates */
+    float inertia[6];     /* about the COM, link axes: xx, yy, zz, xy, xz, yz */
+} ppenv_joint;
+
+/* A frame rigidly attached to chain link `link` (0..6), or to the world when
+ * link = -1 (then xyz/rot are the world pose).  Used for the observed bodies. */
+typedef struct ppenv_frame {
+    int32_t link;
+    float xyz[3];
+    float rot[9];         /* row-major, link <- frame */
+} ppenv_frame;
+
+/* Capsule (a != b) or sphere (a == b) collision shape attached like a frame. */
+typedef struct ppenv_shape {
+    int32_t link;         /* -1 = static, a/b in world coordinates */
+    float a[3], b[3];
+    float radius;
+    float restitution;    /* COMBINED ball x surface coefficients (the host clamps each material's
+                             restitution to restitution_max, then averages: PhysX default combine mode) */
+    float friction;
+} ppenv_shape;
+
+typedef struct ppenv_box {
+    float center[3];
+    float half[3];
+    float restitution;    /* combined, as in ppenv_shape */
+    float friction;
+} ppenv_box;
+
+/* Everything the step needs that is not per-env state.  Built by the host
+ * (isaacgym_amd/scene.py) from the task cfg; the same struct feeds the HIP
+ * library and the CPU oracle.  Replaces the constants the reference scatters
+ * over __init__/create_sim/_create_envs (TT:60-116,325-344,387-711) and the
+ * `sim:` block of cfg/task/HumanoidPingpongTiltG1.yaml:77-98. */
+typedef struct ppenv_config {
+    int32_t abi_version;      /* PPENV_ABI_VERSION */
+    int32_t variant;          /* PPENV_VARIANT_* */
+    int32_t num_envs;         /* envs owned by this handle (local shard) */
+    int32_t env_id_offset;    /* global id of local env 0 (multi-GPU shard; keys the RNG) */
+    uint64_t seed;
+    int32_t device_id;
+
+    /* simulation (yaml sim: block) */
+    float dt;                 /* 0.0083 */
+    int32_t substeps;         /* 2 */
+    int32_t ball_substeps;    /* ball micro-steps per substep (design param, default 4) */
+    float gravity_z;          /* -9.8 (TT:329-331 overrides the yaml's -9.81) */
+    float contact_offset;     /* 2e-4 */
+    float bounce_threshold;   /* 0.2 */
+    float max_depenetration_velocity; /* 10 */
+    float clip_actions;       /* env.clipActions = 1.0 */
+    float clip_obs;           /* VecTask clipObservations (inf = off) */
+
+    /* articulated arm */
+    float base_pos[3];        /* chain base (torso frame) in the world */
+    float base_rot[9];        /* row-major, world <- base */
+    ppenv_joint joint[PPENV_NUM_DOF];
+    float init_dof_pos[PPENV_NUM_DOF];  /* zeros (TT:471,547) */
+    float init_dof_vel[PPENV_NUM_DOF];
+
+    /* observed bodies, in bodyStatesId order; entry 0 is the pelvis (root) */
+    ppenv_frame obs_body[PPENV_NUM_OBS_BODIES];
+    int32_t paddle_obs_index; /* which obs_body is the paddle (9) */
+
+    /* actor root poses (TT:522-523,575,622); xyzw */
+    float humanoid_root_pos[3], humanoid_root_quat[4];
+    float table_root_pos[3], table_root_quat[4];
+    float ball_init_pos[3], ball_init_quat[4];
+
+    /* ball */
+    float ball_radius, ball_mass;
+    float ball_inertia_factor;   /* I = k m r^2 ; 2/3 = thin shell */
+    float ball_restitution, ball_friction;   /* raw ball material (informational; surfaces carry combined values) */
+    float ball_angular_damping;
+    float restitution_max;       /* materials are clamped to this before combining (1.0) */
+
+    /* static scene */
+    float ground_z, ground_restitution, ground_friction;   /* combined */
+    ppenv_box table;             /* playing surface slab */
+    ppenv_box net;
+    /* paddle blade: disc attached to chain link `paddle_link` */
+    int32_t paddle_link;
+    float paddle_center[3];      /* link coordinates */
+    float paddle_normal[3];      /* unit, link coordinates */
+    float paddle_radius, paddle_half_thickness;
+    float paddle_restitution, paddle_friction;   /* combined */
+    int32_t num_shapes;
+    ppenv_shape shape[PPENV_MAX_SHAPES];
+    float humanoid_bound_center[3]; /* ball farther than this sphere skips arm/body shapes */
+    float humanoid_bound_radius;
+
+    /* serve distribution, generate_random_speed_for_ball (TT:296-323, T3:289-305, TN:301-328) */
+    float serve_speed_lo, serve_speed_hi;
+    float serve_tilt_lo_deg, serve_tilt_hi_deg;
+    float serve_tilt_z_lo_deg, serve_tilt_z_hi_deg;
+
+    /* reward constants (TT:84,103-107) */
+    int32_t max_episode_length;
+    float alpha_velocity_reward;
+    float power_coefficient;
+    float penalty;
+    float hit_table_reward;
+    float not_hit_table_penalty;
+} ppenv_config;
+
+/* Device pointers of the buffers a handle owns, for zero-copy wrapping (the
+ * analogue of gymtorch.wrap_tensor, TT:153-208).  SoA state arrays are
+ * [field][num_envs]; surface tensors use the reference's AoS layouts. */
+typedef struct ppenv_buffers {
+    int32_t num_envs;
+    /* VecTask surface */
+    float* obs_buf;        /* [N, 80] f32 */
+    float* rew_buf;        /* [N] f32 */
+    int64_t* reset_buf;    /* [N] i64 */
+    int64_t* progress_buf; /* [N] i64 */
+    /* SoA simulation state */
+    float* dof_pos;        /* [7][N] */
+    float* dof_vel;        /* [7][N] */
+    float* dof_force;      /* [7][N]  drive torque of the last substep */
+    float* ball;           /* [13][N] pos3 quat4 linvel3 angvel3 */
+    uint32_t* flags;       /* [N] PPENV_FLAG_* */
+    uint32_t* episode;     /* [N] resets so far (RNG counter) */
+    float* serve_override; /* [3][N]; used instead of the RNG while the override is on */
+} ppenv_buffers;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+
+/* Bytes of device memory one handle needs for `cfg->num_envs` envs. */
+size_t ppenv_arena_bytes(const ppenv_config* cfg);
+
+/* Create an environment.  If arena_dev is non-NULL it must point to at least
+ * ppenv_arena_bytes(cfg) bytes of 256-byte-aligned device memory owned by the
+ * caller (e.g. a torch tensor) that outlives the handle; otherwise the library
+ * allocates.  State is initialised as after the reference's _create_envs
+ * (TT:512-643): dofs at rest, ball at its start pose with a fresh serve.
+ * Replaces VecTask.__init__ -> create_sim -> _create_envs (TT:118,325-344). */
+int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, void* stream, struct ppenv** out);
+void ppenv_destroy(struct ppenv* env);
+int ppenv_buffers_of(struct ppenv* env, ppenv_buffers* out);
+int ppenv_config_of(struct ppenv* env, ppenv_config* out);
+
+/* ---- the hot path ---------------------------------------------------------- */
+
+/* One VecTask.step(): clamp actions, action->PD target (TT:1003-1014), snapshot
+ * ball vx (TT:1020), `substeps` physics substeps (gym.simulate), progress += 1
+ * (TT:1023), reward + reset decision (TT:739-758), masked reset (TT:847-906),
+ * observations (TT:770-799) — one fused kernel launch.
+ * actions_dev: [N, 7] f32 row-major (the policy's tensor, not copied). */
+int ppenv_step(struct ppenv* env, const float* actions_dev, void* stream);
+
+/* Reset every env to its initial state with a fresh serve and recompute
+ * observations (VecTask.reset()). */
+int ppenv_reset_all(struct ppenv* env, void* stream);
+
+/* ---- Isaac-Gym tensor-API mode --------------------------------------------- */
+
+/* post_physics_step on caller-supplied simulator tensors in the reference's own
+ * layouts: the drop-in for TT:1022-1039 when the physics comes from elsewhere
+ * (and the entry the golden-vector parity tests drive).
+ *   rigid_body_states_dev [N, 42, 13], root_states_dev [N, 3, 13] (read AND
+ *   written: reset rows are restored in place like TT:853-862),
+ *   dof_states_dev [N, 7, 2] (same), dof_force_dev [N, 7],
+ *   pre_ball_vx_dev [N] (ball vx captured in pre_physics_step, TT:1020).
+ * Uses and updates the handle's progress/flags/episode buffers and writes
+ * obs_buf / rew_buf / reset_buf.  The handle's own SoA physics state is not
+ * touched. */
+int ppenv_post_physics_step(struct ppenv* env, const float* rigid_body_states_dev, float* root_states_dev,
+                            float* dof_states_dev, const float* dof_force_dev, const float* pre_ball_vx_dev,
+                            void* stream);
+
+/* gym.refresh_* equivalents (TT:801-807): materialise the reference-layout
+ * tensors from the SoA state on demand. */
+int ppenv_refresh_root_states(struct ppenv* env, float* root_states_dev /* [N,3,13] */, void* stream);
+int ppenv_refresh_dof_states(struct ppenv* env, float* dof_states_dev /* [N,7,2] */, void* stream);
+int ppenv_refresh_dof_force(struct ppenv* env, float* dof_force_dev /* [N,7] */, void* stream);
+/* Only the 10 observed humanoid bodies, the table and the ball rows are
+ * meaningful; the other humanoid rows are written as the static root pose. */
+int ppenv_refresh_rigid_body_states(struct ppenv* env, float* rb_states_dev /* [N,42,13] */, void* stream);
+
+/* ---- state I/O (parity tests, checkpoint) ----------------------------------- */
+
+/* Serve velocities to use at the next resets instead of the RNG
+ * (the reference draws them from Python `random`, TT:857-862). on = 0 disables. */
+int ppenv_set_serve_override(struct ppenv* env, const float* serve_dev /* [N,3] row-major or NULL */, int on, void* stream);
+
+/* Host-side blob of the full per-env state, SoA, in this order:
+ *   dof_pos f32[7][N], dof_vel f32[7][N], dof_force f32[7][N], ball f32[13][N],
+ *   flags u32[N], episode u32[N], progress i64[N], reset i64[N]. */
+size_t ppenv_state_bytes(struct ppenv* env);
+int ppenv_get_state(struct ppenv* env, void* dst_host, size_t n);
+int ppenv_set_state(struct ppenv* env, const void* src_host, size_t n);
+
+const char* ppenv_last_error(void);
+int ppenv_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPENV_H */

@@ -1,0 +1,223 @@
+"""ctypes binding of oracle/libppenv_oracle.so.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package (isaacgym_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from isaacgym_amd import scene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libppenv_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "ppenv_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "ppenv.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+class OracleBuffers(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32),
+        ("obs_buf", C.POINTER(C.c_float)), ("rew_buf", C.POINTER(C.c_float)),
+        ("reset_buf", C.POINTER(C.c_int64)), ("progress_buf", C.POINTER(C.c_int64)),
+        ("dof_pos", C.POINTER(C.c_float)), ("dof_vel", C.POINTER(C.c_float)),
+        ("dof_force", C.POINTER(C.c_float)), ("ball", C.POINTER(C.c_float)),
+        ("flags", C.POINTER(C.c_uint32)), ("episode", C.POINTER(C.c_uint32)),
+        ("serve_override", C.POINTER(C.c_float)),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.ppo_create.restype = C.c_void_p
+        L.ppo_create.argtypes = [C.POINTER(scene.Config)]
+        for name in ("ppo_destroy", "ppo_init", "ppo_reset_all"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.ppo_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.ppo_buffers_of.argtypes = [C.c_void_p, C.POINTER(OracleBuffers)]
+        L.ppo_step.argtypes = [C.c_void_p, C.c_void_p]
+        L.ppo_set_serve_override.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ppo_post_physics_step.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        for name in ("ppo_refresh_root_states", "ppo_refresh_dof_states", "ppo_refresh_dof_force",
+                     "ppo_refresh_rigid_body_states"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        L.ppo_state_bytes.restype = C.c_size_t
+        L.ppo_state_bytes.argtypes = [C.c_void_p]
+        L.ppo_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ppo_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        dp = C.POINTER(C.c_double)
+        L.ppo_arm_qdd.argtypes = [C.POINTER(scene.Config), dp, dp, dp, dp, dp]
+        L.ppo_arm_inverse_dynamics.argtypes = [C.POINTER(scene.Config), dp, dp, dp, dp]
+        L.ppo_arm_body_states.argtypes = [C.POINTER(scene.Config), dp, dp, C.POINTER(C.c_float)]
+        L.ppo_arm_energy.restype = C.c_double
+        L.ppo_arm_energy.argtypes = [C.POINTER(scene.Config), dp, dp]
+        L.ppo_serve_velocity.argtypes = [C.POINTER(scene.Config), C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        L.ppo_compute_obs.argtypes = [C.c_void_p] * 5
+        _lib = L
+    return _lib
+
+
+def _np_view(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    arr = np.ctypeslib.as_array(ptr, shape=(n,))
+    return arr.view(dtype).reshape(shape)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleEnv:
+    """numpy-facing wrapper; array attributes alias the oracle's memory."""
+
+    def __init__(self, config, threads=1):
+        self.L = lib()
+        self.config = config
+        self.h = self.L.ppo_create(C.byref(config))
+        if not self.h:
+            raise ValueError("ppo_create rejected the config")
+        self.L.ppo_set_threads(self.h, threads)
+        self.L.ppo_init(self.h)
+        b = OracleBuffers()
+        self.L.ppo_buffers_of(self.h, C.byref(b))
+        n = self.num_envs = b.num_envs
+        self.obs_buf = _np_view(b.obs_buf, (n, scene.NUM_OBS), np.float32)
+        self.rew_buf = _np_view(b.rew_buf, (n,), np.float32)
+        self.reset_buf = _np_view(b.reset_buf, (n,), np.int64)
+        self.progress_buf = _np_view(b.progress_buf, (n,), np.int64)
+        self.dof_pos = _np_view(b.dof_pos, (scene.NUM_DOF, n), np.float32)
+        self.dof_vel = _np_view(b.dof_vel, (scene.NUM_DOF, n), np.float32)
+        self.dof_force = _np_view(b.dof_force, (scene.NUM_DOF, n), np.float32)
+        self.ball = _np_view(b.ball, (13, n), np.float32)
+        self.flags = _np_view(b.flags, (n,), np.uint32)
+        self.episode = _np_view(b.episode, (n,), np.uint32)
+
+    def close(self):
+        if self.h:
+            self.L.ppo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_threads(self, t):
+        self.L.ppo_set_threads(self.h, t)
+
+    def step(self, actions):
+        a = _f32(actions)
+        assert a.shape == (self.num_envs, scene.NUM_DOF)
+        self.L.ppo_step(self.h, a.ctypes.data)
+
+    def reset_all(self):
+        self.L.ppo_reset_all(self.h)
+
+    def set_serve_override(self, serve, on=True):
+        if serve is None:
+            self.L.ppo_set_serve_override(self.h, None, int(on))
+        else:
+            s = _f32(serve)
+            assert s.shape == (self.num_envs, 3)
+            self.L.ppo_set_serve_override(self.h, s.ctypes.data, int(on))
+
+    def post_physics_step(self, rb_states, root_states, dof_states, dof_force, pre_ball_vx):
+        """root_states / dof_states must be C-contiguous float32 arrays; they are updated in place."""
+        for a in (rb_states, root_states, dof_states, dof_force, pre_ball_vx):
+            assert a.dtype == np.float32 and a.flags.c_contiguous
+        self.L.ppo_post_physics_step(self.h, rb_states.ctypes.data, root_states.ctypes.data, dof_states.ctypes.data,
+                                     dof_force.ctypes.data, pre_ball_vx.ctypes.data)
+
+    def refresh_root_states(self):
+        out = np.empty((self.num_envs, scene.NUM_ACTORS, 13), np.float32)
+        self.L.ppo_refresh_root_states(self.h, out.ctypes.data)
+        return out
+
+    def refresh_dof_states(self):
+        out = np.empty((self.num_envs, scene.NUM_DOF, 2), np.float32)
+        self.L.ppo_refresh_dof_states(self.h, out.ctypes.data)
+        return out
+
+    def refresh_dof_force(self):
+        out = np.empty((self.num_envs, scene.NUM_DOF), np.float32)
+        self.L.ppo_refresh_dof_force(self.h, out.ctypes.data)
+        return out
+
+    def refresh_rigid_body_states(self):
+        out = np.empty((self.num_envs, scene.NUM_BODIES, 13), np.float32)
+        self.L.ppo_refresh_rigid_body_states(self.h, out.ctypes.data)
+        return out
+
+    def get_state(self):
+        n = self.L.ppo_state_bytes(self.h)
+        buf = np.empty(n, np.uint8)
+        rc = self.L.ppo_get_state(self.h, buf.ctypes.data, n)
+        assert rc == 0
+        return buf
+
+    def set_state(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        rc = self.L.ppo_set_state(self.h, blob.ctypes.data, blob.size)
+        if rc != 0:
+            raise ValueError("state blob size mismatch")
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def arm_qdd(config, q, qd, tau, arm_eff):
+    q, qd, tau, arm_eff = (np.ascontiguousarray(x, np.float64) for x in (q, qd, tau, arm_eff))
+    out = np.zeros(scene.NUM_DOF)
+    lib().ppo_arm_qdd(C.byref(config), _dp(q), _dp(qd), _dp(tau), _dp(arm_eff), _dp(out))
+    return out
+
+
+def arm_inverse_dynamics(config, q, qd, qdd):
+    q, qd, qdd = (np.ascontiguousarray(x, np.float64) for x in (q, qd, qdd))
+    out = np.zeros(scene.NUM_DOF)
+    lib().ppo_arm_inverse_dynamics(C.byref(config), _dp(q), _dp(qd), _dp(qdd), _dp(out))
+    return out
+
+
+def arm_body_states(config, q, qd):
+    q, qd = (np.ascontiguousarray(x, np.float64) for x in (q, qd))
+    out = np.zeros((scene.NUM_OBS_BODIES, 13), np.float32)
+    lib().ppo_arm_body_states(C.byref(config), _dp(q), _dp(qd), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def arm_energy(config, q, qd):
+    q, qd = (np.ascontiguousarray(x, np.float64) for x in (q, qd))
+    return lib().ppo_arm_energy(C.byref(config), _dp(q), _dp(qd))
+
+
+def serve_velocity(config, gid, episode):
+    out = (C.c_float * 3)()
+    lib().ppo_serve_velocity(C.byref(config), gid, episode, out)
+    return np.array(list(out), np.float32)
+
+
+def compute_obs(bodies, dof_pos, dof_vel, ball):
+    bodies, dof_pos, dof_vel, ball = (_f32(x) for x in (bodies, dof_pos, dof_vel, ball))
+    out = np.zeros(scene.NUM_OBS, np.float32)
+    lib().ppo_compute_obs(bodies.ctypes.data, dof_pos.ctypes.data, dof_vel.ctypes.data, ball.ctypes.data, out.ctypes.data)
+    return out

@@ -1,0 +1,901 @@
+/*
+ * ppenv_oracle.c — CPU restatement of the HumanoidPingpong VecTask step.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and only as the checker / reported CPU baseline.  The product path
+ * (isaacgym_amd/) never links, imports or falls back to this file.
+ *
+ * What it restates, and from where (paths relative to /root/reference):
+ *   - step order          tasks/humanoid_pingpong_3_actor_tilt.py:1002-1052 (TT)
+ *   - action -> PD target  TT:1003-1014, limits -> offset/scale TT:649-671
+ *   - reward / reset rule  TT:1105-1270 (TT), T3 = tasks/humanoid_interos_edit_pingpong_only_3_actor.py:1080-1173,
+ *                          TN = tasks/humanoid_pingpong_3_actor_tilt_no_earlystop.py:1115-1322
+ *   - masked reset         TT:847-906, T3:825-881, TN:871-917 (TN leaves dof state alone)
+ *   - serve velocity       TT:296-323, T3:289-305, TN:301-328
+ *   - observations         TT:1640-1708, with calc_heading_quat_inv / my_quat_rotate restated from the
+ *                          published isaacgymenvs.utils.torch_jit_utils (un-vendored dependency, unpinned)
+ *
+ * PARITY PINNING.  The reward / observation / reset part is pinned against the
+ * reference's own torch functions: tests/golden/*.npz hold their outputs on
+ * scripted state sequences (tools/gen_golden.py imports the reference in the
+ * build container).  The rigid-body part (gym.simulate) is closed-source Isaac
+ * Gym / PhysX, absent from the reference and from this pipeline, and no
+ * reference test pins its results: for physics this oracle restates the
+ * build's own written specification (DESIGN.md "Physics specification") —
+ * PARITY UNPINNED for that part.  To make it a real check it deliberately uses
+ * a different algorithm and precision from the HIP kernel: recursive
+ * Newton-Euler in world coordinates + joint-space inertia matrix + dense
+ * solve, in double precision (the kernel runs the articulated-body algorithm
+ * in link coordinates in fp32).
+ *
+ * Reward, reset and observation arithmetic is fp32 in the reference's operation
+ * order, so thresholds flip at the same inputs.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/ppenv.h"
+
+#define ND PPENV_NUM_DOF
+#define NB PPENV_NUM_OBS_BODIES
+
+typedef struct ppo_env {
+    ppenv_config cfg;
+    int n;
+    float *obs, *rew;
+    int64_t *reset, *progress;
+    float *dof_pos, *dof_vel, *dof_force, *ball; /* SoA [k][N] */
+    uint32_t *flags, *episode;
+    float *serve; /* [3][N] */
+    int serve_on;
+    int threads;
+} ppo_env;
+
+/* ------------------------------------------------------------------ small math */
+typedef struct { double x, y, z; } v3;
+typedef struct { double m[9]; } m3;
+
+static v3 V(double x, double y, double z) { v3 r = {x, y, z}; return r; }
+static v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static v3 vscale(v3 a, double s) { return V(a.x * s, a.y * s, a.z * s); }
+static double vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static double vnorm(v3 a) { return sqrt(vdot(a, a)); }
+static v3 vf(const float* p) { return V(p[0], p[1], p[2]); }
+static v3 mv(const m3* a, v3 v) {
+    return V(a->m[0] * v.x + a->m[1] * v.y + a->m[2] * v.z, a->m[3] * v.x + a->m[4] * v.y + a->m[5] * v.z,
+             a->m[6] * v.x + a->m[7] * v.y + a->m[8] * v.z);
+}
+static m3 mm(const m3* a, const m3* b) {
+    m3 r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += a->m[3 * i + k] * b->m[3 * k + j];
+            r.m[3 * i + j] = s;
+        }
+    return r;
+}
+static m3 mt(const m3* a) {
+    m3 r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r.m[3 * i + j] = a->m[3 * j + i];
+    return r;
+}
+static m3 mf(const float* p) {
+    m3 r;
+    for (int i = 0; i < 9; i++) r.m[i] = p[i];
+    return r;
+}
+static m3 axis_rot(int axis, double q) {
+    double c = cos(q), s = sin(q);
+    m3 r = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    if (axis == 0) { r.m[4] = c; r.m[5] = -s; r.m[7] = s; r.m[8] = c; }
+    else if (axis == 1) { r.m[0] = c; r.m[2] = s; r.m[6] = -s; r.m[8] = c; }
+    else { r.m[0] = c; r.m[1] = -s; r.m[3] = s; r.m[4] = c; }
+    return r;
+}
+/* rotation matrix -> xyzw quaternion, w >= 0 */
+static void rot_to_quat(const m3* r, double q[4]) {
+    double tr = r->m[0] + r->m[4] + r->m[8];
+    double x, y, z, w;
+    if (tr > 0) {
+        double s = sqrt(tr + 1.0) * 2;
+        w = 0.25 * s; x = (r->m[7] - r->m[5]) / s; y = (r->m[2] - r->m[6]) / s; z = (r->m[3] - r->m[1]) / s;
+    } else if (r->m[0] > r->m[4] && r->m[0] > r->m[8]) {
+        double s = sqrt(1.0 + r->m[0] - r->m[4] - r->m[8]) * 2;
+        w = (r->m[7] - r->m[5]) / s; x = 0.25 * s; y = (r->m[1] + r->m[3]) / s; z = (r->m[2] + r->m[6]) / s;
+    } else if (r->m[4] > r->m[8]) {
+        double s = sqrt(1.0 + r->m[4] - r->m[0] - r->m[8]) * 2;
+        w = (r->m[2] - r->m[6]) / s; x = (r->m[1] + r->m[3]) / s; y = 0.25 * s; z = (r->m[5] + r->m[7]) / s;
+    } else {
+        double s = sqrt(1.0 + r->m[8] - r->m[0] - r->m[4]) * 2;
+        w = (r->m[3] - r->m[1]) / s; x = (r->m[2] + r->m[6]) / s; y = (r->m[5] + r->m[7]) / s; z = 0.25 * s;
+    }
+    if (w < 0) { x = -x; y = -y; z = -z; w = -w; }
+    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
+
+/* ------------------------------------------------------------------------ RNG
+ * Counter-based, keyed by (seed, global env id, episode index, draw index).
+ * The reference draws from Python's global `random` sequentially on the host
+ * (TT:307-312,857-859), which no vectorised implementation can reproduce; the
+ * parity tests inject serve velocities instead (ppenv_set_serve_override). */
+static uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+static float rng_uniform(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t k) {
+    uint64_t s = mix64(seed + 0x9E3779B97F4A7C15ull * ((uint64_t)gid + 1));
+    uint64_t x = mix64(s + 0x9E3779B97F4A7C15ull * ((uint64_t)episode * 4 + k + 1));
+    return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+/* generate_random_speed_for_ball: TT:296-323 / T3:289-305 / TN:301-328 */
+static void serve_velocity(const ppenv_config* c, uint32_t gid, uint32_t episode, float out[3]) {
+    float u0 = rng_uniform(c->seed, gid, episode, 0);
+    float u1 = rng_uniform(c->seed, gid, episode, 1);
+    float u2 = rng_uniform(c->seed, gid, episode, 2);
+    double speed = c->serve_speed_lo + (c->serve_speed_hi - c->serve_speed_lo) * u0;
+    double a = (c->serve_tilt_lo_deg + (c->serve_tilt_hi_deg - c->serve_tilt_lo_deg) * u1) * (M_PI / 180.0);
+    double az = (c->serve_tilt_z_lo_deg + (c->serve_tilt_z_hi_deg - c->serve_tilt_z_lo_deg) * u2) * (M_PI / 180.0);
+    if (c->variant == PPENV_VARIANT_T3) {            /* T3:296-300 */
+        double s = -speed;
+        out[0] = (float)(s * cos(a)); out[1] = (float)(s * sin(a)); out[2] = 0.0f;
+    } else if (c->variant == PPENV_VARIANT_TT) {     /* TT:307-318 (sic: sin a sin az, then sin a) */
+        double s = -speed;
+        out[0] = (float)(s * cos(a) * cos(az)); out[1] = (float)(s * sin(a) * sin(az)); out[2] = (float)(s * sin(a));
+    } else {                                         /* TN:312-323 */
+        double s = speed;
+        out[0] = (float)(-s * cos(a) * cos(az)); out[1] = (float)(s * sin(a) * cos(az)); out[2] = (float)(s * sin(az));
+    }
+}
+
+/* ------------------------------------------------------- arm kinematics (world) */
+typedef struct {
+    m3 R[ND];      /* world <- link */
+    v3 p[ND];      /* link origin, world */
+    v3 z[ND];      /* joint axis, world */
+    v3 w[ND];      /* angular velocity, world */
+    v3 v[ND];      /* linear velocity of link origin, world */
+} arm_fk;
+
+static void arm_forward_kinematics(const ppenv_config* c, const double* q, const double* qd, arm_fk* k) {
+    m3 Rp = mf(c->base_rot);
+    v3 pp = vf(c->base_pos), wp = V(0, 0, 0), vp = V(0, 0, 0);
+    for (int i = 0; i < ND; i++) {
+        const ppenv_joint* j = &c->joint[i];
+        m3 R0 = mf(j->origin_rot), Rq = axis_rot(j->axis, q[i]);
+        m3 E = mm(&R0, &Rq);
+        v3 d = mv(&Rp, vf(j->origin_xyz));
+        k->p[i] = vadd(pp, d);
+        k->R[i] = mm(&Rp, &E);
+        v3 e = V(j->axis == 0, j->axis == 1, j->axis == 2);
+        k->z[i] = mv(&k->R[i], e);
+        k->v[i] = vadd(vp, vcross(wp, d));
+        k->w[i] = vadd(wp, vscale(k->z[i], qd[i]));
+        Rp = k->R[i]; pp = k->p[i]; wp = k->w[i]; vp = k->v[i];
+    }
+}
+
+/* Recursive Newton-Euler, world coordinates: tau = RNEA(q, qd, qdd) with gravity
+ * folded in as a base acceleration of -g when grav != 0. */
+static void arm_rnea(const ppenv_config* c, const arm_fk* k, const double* qd, const double* qdd, double grav,
+                     int use_vel, double* tau) {
+    v3 alpha[ND], acc[ND], F[ND], N[ND], comw[ND];
+    v3 wp = V(0, 0, 0), alp = V(0, 0, 0), ap = V(0, 0, grav), pp = vf(c->base_pos); /* base accelerates up by |g| */
+    for (int i = 0; i < ND; i++) {
+        const ppenv_joint* j = &c->joint[i];
+        v3 d = vsub(k->p[i], pp);
+        v3 wi = use_vel ? k->w[i] : V(0, 0, 0);
+        double qdi = use_vel ? qd[i] : 0.0;
+        alpha[i] = vadd(vadd(alp, vscale(k->z[i], qdd[i])), vcross(wp, vscale(k->z[i], qdi)));
+        acc[i] = vadd(vadd(ap, vcross(alp, d)), vcross(wp, vcross(wp, d)));
+        comw[i] = mv(&k->R[i], vf(j->com));
+        v3 ac = vadd(vadd(acc[i], vcross(alpha[i], comw[i])), vcross(wi, vcross(wi, comw[i])));
+        m3 I = {{j->inertia[0], j->inertia[3], j->inertia[4], j->inertia[3], j->inertia[1], j->inertia[5],
+                 j->inertia[4], j->inertia[5], j->inertia[2]}};
+        m3 Rt = mt(&k->R[i]);
+        m3 RI = mm(&k->R[i], &I);
+        m3 Iw = mm(&RI, &Rt);
+        F[i] = vscale(ac, j->mass);
+        N[i] = vadd(mv(&Iw, alpha[i]), vcross(wi, mv(&Iw, wi)));
+        wp = wi; alp = alpha[i]; ap = acc[i]; pp = k->p[i];
+    }
+    v3 f = V(0, 0, 0), n = V(0, 0, 0); /* force / moment (about origin of link i) transmitted through joint i */
+    for (int i = ND - 1; i >= 0; i--) {
+        if (i < ND - 1) n = vadd(n, vcross(vsub(k->p[i + 1], k->p[i]), f)); /* shift child's moment to this origin */
+        f = vadd(f, F[i]);
+        n = vadd(n, vadd(N[i], vcross(comw[i], F[i])));
+        tau[i] = vdot(k->z[i], n);
+    }
+}
+
+/* qdd from (M + diag(arm)) qdd = tau - C */
+static void arm_forward_dynamics(const ppenv_config* c, const arm_fk* k, const double* qd, const double* tau,
+                                 const double* arm_eff, double* qdd) {
+    double C[ND], zero[ND] = {0}, M[ND][ND + 1], col[ND], unit[ND];
+    arm_rnea(c, k, qd, zero, -(double)c->gravity_z, 1, C);
+    for (int j = 0; j < ND; j++) {
+        memset(unit, 0, sizeof unit);
+        unit[j] = 1.0;
+        arm_rnea(c, k, qd, unit, 0.0, 0, col);
+        for (int i = 0; i < ND; i++) M[i][j] = col[i];
+    }
+    for (int i = 0; i < ND; i++) { M[i][i] += arm_eff[i]; M[i][ND] = tau[i] - C[i]; }
+    for (int p = 0; p < ND; p++) { /* Gaussian elimination with partial pivoting */
+        int best = p;
+        for (int r = p + 1; r < ND; r++) if (fabs(M[r][p]) > fabs(M[best][p])) best = r;
+        if (best != p) for (int cidx = 0; cidx <= ND; cidx++) { double t = M[p][cidx]; M[p][cidx] = M[best][cidx]; M[best][cidx] = t; }
+        for (int r = p + 1; r < ND; r++) {
+            double fct = M[r][p] / M[p][p];
+            for (int cidx = p; cidx <= ND; cidx++) M[r][cidx] -= fct * M[p][cidx];
+        }
+    }
+    for (int i = ND - 1; i >= 0; i--) {
+        double s = M[i][ND];
+        for (int j = i + 1; j < ND; j++) s -= M[i][j] * qdd[j];
+        qdd[i] = s / M[i][i];
+    }
+}
+
+/* world pose / velocity of a frame attached to a chain link (or static) */
+static void frame_state(const ppenv_config* c, const arm_fk* k, const ppenv_frame* f, v3* pos, m3* rot, v3* lin, v3* ang) {
+    m3 Rf = mf(f->rot);
+    if (f->link < 0) {
+        *pos = vf(f->xyz); *rot = Rf; *lin = V(0, 0, 0); *ang = V(0, 0, 0);
+        return;
+    }
+    (void)c;
+    v3 off = mv(&k->R[f->link], vf(f->xyz));
+    *pos = vadd(k->p[f->link], off);
+    *rot = mm(&k->R[f->link], &Rf);
+    *ang = k->w[f->link];
+    *lin = vadd(k->v[f->link], vcross(k->w[f->link], off));
+}
+static v3 link_point(const arm_fk* k, int link, const float* local) {
+    if (link < 0) return vf(local);
+    return vadd(k->p[link], mv(&k->R[link], vf(local)));
+}
+
+/* ---------------------------------------------------------------- ball contacts */
+typedef struct { v3 p, v, w; } ball_t;
+
+/* Resolve one contact: n = unit normal surface -> ball, s = separation, u = surface velocity. */
+static void contact_resolve(const ppenv_config* c, ball_t* b, v3 n, double s, v3 u, double e, double mu, double hb) {
+    if (!(s < c->contact_offset)) return;
+    double r = c->ball_radius, kappa = c->ball_inertia_factor;
+    v3 vrel = vsub(vadd(b->v, vcross(b->w, vscale(n, -r))), u);
+    double vn = vdot(vrel, n);
+    if (vn < 0) {
+        double e_eff = (-vn > c->bounce_threshold) ? e : 0.0;
+        double jn = -(1.0 + e_eff) * vn;
+        v3 vt = vsub(vrel, vscale(n, vn));
+        double vtl = vnorm(vt);
+        double jt = 0;
+        v3 dir = V(0, 0, 0);
+        if (vtl > 1e-9) {
+            dir = vscale(vt, 1.0 / vtl);
+            double stick = vtl / (1.0 + 1.0 / kappa);
+            jt = mu * jn < stick ? mu * jn : stick;
+        }
+        b->v = vadd(b->v, vsub(vscale(n, jn), vscale(dir, jt)));
+        b->w = vadd(b->w, vscale(vcross(n, dir), jt / (kappa * r)));
+    }
+    if (s < 0) {
+        double push = -s, cap = c->max_depenetration_velocity * hb;
+        b->p = vadd(b->p, vscale(n, push < cap ? push : cap));
+    }
+}
+static double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+static void contact_box(const ppenv_config* c, ball_t* b, const ppenv_box* box, double hb) {
+    v3 d = vsub(b->p, vf(box->center));
+    v3 h = vf(box->half);
+    v3 q = V(clampd(d.x, -h.x, h.x), clampd(d.y, -h.y, h.y), clampd(d.z, -h.z, h.z));
+    v3 diff = vsub(d, q);
+    double dist = vnorm(diff);
+    v3 n; double s;
+    if (dist > 1e-12) { n = vscale(diff, 1.0 / dist); s = dist - c->ball_radius; }
+    else { /* centre inside the box: leave through the nearest face */
+        double px = h.x - fabs(d.x), py = h.y - fabs(d.y), pz = h.z - fabs(d.z);
+        if (px <= py && px <= pz) { n = V(d.x >= 0 ? 1 : -1, 0, 0); s = -px - c->ball_radius; }
+        else if (py <= pz) { n = V(0, d.y >= 0 ? 1 : -1, 0); s = -py - c->ball_radius; }
+        else { n = V(0, 0, d.z >= 0 ? 1 : -1); s = -pz - c->ball_radius; }
+    }
+    contact_resolve(c, b, n, s, V(0, 0, 0), box->restitution, box->friction, hb);
+}
+static void contact_capsule(const ppenv_config* c, ball_t* b, v3 a, v3 bb, v3 ua, v3 ub, double radius, double e,
+                            double mu, double hb) {
+    v3 ab = vsub(bb, a);
+    double l2 = vdot(ab, ab), t = 0;
+    if (l2 > 1e-12) t = clampd(vdot(vsub(b->p, a), ab) / l2, 0, 1);
+    v3 cp = vadd(a, vscale(ab, t));
+    v3 diff = vsub(b->p, cp);
+    double dist = vnorm(diff);
+    v3 n = dist > 1e-12 ? vscale(diff, 1.0 / dist) : V(0, 0, 1);
+    v3 u = vadd(ua, vscale(vsub(ub, ua), t));
+    contact_resolve(c, b, n, dist - radius - c->ball_radius, u, e, mu, hb);
+}
+/* solid disc (flat cylinder): centre cc, unit axis nn, linear velocity uc of the centre, axis rate nd */
+static void contact_disc(const ppenv_config* c, ball_t* b, v3 cc, v3 nn, v3 uc, v3 nd, double hb) {
+    double R = c->paddle_radius, tp = c->paddle_half_thickness;
+    v3 d = vsub(b->p, cc);
+    double hgt = vdot(d, nn);
+    v3 radial = vsub(d, vscale(nn, hgt));
+    double rr = vnorm(radial);
+    v3 n, closest; double s;
+    if (fabs(hgt) < tp && rr < R) { /* centre inside the blade: leave through the nearer face */
+        double sg = hgt >= 0 ? 1.0 : -1.0;
+        n = vscale(nn, sg);
+        s = -(tp - fabs(hgt)) - c->ball_radius;
+        closest = vadd(cc, vadd(vscale(nn, sg * tp), radial));
+    } else {
+        double hc = clampd(hgt, -tp, tp);
+        double rc = rr < R ? rr : R;
+        v3 rdir = rr > 1e-12 ? vscale(radial, rc / rr) : V(0, 0, 0);
+        closest = vadd(cc, vadd(vscale(nn, hc), rdir));
+        v3 diff = vsub(b->p, closest);
+        double dist = vnorm(diff);
+        n = dist > 1e-12 ? vscale(diff, 1.0 / dist) : nn;
+        s = dist - c->ball_radius;
+    }
+    v3 omega_perp = vcross(nn, nd);
+    v3 u = vadd(uc, vcross(omega_perp, vsub(closest, cc)));
+    contact_resolve(c, b, n, s, u, c->paddle_restitution, c->paddle_friction, hb);
+}
+
+/* moving collision geometry sampled at both ends of a substep */
+typedef struct {
+    v3 pc, pn;                    /* paddle centre, axis */
+    v3 sa[PPENV_MAX_SHAPES], sb[PPENV_MAX_SHAPES];
+} arm_geom;
+
+static void arm_geometry(const ppenv_config* c, const arm_fk* k, arm_geom* g) {
+    g->pc = link_point(k, c->paddle_link, c->paddle_center);
+    g->pn = mv(&k->R[c->paddle_link], vf(c->paddle_normal));
+    for (int s = 0; s < c->num_shapes; s++) {
+        g->sa[s] = link_point(k, c->shape[s].link, c->shape[s].a);
+        g->sb[s] = link_point(k, c->shape[s].link, c->shape[s].b);
+    }
+}
+static v3 vlerp(v3 a, v3 b, double f) { return vadd(a, vscale(vsub(b, a), f)); }
+
+static void ball_substep(const ppenv_config* c, ball_t* b, double quat[4], const arm_geom* g0, const arm_geom* g1, double h) {
+    int M = c->ball_substeps;
+    double hb = h / M;
+    for (int m = 0; m < M; m++) {
+        double f = (double)m / M;
+        b->v.z += c->gravity_z * hb;
+        double damp = 1.0 - c->ball_angular_damping * hb;
+        b->w = vscale(b->w, damp > 0 ? damp : 0);
+        /* ground */
+        contact_resolve(c, b, V(0, 0, 1), b->p.z - c->ground_z - c->ball_radius, V(0, 0, 0), c->ground_restitution,
+                        c->ground_friction, hb);
+        contact_box(c, b, &c->table, hb);
+        contact_box(c, b, &c->net, hb);
+        if (vnorm(vsub(b->p, vf(c->humanoid_bound_center))) < c->humanoid_bound_radius) {
+            v3 cc = vlerp(g0->pc, g1->pc, f);
+            v3 nn = vlerp(g0->pn, g1->pn, f);
+            nn = vscale(nn, 1.0 / vnorm(nn));
+            contact_disc(c, b, cc, nn, vscale(vsub(g1->pc, g0->pc), 1.0 / h), vscale(vsub(g1->pn, g0->pn), 1.0 / h), hb);
+            for (int s = 0; s < c->num_shapes; s++) {
+                const ppenv_shape* sh = &c->shape[s];
+                v3 a = vlerp(g0->sa[s], g1->sa[s], f), bb = vlerp(g0->sb[s], g1->sb[s], f);
+                v3 ua = vscale(vsub(g1->sa[s], g0->sa[s]), 1.0 / h), ub = vscale(vsub(g1->sb[s], g0->sb[s]), 1.0 / h);
+                contact_capsule(c, b, a, bb, ua, ub, sh->radius, sh->restitution, sh->friction, hb);
+            }
+        }
+        b->p = vadd(b->p, vscale(b->v, hb));
+    }
+    /* orientation: q <- normalize(q + h/2 * (w,0) (x) q), xyzw */
+    double wx = b->w.x, wy = b->w.y, wz = b->w.z, x = quat[0], y = quat[1], z = quat[2], w = quat[3];
+    double dx = 0.5 * h * (wx * w + wy * z - wz * y);
+    double dy = 0.5 * h * (wy * w + wz * x - wx * z);
+    double dz = 0.5 * h * (wz * w + wx * y - wy * x);
+    double dw = 0.5 * h * (-wx * x - wy * y - wz * z);
+    x += dx; y += dy; z += dz; w += dw;
+    double nrm = sqrt(x * x + y * y + z * z + w * w);
+    quat[0] = x / nrm; quat[1] = y / nrm; quat[2] = z / nrm; quat[3] = w / nrm;
+}
+
+/* ------------------------------------------------------ fp32 reward / obs / reset */
+/* my_quat_rotate (torch_jit_utils): a = v (2 w^2 - 1), b = 2 w (qv x v), c = 2 qv (qv . v) */
+static void quat_rotate_f(const float q[4], const float v[3], float out[3]) {
+    float qw = q[3];
+    float s = 2.0f * (qw * qw) - 1.0f;
+    float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+    float dot = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+    out[0] = v[0] * s + cx * qw * 2.0f + q[0] * dot * 2.0f;
+    out[1] = v[1] * s + cy * qw * 2.0f + q[1] * dot * 2.0f;
+    out[2] = v[2] * s + cz * qw * 2.0f + q[2] * dot * 2.0f;
+}
+/* calc_heading_quat_inv (torch_jit_utils) */
+static void heading_quat_inv_f(const float q[4], float out[4]) {
+    float ref[3] = {1.0f, 0.0f, 0.0f}, rd[3];
+    quat_rotate_f(q, ref, rd);
+    float heading = atan2f(rd[1], rd[0]);
+    float theta = (-heading) / 2.0f;
+    float xyz2 = sinf(theta), w = cosf(theta);
+    float nrm = sqrtf(xyz2 * xyz2 + w * w);
+    if (nrm < 1e-9f) nrm = 1e-9f;
+    out[0] = 0.0f / nrm; out[1] = 0.0f / nrm; out[2] = xyz2 / nrm; out[3] = w / nrm;
+}
+
+/* observed body states for one env: [NB][13] pos3 quat4 lin3 ang3 */
+typedef float bodies_t[NB][13];
+
+/* compute_observations: TT:770-799 -> 1640-1708 */
+static void compute_obs(const bodies_t bs, const float* dof_pos, const float* dof_vel, const float* ball, float* obs) {
+    const float* root_pos = &bs[0][0];
+    float hinv[4];
+    heading_quat_inv_f(&bs[0][3], hinv);
+    for (int j = 0; j < NB; j++) {   /* TT:1696-1697 */
+        float rel[3] = {bs[j][0] - root_pos[0], bs[j][1] - root_pos[1], bs[j][2] - root_pos[2]};
+        quat_rotate_f(hinv, rel, &obs[3 * j]);
+        quat_rotate_f(hinv, &bs[j][7], &obs[3 * NB + 3 * j]);
+    }
+    for (int d = 0; d < ND; d++) {   /* TT:1702-1703 */
+        obs[6 * NB + d] = dof_pos[d];
+        obs[6 * NB + ND + d] = dof_vel[d] * 0.1f;
+    }
+    float rel[3] = {ball[0] - root_pos[0], ball[1] - root_pos[1], ball[2] - root_pos[2]};
+    quat_rotate_f(hinv, rel, &obs[6 * NB + 2 * ND]);          /* TT:1657-1660 */
+    quat_rotate_f(hinv, &ball[7], &obs[6 * NB + 2 * ND + 3]);
+}
+
+static float power_term(const float* dof_force, const float* dof_vel) {
+    float p = 0.0f;
+    for (int d = 0; d < ND; d++) p += fabsf(dof_force[d] * dof_vel[d]);
+    return p;
+}
+
+/* Reward + reset decision for one env.  Inputs are the post-step, pre-reset
+ * state; flags are read-modify-write (sticky).  Returns reward, *reset_out 0/1. */
+static float compute_reward(const ppenv_config* c, float humanoid_x, const float* paddle_pos, float pre_vx,
+                            const float* ball, const float* dof_force, const float* dof_vel, int64_t progress,
+                            uint32_t* flags, int64_t* reset_out) {
+    const float Bx = ball[0], By = ball[1], Bz = ball[2], vx = ball[7];
+    const float alpha = c->alpha_velocity_reward, penalty = c->penalty;
+    const float threshold = 0.1f;
+    float power_reward = -c->power_coefficient * power_term(dof_force, dof_vel);
+    uint32_t f = *flags;
+    float reward;
+    int64_t die = 0;
+    if (c->variant == PPENV_VARIANT_T3) {                   /* T3:1080-1173 */
+        float dx = paddle_pos[0] - Bx, dy = paddle_pos[1] - By, dz = paddle_pos[2] - Bz;
+        float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);
+        float vel_reward = (pre_vx < 0.0f && vx > 0.0f) ? alpha * fabsf(vx) : 0.0f;      /* T3:1126-1128 */
+        reward = pos_reward + power_reward + vel_reward;                                   /* T3:1141 */
+        int missed = Bx < paddle_pos[0] - 1e-3f;                                           /* T3:1146 */
+        if (missed) reward = reward + penalty;
+        if (missed) die = 1;                                                               /* T3:1158 */
+        if (Bz < threshold) die = 1;                                                       /* T3:1161 */
+    } else if (c->variant == PPENV_VARIANT_TT) {            /* TT:1105-1270 */
+        float dx = paddle_pos[0] - Bx, dy = paddle_pos[1] - By, dz = paddle_pos[2] - Bz;
+        float dist = sqrtf(dx * dx + dy * dy + dz * dz);                                   /* TT:1144-1146 */
+        float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                             /* TT:1147 */
+        int cond = pre_vx < 0.0f && vx > 0.0f;                                             /* TT:1153 */
+        float vel_reward = (cond && !(f & PPENV_FLAG_COND_CALC)) ? alpha * fabsf(vx) : 0.0f;   /* TT:1156-1160 */
+        if (cond) f |= PPENV_FLAG_COND_CALC;                                               /* TT:1163 */
+        int missed = Bx < humanoid_x - 0.05f;                                              /* TT:1169 */
+        reward = missed ? 0.0f + penalty : 0.0f;                                           /* TT:1172-1173 */
+        int bounce = Bz < 0.83f && vx > 0.0f && By < 0.6f && By > -0.6f;                   /* TT:1184 */
+        float hit = 0.0f;
+        int early = Bx < 2.44f && bounce;
+        if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = c->not_hit_table_penalty;        /* TT:1187-1191 */
+        if (early) f |= PPENV_FLAG_REWARD_CALC;                                            /* TT:1192 */
+        if (early) f &= ~PPENV_FLAG_NO_BOUNCE;                                             /* TT:1196 */
+        int inx = Bx > 2.44f && Bx < 3.1f;                                                 /* TT:1199 */
+        int good = inx && bounce && (f & PPENV_FLAG_NO_BOUNCE);
+        if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = c->hit_table_reward;              /* TT:1201-1205 */
+        if (good) f |= PPENV_FLAG_REWARD_CALC;                                             /* TT:1206 */
+        if (Bx >= 3.1f && vx > 0.0f && !(f & PPENV_FLAG_REWARD_CALC)) hit = c->not_hit_table_penalty; /* TT:1209-1213 */
+        if (Bx >= 3.1f) f |= PPENV_FLAG_REWARD_CALC;                                       /* TT:1214 (no vx guard) */
+        float net = (Bx > 1.7f && Bx < 1.8f && vx > 0.0f && By < 0.4f && By > -0.4f && Bz > 0.98f && Bz < 1.14f)
+                        ? 400.0f : 0.0f;                                                   /* TT:1226-1244 */
+        reward += (((pos_reward + power_reward) + vel_reward) + hit) + net;               /* TT:1251 */
+        if (Bz < threshold) die = 1;                                                       /* TT:1263 */
+    } else {                                                /* TN:1115-1322 */
+        int hit_paddle = pre_vx < 0.0f && vx > 1.0f;                                       /* TN:1160 */
+        int missed = (Bx < humanoid_x - 0.05f) || (Bx < paddle_pos[0] - 0.1f);             /* TN:1165 */
+        reward = (!(f & PPENV_FLAG_MISSED_CALC) && missed) ? 0.0f + penalty : 0.0f;        /* TN:1172-1176 */
+        if (missed) f |= PPENV_FLAG_MISSED_CALC;                                           /* TN:1178 */
+        float dy = paddle_pos[1] - By, dz = paddle_pos[2] - Bz;
+        float dist = sqrtf(dy * dy + dz * dz);                                             /* TN:1185-1186 */
+        float pos_reward = 0.0f;
+        if (!(f & PPENV_FLAG_COND_CALC) || (Bx < humanoid_x - 0.05f))
+            pos_reward = 1.0f * expf(-20.0f * dist * dist);                                /* TN:1188-1192 */
+        float vel_reward = (hit_paddle && !(f & PPENV_FLAG_COND_CALC)) ? alpha * fabsf(vx) : 0.0f;  /* TN:1198-1202 */
+        if (hit_paddle) f |= PPENV_FLAG_COND_CALC;                                         /* TN:1204 */
+        reward += (pos_reward + power_reward) + vel_reward;                                /* TN:1299 */
+        if (Bz < threshold) reward = -800.0f + reward;                                     /* TN:1313-1315 */
+        /* no early stop: die stays 0 (TN:1317) */
+    }
+    *flags = f;
+    *reset_out = (progress >= (int64_t)c->max_episode_length - 1) ? 1 : die;  /* TT:1265 */
+    return reward;
+}
+
+static uint32_t initial_flags(const ppenv_config* c) {
+    (void)c;
+    return PPENV_FLAG_NO_BOUNCE; /* TT:241-243 / TN:244-248: all False except no_bounce_before_half_mask */
+}
+
+/* ------------------------------------------------------------------ lifecycle */
+ppo_env* ppo_create(const ppenv_config* cfg) {
+    if (!cfg || cfg->abi_version != PPENV_ABI_VERSION || cfg->num_envs <= 0) return NULL;
+    ppo_env* e = (ppo_env*)calloc(1, sizeof *e);
+    e->cfg = *cfg;
+    int n = e->n = cfg->num_envs;
+    e->threads = 1;
+    e->obs = (float*)calloc((size_t)n * PPENV_NUM_OBS, sizeof(float));
+    e->rew = (float*)calloc(n, sizeof(float));
+    e->reset = (int64_t*)calloc(n, sizeof(int64_t));
+    e->progress = (int64_t*)calloc(n, sizeof(int64_t));
+    e->dof_pos = (float*)calloc((size_t)n * ND, sizeof(float));
+    e->dof_vel = (float*)calloc((size_t)n * ND, sizeof(float));
+    e->dof_force = (float*)calloc((size_t)n * ND, sizeof(float));
+    e->ball = (float*)calloc((size_t)n * 13, sizeof(float));
+    e->flags = (uint32_t*)calloc(n, sizeof(uint32_t));
+    e->episode = (uint32_t*)calloc(n, sizeof(uint32_t));
+    e->serve = (float*)calloc((size_t)n * 3, sizeof(float));
+    return e;
+}
+void ppo_destroy(ppo_env* e) {
+    if (!e) return;
+    free(e->obs); free(e->rew); free(e->reset); free(e->progress); free(e->dof_pos); free(e->dof_vel);
+    free(e->dof_force); free(e->ball); free(e->flags); free(e->episode); free(e->serve); free(e);
+}
+void ppo_set_threads(ppo_env* e, int t) { e->threads = t > 0 ? t : 1; }
+
+typedef struct ppo_buffers {
+    int32_t num_envs;
+    float* obs_buf; float* rew_buf; int64_t* reset_buf; int64_t* progress_buf;
+    float* dof_pos; float* dof_vel; float* dof_force; float* ball;
+    uint32_t* flags; uint32_t* episode; float* serve_override;
+} ppo_buffers;
+void ppo_buffers_of(ppo_env* e, ppo_buffers* b) {
+    b->num_envs = e->n; b->obs_buf = e->obs; b->rew_buf = e->rew; b->reset_buf = e->reset;
+    b->progress_buf = e->progress; b->dof_pos = e->dof_pos; b->dof_vel = e->dof_vel; b->dof_force = e->dof_force;
+    b->ball = e->ball; b->flags = e->flags; b->episode = e->episode; b->serve_override = e->serve;
+}
+
+static void fresh_serve(ppo_env* e, int i, float v[3]) {
+    if (e->serve_on) { for (int k = 0; k < 3; k++) v[k] = e->serve[(size_t)k * e->n + i]; }
+    else serve_velocity(&e->cfg, (uint32_t)(e->cfg.env_id_offset + i), e->episode[i], v);
+}
+
+/* restore env i's simulation state to the initial one with a fresh serve (TT:853-867) */
+static void reset_env_state(ppo_env* e, int i, int reset_dofs) {
+    const ppenv_config* c = &e->cfg;
+    int n = e->n;
+    float v[3];
+    fresh_serve(e, i, v);
+    for (int k = 0; k < 3; k++) e->ball[(size_t)k * n + i] = c->ball_init_pos[k];
+    for (int k = 0; k < 4; k++) e->ball[(size_t)(3 + k) * n + i] = c->ball_init_quat[k];
+    for (int k = 0; k < 3; k++) e->ball[(size_t)(7 + k) * n + i] = v[k];
+    for (int k = 0; k < 3; k++) e->ball[(size_t)(10 + k) * n + i] = 0.0f;
+    if (reset_dofs)
+        for (int d = 0; d < ND; d++) {
+            e->dof_pos[(size_t)d * n + i] = c->init_dof_pos[d];
+            e->dof_vel[(size_t)d * n + i] = c->init_dof_vel[d];
+        }
+}
+
+static void gather_env(const ppo_env* e, int i, float* q, float* qd, float* ball) {
+    int n = e->n;
+    for (int d = 0; d < ND; d++) { q[d] = e->dof_pos[(size_t)d * n + i]; qd[d] = e->dof_vel[(size_t)d * n + i]; }
+    for (int k = 0; k < 13; k++) ball[k] = e->ball[(size_t)k * n + i];
+}
+
+static void bodies_from_fk(const ppenv_config* c, const arm_fk* k, bodies_t bs) {
+    for (int j = 0; j < NB; j++) {
+        v3 pos, lin, ang; m3 rot; double qt[4];
+        frame_state(c, k, &c->obs_body[j], &pos, &rot, &lin, &ang);
+        rot_to_quat(&rot, qt);
+        bs[j][0] = (float)pos.x; bs[j][1] = (float)pos.y; bs[j][2] = (float)pos.z;
+        for (int t = 0; t < 4; t++) bs[j][3 + t] = (float)qt[t];
+        bs[j][7] = (float)lin.x; bs[j][8] = (float)lin.y; bs[j][9] = (float)lin.z;
+        bs[j][10] = (float)ang.x; bs[j][11] = (float)ang.y; bs[j][12] = (float)ang.z;
+    }
+}
+
+/* observations of env i from the current SoA state (used by create / reset_all) */
+static void obs_from_state(ppo_env* e, int i) {
+    const ppenv_config* c = &e->cfg;
+    float qf[ND], qdf[ND], ball[13];
+    double q[ND], qd[ND];
+    gather_env(e, i, qf, qdf, ball);
+    for (int d = 0; d < ND; d++) { q[d] = qf[d]; qd[d] = qdf[d]; }
+    arm_fk k;
+    arm_forward_kinematics(c, q, qd, &k);
+    bodies_t bs;
+    bodies_from_fk(c, &k, bs);
+    compute_obs(bs, qf, qdf, ball, &e->obs[(size_t)i * PPENV_NUM_OBS]);
+}
+
+static void init_env(ppo_env* e, int i) {
+    reset_env_state(e, i, 1);
+    for (int d = 0; d < ND; d++) e->dof_force[(size_t)d * e->n + i] = 0.0f;
+    e->flags[i] = initial_flags(&e->cfg);
+    e->progress[i] = 0;
+    e->reset[i] = 1;  /* upstream VecTask.allocate_buffers: reset_buf = ones; overwritten by the first step (TT:740) */
+    e->rew[i] = 0.0f;
+    obs_from_state(e, i);
+}
+/* state as after _create_envs (TT:512-643): creation is episode 0 of every env */
+void ppo_init(ppo_env* e) {
+    for (int i = 0; i < e->n; i++) { e->episode[i] = 0; init_env(e, i); }
+}
+/* VecTask.reset(): every env back to its initial state with a fresh serve */
+void ppo_reset_all(ppo_env* e) {
+    for (int i = 0; i < e->n; i++) { e->episode[i] += 1; init_env(e, i); }
+}
+void ppo_set_serve_override(ppo_env* e, const float* serve /* [N,3] */, int on) {
+    e->serve_on = on;
+    if (on && serve)
+        for (int i = 0; i < e->n; i++)
+            for (int k = 0; k < 3; k++) e->serve[(size_t)k * e->n + i] = serve[(size_t)i * 3 + k];
+}
+
+/* -------------------------------------------------------------------- the step */
+static void step_env(ppo_env* e, int i, const float* actions) {
+    const ppenv_config* c = &e->cfg;
+    int n = e->n;
+    float qf[ND], qdf[ND], ballf[13];
+    gather_env(e, i, qf, qdf, ballf);
+
+    /* pre_physics_step: TT:1003-1020 (clamp is VecTask.step, clipActions) */
+    double target[ND];
+    for (int d = 0; d < ND; d++) {
+        float a = actions[(size_t)i * ND + d];
+        a = fminf(fmaxf(a, -c->clip_actions), c->clip_actions);
+        float lo = c->joint[d].lower, hi = c->joint[d].upper;
+        float off = 0.5f * (hi + lo), scale = 0.5f * (hi - lo);   /* TT:664-665 */
+        target[d] = off + scale * a;                                /* TT:1008 */
+    }
+    float pre_vx = ballf[7];                                        /* TT:1020 */
+
+    /* gym.simulate: `substeps` substeps of the build's physics specification */
+    double q[ND], qd[ND], tau_drive[ND] = {0};
+    for (int d = 0; d < ND; d++) { q[d] = qf[d]; qd[d] = qdf[d]; }
+    ball_t b = {vf(&ballf[0]), vf(&ballf[7]), vf(&ballf[10])};
+    double bq[4] = {ballf[3], ballf[4], ballf[5], ballf[6]};
+    double h = (double)c->dt / c->substeps;
+    arm_fk k0, k1;
+    arm_forward_kinematics(c, q, qd, &k0);
+    for (int s = 0; s < c->substeps; s++) {
+        double tau[ND], arm_eff[ND], qdd[ND];
+        int sat[ND];
+        for (int d = 0; d < ND; d++) {
+            const ppenv_joint* j = &c->joint[d];
+            double err = target[d] - q[d];
+            double t_exp = j->kp * err - j->kd * qd[d];
+            sat[d] = fabs(t_exp) > j->effort;
+            if (sat[d]) { tau[d] = t_exp > 0 ? j->effort : -j->effort; arm_eff[d] = j->armature; }
+            else { tau[d] = j->kp * (err - h * qd[d]) - j->kd * qd[d]; arm_eff[d] = j->armature + h * j->kd + h * h * j->kp; }
+        }
+        arm_forward_dynamics(c, &k0, qd, tau, arm_eff, qdd);
+        for (int d = 0; d < ND; d++) {
+            const ppenv_joint* j = &c->joint[d];
+            double err = target[d] - q[d];
+            double v_new = qd[d] + h * qdd[d];
+            tau_drive[d] = sat[d] ? tau[d] : j->kp * (err - h * v_new) - j->kd * v_new;
+            v_new = clampd(v_new, -j->vel_limit, j->vel_limit);
+            double q_new = q[d] + h * v_new;
+            if (q_new > j->upper) { q_new = j->upper; if (v_new > 0) v_new = 0; }
+            if (q_new < j->lower) { q_new = j->lower; if (v_new < 0) v_new = 0; }
+            q[d] = q_new; qd[d] = v_new;
+        }
+        arm_forward_kinematics(c, q, qd, &k1);
+        arm_geom g0, g1;
+        arm_geometry(c, &k0, &g0);
+        arm_geometry(c, &k1, &g1);
+        ball_substep(c, &b, bq, &g0, &g1, h);
+        k0 = k1;
+    }
+
+    /* refresh_sim_tensors (TT:801-807): round the state to the fp32 tensors */
+    float dof_force[ND];
+    for (int d = 0; d < ND; d++) { qf[d] = (float)q[d]; qdf[d] = (float)qd[d]; dof_force[d] = (float)tau_drive[d]; }
+    ballf[0] = (float)b.p.x; ballf[1] = (float)b.p.y; ballf[2] = (float)b.p.z;
+    for (int t = 0; t < 4; t++) ballf[3 + t] = (float)bq[t];
+    ballf[7] = (float)b.v.x; ballf[8] = (float)b.v.y; ballf[9] = (float)b.v.z;
+    ballf[10] = (float)b.w.x; ballf[11] = (float)b.w.y; ballf[12] = (float)b.w.z;
+    bodies_t bs;
+    bodies_from_fk(c, &k0, bs);
+
+    /* post_physics_step: TT:1022-1039 */
+    int64_t progress = e->progress[i] + 1;                          /* TT:1023 */
+    uint32_t flags = e->flags[i];
+    int64_t reset;
+    float rew = compute_reward(c, c->humanoid_root_pos[0], bs[c->paddle_obs_index], pre_vx, ballf, dof_force, qdf,
+                               progress, &flags, &reset);
+    for (int d = 0; d < ND; d++) {
+        e->dof_pos[(size_t)d * n + i] = qf[d]; e->dof_vel[(size_t)d * n + i] = qdf[d];
+        e->dof_force[(size_t)d * n + i] = dof_force[d];
+    }
+    for (int t = 0; t < 13; t++) e->ball[(size_t)t * n + i] = ballf[t];
+    if (reset) {                                                    /* TT:1034-1036 -> 847-906 */
+        e->episode[i] += 1;
+        reset_env_state(e, i, c->variant != PPENV_VARIANT_TN);      /* TN:888-901 keeps the dof state */
+        progress = 0;                                               /* TT:902 */
+        flags = initial_flags(c);                                   /* TT:903-905 */
+        gather_env(e, i, qf, qdf, ballf);
+    }
+    e->progress[i] = progress; e->flags[i] = flags; e->rew[i] = rew; e->reset[i] = reset;
+    /* TT:1039: dof / ball already show the reset state, body states are the pre-reset ones */
+    compute_obs(bs, qf, qdf, ballf, &e->obs[(size_t)i * PPENV_NUM_OBS]);
+}
+
+void ppo_step(ppo_env* e, const float* actions) {
+    int n = e->n;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(e->threads) schedule(static)
+#endif
+    for (int i = 0; i < n; i++) step_env(e, i, actions);
+}
+
+/* ---------------------------------------------- Isaac-Gym tensor-API mode (TT:1022-1039) */
+void ppo_post_physics_step(ppo_env* e, const float* rb_states /* [N,42,13] */, float* root_states /* [N,3,13] */,
+                           float* dof_states /* [N,7,2] */, const float* dof_force /* [N,7] */,
+                           const float* pre_ball_vx /* [N] */) {
+    const ppenv_config* c = &e->cfg;
+    static const int body_ids[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};
+    for (int i = 0; i < e->n; i++) {
+        const float* rb = &rb_states[(size_t)i * PPENV_NUM_BODIES * 13];
+        float* root = &root_states[(size_t)i * PPENV_NUM_ACTORS * 13];
+        float* dofs = &dof_states[(size_t)i * ND * 2];
+        bodies_t bs;
+        for (int j = 0; j < NB; j++) memcpy(bs[j], &rb[body_ids[j] * 13], 13 * sizeof(float));
+        float qf[ND], qdf[ND];
+        for (int d = 0; d < ND; d++) { qf[d] = dofs[2 * d]; qdf[d] = dofs[2 * d + 1]; }
+        float* ball = &root[2 * 13];
+        int64_t progress = e->progress[i] + 1;
+        uint32_t flags = e->flags[i];
+        int64_t reset;
+        float rew = compute_reward(c, root[0], &rb[39 * 13], pre_ball_vx[i], ball, &dof_force[(size_t)i * ND], qdf,
+                                   progress, &flags, &reset);
+        if (reset) {
+            e->episode[i] += 1;
+            float v[3];
+            fresh_serve(e, i, v);
+            const float* init_pos[3] = {c->humanoid_root_pos, c->table_root_pos, c->ball_init_pos};
+            const float* init_quat[3] = {c->humanoid_root_quat, c->table_root_quat, c->ball_init_quat};
+            for (int a = 0; a < 3; a++) {            /* TT:853-855 */
+                memcpy(&root[a * 13], init_pos[a], 3 * sizeof(float));
+                memcpy(&root[a * 13 + 3], init_quat[a], 4 * sizeof(float));
+                memset(&root[a * 13 + 7], 0, 6 * sizeof(float));
+            }
+            memcpy(&ball[7], v, 3 * sizeof(float));  /* TT:857-862 */
+            if (c->variant != PPENV_VARIANT_TN)
+                for (int d = 0; d < ND; d++) { dofs[2 * d] = qf[d] = c->init_dof_pos[d]; dofs[2 * d + 1] = qdf[d] = c->init_dof_vel[d]; }
+            progress = 0;
+            flags = initial_flags(c);
+        }
+        e->progress[i] = progress; e->flags[i] = flags; e->rew[i] = rew; e->reset[i] = reset;
+        compute_obs(bs, qf, qdf, ball, &e->obs[(size_t)i * PPENV_NUM_OBS]);
+    }
+}
+
+/* ------------------------------------------------------------ refresh (gym.refresh_*) */
+void ppo_refresh_root_states(ppo_env* e, float* out /* [N,3,13] */) {
+    const ppenv_config* c = &e->cfg;
+    for (int i = 0; i < e->n; i++) {
+        float* r = &out[(size_t)i * 39];
+        memset(r, 0, 39 * sizeof(float));
+        memcpy(r, c->humanoid_root_pos, 12); memcpy(r + 3, c->humanoid_root_quat, 16);
+        memcpy(r + 13, c->table_root_pos, 12); memcpy(r + 16, c->table_root_quat, 16);
+        for (int k = 0; k < 13; k++) r[26 + k] = e->ball[(size_t)k * e->n + i];
+    }
+}
+void ppo_refresh_dof_states(ppo_env* e, float* out /* [N,7,2] */) {
+    for (int i = 0; i < e->n; i++)
+        for (int d = 0; d < ND; d++) {
+            out[((size_t)i * ND + d) * 2] = e->dof_pos[(size_t)d * e->n + i];
+            out[((size_t)i * ND + d) * 2 + 1] = e->dof_vel[(size_t)d * e->n + i];
+        }
+}
+void ppo_refresh_dof_force(ppo_env* e, float* out /* [N,7] */) {
+    for (int i = 0; i < e->n; i++)
+        for (int d = 0; d < ND; d++) out[(size_t)i * ND + d] = e->dof_force[(size_t)d * e->n + i];
+}
+void ppo_refresh_rigid_body_states(ppo_env* e, float* out /* [N,42,13] */) {
+    const ppenv_config* c = &e->cfg;
+    static const int body_ids[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};
+    for (int i = 0; i < e->n; i++) {
+        float qf[ND], qdf[ND], ball[13];
+        double q[ND], qd[ND];
+        gather_env(e, i, qf, qdf, ball);
+        for (int d = 0; d < ND; d++) { q[d] = qf[d]; qd[d] = qdf[d]; }
+        arm_fk k;
+        arm_forward_kinematics(c, q, qd, &k);
+        bodies_t bs;
+        bodies_from_fk(c, &k, bs);
+        float* rb = &out[(size_t)i * PPENV_NUM_BODIES * 13];
+        for (int b = 0; b < PPENV_NUM_HUMANOID_BODIES; b++) {
+            memset(&rb[b * 13], 0, 13 * sizeof(float));
+            memcpy(&rb[b * 13], c->humanoid_root_pos, 12); memcpy(&rb[b * 13 + 3], c->humanoid_root_quat, 16);
+        }
+        for (int j = 0; j < NB; j++) memcpy(&rb[body_ids[j] * 13], bs[j], 13 * sizeof(float));
+        memset(&rb[40 * 13], 0, 13 * sizeof(float));
+        memcpy(&rb[40 * 13], c->table_root_pos, 12); memcpy(&rb[40 * 13 + 3], c->table_root_quat, 16);
+        memcpy(&rb[41 * 13], ball, 13 * sizeof(float));
+    }
+}
+
+/* ---------------------------------------------------------------- state blob I/O */
+size_t ppo_state_bytes(ppo_env* e) { return (size_t)e->n * ((ND * 3 + 13) * 4 + 4 + 4 + 8 + 8); }
+static unsigned char* blob_copy(unsigned char* p, void* arr, size_t bytes, int to_blob) {
+    if (to_blob) memcpy(p, arr, bytes); else memcpy(arr, p, bytes);
+    return p + bytes;
+}
+static void blob_io(ppo_env* e, unsigned char* p, int to_blob) {
+    size_t n = e->n;
+    p = blob_copy(p, e->dof_pos, n * ND * 4, to_blob);
+    p = blob_copy(p, e->dof_vel, n * ND * 4, to_blob);
+    p = blob_copy(p, e->dof_force, n * ND * 4, to_blob);
+    p = blob_copy(p, e->ball, n * 13 * 4, to_blob);
+    p = blob_copy(p, e->flags, n * 4, to_blob);
+    p = blob_copy(p, e->episode, n * 4, to_blob);
+    p = blob_copy(p, e->progress, n * 8, to_blob);
+    p = blob_copy(p, e->reset, n * 8, to_blob);
+}
+int ppo_get_state(ppo_env* e, void* dst, size_t nbytes) {
+    if (nbytes != ppo_state_bytes(e)) return PPENV_ESTATE;
+    blob_io(e, (unsigned char*)dst, 1);
+    return 0;
+}
+int ppo_set_state(ppo_env* e, const void* src, size_t nbytes) {
+    if (nbytes != ppo_state_bytes(e)) return PPENV_ESTATE;
+    blob_io(e, (unsigned char*)src, 0);
+    return 0;
+}
+
+/* ------------------------------------------------- exposed pieces for unit tests */
+/* joint accelerations for one env (KAT: compare against the kernel's ABA) */
+void ppo_arm_qdd(const ppenv_config* c, const double* q, const double* qd, const double* tau, const double* arm_eff,
+                 double* qdd) {
+    arm_fk k;
+    arm_forward_kinematics(c, q, qd, &k);
+    arm_forward_dynamics(c, &k, qd, tau, arm_eff, qdd);
+}
+void ppo_arm_inverse_dynamics(const ppenv_config* c, const double* q, const double* qd, const double* qdd, double* tau) {
+    arm_fk k;
+    arm_forward_kinematics(c, q, qd, &k);
+    arm_rnea(c, &k, qd, qdd, -(double)c->gravity_z, 1, tau);
+}
+void ppo_arm_body_states(const ppenv_config* c, const double* q, const double* qd, float* out /* [10][13] */) {
+    arm_fk k;
+    arm_forward_kinematics(c, q, qd, &k);
+    bodies_from_fk(c, &k, (float(*)[13])out);
+}
+/* total mechanical energy of the arm (kinetic + potential), for conservation tests */
+double ppo_arm_energy(const ppenv_config* c, const double* q, const double* qd) {
+    arm_fk k;
+    arm_forward_kinematics(c, q, qd, &k);
+    double E = 0;
+    for (int i = 0; i < ND; i++) {
+        const ppenv_joint* j = &c->joint[i];
+        v3 comw = mv(&k.R[i], vf(j->com));
+        v3 vc = vadd(k.v[i], vcross(k.w[i], comw));
+        m3 I = {{j->inertia[0], j->inertia[3], j->inertia[4], j->inertia[3], j->inertia[1], j->inertia[5],
+                 j->inertia[4], j->inertia[5], j->inertia[2]}};
+        m3 Rt = mt(&k.R[i]);
+        v3 wl = mv(&Rt, k.w[i]);
+        E += 0.5 * j->mass * vdot(vc, vc) + 0.5 * vdot(wl, mv(&I, wl));
+        E += -j->mass * c->gravity_z * (k.p[i].z + comw.z);
+    }
+    return E;
+}
+void ppo_serve_velocity(const ppenv_config* c, uint32_t gid, uint32_t episode, float out[3]) { serve_velocity(c, gid, episode, out); }
+void ppo_compute_obs(const float* bodies /* [10][13] */, const float* dof_pos, const float* dof_vel, const float* ball, float* obs) {
+    compute_obs((const float(*)[13])bodies, dof_pos, dof_vel, ball, obs);
+}

@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code on scripted inputs.
+
+Runs only in the build container (needs /root/reference).  For each 7-DoF task
+variant it instantiates the reference task class without its Isaac Gym
+constructor (object.__new__), gives it CPU torch tensors laid out exactly like
+the simulator tensors it wraps (TT:153-214), and calls the reference's own
+`post_physics_step()` (TT:1022-1052) once per scripted step.  That executes the
+reference's `compute_reward` -> `compute_pingpong_reward*`, `reset_idx` ->
+`_reset_idx` (with Python `random` driving `generate_random_speed_for_ball`)
+and `compute_observations`, with sticky flags and progress carried from step to
+step.  `gym.simulate` does not exist offline, so the state between steps comes
+from a small scripted ball/arm generator below — it only has to visit every
+branch of the reward, not be physical.
+
+Outputs per variant (arrays over T steps x N envs), all float32 unless noted:
+  in_bodies   [T,N,10,13]  rigid-body rows bodyStatesId=[0,31..39] fed to the reference
+  in_root     [T,N,3,13]   actor root states before post_physics_step
+  in_dof      [T,N,7,2]    dof states before
+  in_dof_force[T,N,7]
+  in_pre_vx   [T,N]        ball vx captured by pre_physics_step
+  serve       [T,N,3]      serve velocity the reference drew for envs it reset (NaN elsewhere)
+  out_rew [T,N], out_reset [T,N] i64, out_obs [T,N,80], out_progress [T,N] i64,
+  out_flags [T,N] u32 (PPENV_FLAG_* packing), out_root [T,N,3,13], out_dof [T,N,7,2]
+plus the scalar task constants used.  The fixture is data only; no reference
+source text is stored.
+"""
+import contextlib
+import io
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_loader  # noqa: E402
+from isaacgym_amd import scene  # noqa: E402
+
+BODY_IDS = [0, 31, 32, 33, 34, 35, 36, 37, 38, 39]
+N_ENVS, T_STEPS = 48, 40
+
+
+class Vec3:
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        self.x, self.y, self.z = x, y, z
+
+
+class FakeGym:
+    """Stands in for the gym handle: refresh_* are no-ops (tensors are injected), set_* succeed."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return lambda *a, **k: True
+
+
+VARIANTS = {
+    "TT": dict(file="humanoid_pingpong_3_actor_tilt.py", cls="HumanoidPingpongTilt"),
+    "TN": dict(file="humanoid_pingpong_3_actor_tilt_no_earlystop.py", cls=None),
+    "T3": dict(file="humanoid_interos_edit_pingpong_only_3_actor.py", cls=None),
+}
+
+
+def find_task_class(mod):
+    """The task class is the one defining post_physics_step."""
+    for name, obj in vars(mod).items():
+        if isinstance(obj, type) and "post_physics_step" in vars(obj):
+            return obj
+    raise RuntimeError("no task class found")
+
+
+def make_instance(variant, mod, cfg, n, episode_length):
+    cls = find_task_class(mod)
+    sys.modules["isaacgym.gymapi"].Vec3 = Vec3
+    mod.gymapi.Vec3 = Vec3
+    o = object.__new__(cls)
+    env = cfg["env"]
+    o.cfg = cfg
+    o.num_envs, o.device, o.headless, o.randomize = n, "cpu", True, False
+    o.gym, o.sim, o.viewer = FakeGym(), None, None
+    o.num_steps = 1
+    o.max_episode_length = episode_length
+    o.alpha = env["alphaVelocityReward"]
+    o.power_coefficient = env["powerCoefficient"]
+    o.penalty = env["penalty"]
+    o.hit_table_reward = env["hitTableReward"]
+    o.not_hit_table_penalty = env["nothitTablePenalty"]
+    sc = cfg["scene"]
+    o.initial_speed_range = tuple(sc["serve_speed"])
+    o.tilt_angle_range = tuple(sc["serve_tilt"])
+    o.tilt_z_angle_range = tuple(sc["serve_tilt_z"])
+    o.actors_per_env, o.dofs_per_env = 3, 7
+
+    o.progress_buf = torch.zeros(n, dtype=torch.long)
+    o.randomize_buf = torch.zeros(n, dtype=torch.long)
+    o.reset_buf = torch.ones(n, dtype=torch.long)
+    o.reset_buf_force = torch.zeros(n, dtype=torch.long)
+    o.rew_buf = torch.zeros(n)
+    o.obs_buf = torch.zeros(n, 80)
+    o.actions = torch.zeros(n, 7)
+
+    c = scene.build_config(variant, cfg=cfg, num_envs=n)
+    init_root = torch.from_numpy(scene.initial_root_states(c))
+    o.root_states = init_root.repeat(n, 1).clone()                      # [N*3, 13]
+    o.vec_root_states = o.root_states.view(n, 3, 13)
+    o.initial_vec_root_states = o.vec_root_states.clone()
+    o.initial_pos = o.initial_vec_root_states[:, :, 0:3]
+    o.initial_rot = o.initial_vec_root_states[:, :, 3:7]
+    o.humanoid1_root_states = o.vec_root_states[:, 0, :]
+    o.table_root_states = o.vec_root_states[:, 1, :]
+    o.ball2_root_states = o.vec_root_states[:, 2, :]
+    o.pre_ball2_root_states = o.ball2_root_states.clone()
+
+    o.rb_states = torch.zeros(n * 42, 13)
+    o.body_states = o.rb_states.view(n, 42, 13)
+    o.vec_rb_states = o.rb_states.view(n, -1, 13)
+    o.humanoid1_paddle_rb_states = o.vec_rb_states[:, 39, :]
+    o.body_states_id = torch.tensor(BODY_IDS, dtype=torch.long)
+
+    o.dof_states = torch.zeros(n * 7, 2)
+    o.vec_dof_states = o.dof_states.view(n, 7, 2)
+    o.dof_pos = o.vec_dof_states[..., 0]
+    o.dof_vel = o.vec_dof_states[..., 1]
+    o.initial_dof_states = o.vec_dof_states.clone()
+    o.dof_force_tensor = torch.zeros(n, 7)
+    o.actor_indices = torch.arange(n * 3, dtype=torch.long)
+    o.dof_indices = torch.arange(n, dtype=torch.long)
+
+    o.reward_calculated = torch.zeros(n, dtype=torch.bool)
+    o.condition_calculated = torch.zeros(n, dtype=torch.bool)
+    o.no_bounce_before_half_mask = torch.ones(n, dtype=torch.bool)
+    o.paddle_condition_calculated = torch.zeros(n, dtype=torch.bool)
+    o.missed_ball_calculated = torch.zeros(n, dtype=torch.bool)
+    o.net_condition_calculated = torch.zeros(n, dtype=torch.bool)
+    return o, c
+
+
+def pack_flags(variant, o):
+    f = np.zeros(o.num_envs, dtype=np.uint32)
+    if variant == "TT":
+        f |= o.reward_calculated.numpy().astype(np.uint32) * scene.FLAG_REWARD_CALC
+        f |= o.condition_calculated.numpy().astype(np.uint32) * scene.FLAG_COND_CALC
+        f |= o.no_bounce_before_half_mask.numpy().astype(np.uint32) * scene.FLAG_NO_BOUNCE
+    elif variant == "TN":
+        f |= o.paddle_condition_calculated.numpy().astype(np.uint32) * scene.FLAG_COND_CALC
+        f |= o.missed_ball_calculated.numpy().astype(np.uint32) * scene.FLAG_MISSED_CALC
+        f |= scene.FLAG_NO_BOUNCE  # TN never touches this mask in its active reward; it stays set
+    else:
+        f |= scene.FLAG_NO_BOUNCE  # T3 has no flags; the native state keeps the initial value
+    return f
+
+
+def random_unit_quats(rng, n):
+    q = rng.normal(size=(n, 4))
+    return (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+
+
+def yaw_quats(angles):
+    q = np.zeros((len(angles), 4), np.float32)
+    q[:, 2] = np.sin(0.5 * angles)
+    q[:, 3] = np.cos(0.5 * angles)
+    return q
+
+
+def generate(variant, seed):
+    rng = np.random.default_rng(seed)
+    cfg = scene.default_task_cfg(variant)
+    n, T = N_ENVS, T_STEPS
+    episode_length = 12  # short so that the progress time-out branch (TT:1265) fires inside T steps
+    mod = ref_loader.load_task(VARIANTS[variant]["file"])
+    o, c = make_instance(variant, mod, cfg, n, episode_length)
+
+    drawn = []
+    orig = o.generate_random_speed_for_ball
+
+    def recording(*a, **k):
+        v = orig(*a, **k)
+        drawn.append((v.x, v.y, v.z))
+        return v
+    o.generate_random_speed_for_ball = recording
+
+    # pelvis orientation per env: identity, the T3 yaw, pure yaws, and general tilts
+    pelvis_q = random_unit_quats(rng, n)
+    pelvis_q[: n // 4] = np.array(c.humanoid_root_quat[:], np.float32)
+    pelvis_q[n // 4: n // 2] = yaw_quats(rng.uniform(-np.pi, np.pi, n // 2 - n // 4))
+    pelvis_p = np.tile(np.array(c.humanoid_root_pos[:], np.float32), (n, 1))
+    pelvis_p[n // 2:] += rng.uniform(-0.2, 0.2, (n - n // 2, 3)).astype(np.float32)
+
+    # scripted ball: half the envs fly ballistically with table bounces / paddle returns, half are i.i.d. samples
+    ball = o.vec_root_states[:, 2, :].numpy().copy()
+    ball[:, 7:10] = rng.uniform([-9, -0.8, -1], [-5, 0.8, 1], (n, 3))
+    kin = np.arange(n) < n // 2
+    dt = cfg["sim"]["dt"] * 3.0  # coarse steps so a rally fits into the short episodes
+    lo = np.array([c.joint[j].lower for j in range(7)], np.float32)
+    hi = np.array([c.joint[j].upper for j in range(7)], np.float32)
+    dof = np.zeros((n, 7, 2), np.float32)
+
+    keys = ["in_bodies", "in_root", "in_dof", "in_dof_force", "in_pre_vx", "serve", "out_rew", "out_reset",
+            "out_obs", "out_progress", "out_flags", "out_root", "out_dof"]
+    rec = {k: [] for k in keys}
+    random.seed(seed)
+    for t in range(T):
+        pre_vx = ball[:, 7].copy()
+        # --- scripted "physics"
+        nb = ball.copy()
+        nb[kin, 9] -= 9.8 * dt
+        nb[kin, 0:3] += nb[kin, 7:10] * dt
+        on_table = kin & (nb[:, 2] < 0.78) & (nb[:, 9] < 0) & (nb[:, 0] > 0.38) & (nb[:, 0] < 3.12) & (np.abs(nb[:, 1]) < 0.76)
+        nb[on_table, 2] = 0.78 + (0.78 - nb[on_table, 2])
+        nb[on_table, 9] *= -0.9
+        at_paddle = kin & (nb[:, 0] < 0.35) & (nb[:, 7] < 0) & (rng.uniform(size=n) < 0.7)
+        nb[at_paddle, 7] = rng.uniform(0.5, 7.0, at_paddle.sum())
+        nb[at_paddle, 9] = rng.uniform(0.5, 3.5, at_paddle.sum())
+        iid = ~kin
+        nb[iid, 0:3] = rng.uniform([-0.4, -0.9, 0.0], [3.5, 0.9, 1.4], (iid.sum(), 3))
+        nb[iid, 7:10] = rng.uniform([-9, -2, -4], [9, 2, 4], (iid.sum(), 3))
+        # put some i.i.d. samples right inside the narrow windows (net 1.7<x<1.8, table zones)
+        pick = iid & (rng.uniform(size=n) < 0.3)
+        nb[pick, 0] = rng.uniform(1.68, 1.82, pick.sum())
+        nb[pick, 2] = rng.uniform(0.95, 1.17, pick.sum())
+        pick = iid & (rng.uniform(size=n) < 0.3)
+        nb[pick, 2] = rng.uniform(0.05, 0.9, pick.sum())
+        nb[:, 10:13] = rng.uniform(-20, 20, (n, 3))
+        ball = nb.astype(np.float32)
+        dof[:, :, 1] = rng.uniform(-6, 6, (n, 7))
+        dof[:, :, 0] = np.clip(dof[:, :, 0] + dof[:, :, 1] * dt, lo, hi)
+        dof_force = rng.uniform(-25, 25, (n, 7)).astype(np.float32)
+        bodies = np.zeros((n, 10, 13), np.float32)
+        bodies[:, :, 0:3] = rng.uniform([-0.2, -0.6, 0.7], [0.7, 0.3, 1.6], (n, 10, 3))
+        bodies[:, :, 3:7] = random_unit_quats(rng, n * 10).reshape(n, 10, 4)
+        bodies[:, :, 7:13] = rng.uniform(-5, 5, (n, 10, 6))
+        bodies[:, 0, 0:3] = pelvis_p
+        bodies[:, 0, 3:7] = pelvis_q
+        bodies[:, 0, 7:13] = 0
+        near = rng.uniform(size=n) < 0.4   # paddle close to the ball: exercises the proximity terms
+        bodies[near, 9, 0:3] = ball[near, 0:3] + rng.normal(0, 0.05, (near.sum(), 3))
+
+        # --- inject into the reference object's simulator tensors
+        o.body_states.zero_()
+        o.body_states[:, BODY_IDS, :] = torch.from_numpy(bodies)
+        o.vec_root_states[:, 2, :] = torch.from_numpy(ball)
+        o.vec_dof_states[:] = torch.from_numpy(dof)
+        o.dof_force_tensor[:] = torch.from_numpy(dof_force)
+        o.pre_ball2_root_states = o.ball2_root_states.clone()
+        o.pre_ball2_root_states[:, 7] = torch.from_numpy(pre_vx)
+        rec["in_bodies"].append(bodies.copy())
+        rec["in_root"].append(o.vec_root_states.numpy().copy())
+        rec["in_dof"].append(dof.copy())
+        rec["in_dof_force"].append(dof_force.copy())
+        rec["in_pre_vx"].append(pre_vx.astype(np.float32))
+
+        # --- the reference's own post_physics_step
+        drawn.clear()
+        with contextlib.redirect_stdout(io.StringIO()):
+            o.post_physics_step()
+        serve = np.full((n, 3), np.nan, np.float32)
+        ids = np.nonzero(o.reset_buf.numpy())[0]
+        assert len(ids) == len(drawn)
+        for k, env_id in enumerate(ids):  # _reset_idx draws in ascending env order (TT:857-862)
+            serve[env_id] = np.array(drawn[k], np.float32)
+        rec["serve"].append(serve)
+        rec["out_rew"].append(o.rew_buf.numpy().copy())
+        rec["out_reset"].append(o.reset_buf.numpy().copy())
+        rec["out_obs"].append(o.obs_buf.numpy().copy())
+        rec["out_progress"].append(o.progress_buf.numpy().copy())
+        rec["out_flags"].append(pack_flags(variant, o))
+        rec["out_root"].append(o.vec_root_states.numpy().copy())
+        rec["out_dof"].append(o.vec_dof_states.numpy().copy())
+        # continue the script from whatever the reference left (reset rows included)
+        ball = o.vec_root_states[:, 2, :].numpy().copy()
+        dof = o.vec_dof_states.numpy().copy()
+
+    out = {k: np.stack(v) for k, v in rec.items()}
+    env = cfg["env"]
+    out.update(
+        variant=np.array(variant), episode_length=np.array(episode_length),
+        alpha=np.array(env["alphaVelocityReward"], np.float32), power_coefficient=np.array(env["powerCoefficient"], np.float32),
+        penalty=np.array(env["penalty"], np.float32), hit_table_reward=np.array(env["hitTableReward"], np.float32),
+        not_hit_table_penalty=np.array(env["nothitTablePenalty"], np.float32), seed=np.array(seed),
+    )
+    return out
+
+
+def branch_report(variant, g):
+    rew, reset, fl = g["out_rew"], g["out_reset"], g["out_flags"]
+    print(f"[{variant}] steps x envs = {rew.shape}, resets {int(reset.sum())}, "
+          f"timeouts {(g['out_progress'] == 0).sum() - int(0)}, "
+          f"rew range [{rew.min():.1f}, {rew.max():.1f}], distinct flag words {sorted(set(fl.ravel().tolist()))}")
+    for thr in (1000.0, 300.0, -150.0, -700.0):
+        print(f"    rewards {'>' if thr > 0 else '<'} {thr}: {int(((rew > thr) if thr > 0 else (rew < thr)).sum())}")
+
+
+def main():
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    for i, variant in enumerate(("TT", "TN", "T3")):
+        g = generate(variant, seed=20250 + i)
+        branch_report(variant, g)
+        np.savez_compressed(os.path.join(outdir, f"post_physics_{variant}.npz"), **g)
+    print("wrote", sorted(os.listdir(outdir)))
+
+
+if __name__ == "__main__":
+    main()
