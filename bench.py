@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the fused HumanoidPingpong VecTask step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one VecTask.step() of every env this rank owns = one launch of the fused kernel
+(action->PD target, 2 physics substeps, reward, masked reset, observations).  Workload at N=1:
+BASELINE.json configs[2], "humanoid_pingpong 3-actor tilt, num_envs=16384 on 1 MI355X" (the
+config the metric "env-steps/sec at N_envs=16384" is quoted on).  For N>1 every rank owns its own
+16384 envs on its own GPU (weak scaling: the reference's multi-GPU mode is one env shard + one
+learner per rank, pingpong_note.txt:163); env ids are offset per rank so trajectories do not
+depend on the sharding.  The data path has no collective; once per PPO horizon (32 steps,
+cfg/train/HumanoidPingpongTiltG1PPO.yaml:73) the ranks all-reduce the three scalars the
+reference prints (mean reward, mean progress — TT:763-766 — and the episode count) over RCCL.
+
+Inputs are synthetic and resident in HBM before the timed region: a pool of U(-1,1) action
+tensors from torch.Generator(seed 0).  Timing: W warm-up steps, barrier + synchronize, exactly K
+steps, synchronize + barrier; the max over ranks is used.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NUM_ENVS = 16384
+VARIANT = "TT"
+HORIZON = 32
+# SURVEY.md §8(d) "minimal algorithmic bytes / env-step" for the 7-DoF variants (R 156 + W 452)
+ALGO_BYTES_PER_ENV_STEP = 608
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(num_envs, target_seconds=12.0):
+    """The CPU oracle (oracle/ppenv_oracle.c, kind 'port') timed on this box's host cores on a bounded
+    sample of the same workload.  Reported, not targeted."""
+    import numpy as np
+    from isaacgym_amd import scene
+    from oracle import binding as ob
+    ob.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env = ob.OracleEnv(scene.build_config(VARIANT, num_envs=num_envs, seed=0), threads=cores)
+    rng = np.random.default_rng(0)
+    actions = [rng.uniform(-1, 1, (num_envs, 7)).astype(np.float32) for _ in range(4)]
+    env.step(actions[0])   # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        env.step(actions[steps % 4])
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or steps >= 2000:
+            break
+    return {"value": num_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of the {VARIANT} variant at num_envs={num_envs}, OpenMP over envs, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from isaacgym_amd import _lib, scene
+    from isaacgym_amd.env import PPEnv
+
+    _lib.lib()   # fail loudly when the HIP extension is missing
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a torch.distributed launch with {args.gpus} ranks (see module docstring)")
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    n = args.num_envs
+    env = PPEnv(scene.build_config(VARIANT, num_envs=n, seed=0, device_id=local_rank, env_id_offset=rank * n), device=device)
+    gen = torch.Generator(device=device).manual_seed(rank)
+    pool = [(torch.rand(n, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
+    stats = torch.zeros(3, device=device, dtype=torch.float64)
+
+    def horizon_stats():
+        # what the reference prints every 40 steps (TT:763-766) + finished episodes; 3 scalars over RCCL
+        stats[0] = env.rew_buf.mean()
+        stats[1] = env.progress_buf.float().mean()
+        stats[2] = env.episode.sum()
+        if dist is not None:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+
+    def run(k):
+        for s in range(k):
+            env.step(pool[s & 7])
+            if (s + 1) % HORIZON == 0:
+                horizon_stats()
+
+    run(args.warmup)
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+
+    if dist is not None:
+        t = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    horizon_stats()
+    final_stats = stats.cpu().tolist()
+
+    if rank == 0:
+        total_env_steps = n * world * args.steps
+        # the timed region holds K launches of step_kernel back to back on this stream: HIP-event time / K
+        kernel_us = dev_ms * 1e3 / args.steps
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_us * 1e-6) / 1e9
+        out = {
+            "metric": "env-steps/sec at N_envs=16384 (1/2/4/8 GPUs) + achieved HBM GB/s vs roofline",
+            "value": total_env_steps / wall,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"humanoid_pingpong 3-actor tilt (HumanoidPingpongTiltG1), num_envs={n} per GPU, "
+                                   "random U(-1,1) actions, dt 0.0083 x 2 substeps, fused step kernel",
+                       "num_envs_per_gpu": n, "global_envs": n * world, "horizon_stats_every": HORIZON,
+                       "parallelism": f"env-shard x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "step_kernel<TopoG1>", "avg_kernel_us": kernel_us,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n},
+            "episode_stats": {"mean_reward_last_step": final_stats[0] / world, "mean_progress": final_stats[1] / world,
+                              "episodes_finished": final_stats[2]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""Loader of the HIP library `isaacgym_amd/lib/libppenv.so` (C ABI: include/ppenv.h).
+
+There is no CPU fallback: if the library is missing or does not load, importing the
+environment fails loudly.  `build()` compiles it with hipcc for gfx950 (cross-compiles
+without a GPU); the built .so lives in-tree so it travels with the source snapshot.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from . import scene
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "lib", "libppenv.so")
+SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip")]
+HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(ROOT, "include", "ppenv.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+_lib = None
+
+
+class PPEnvError(RuntimeError):
+    pass
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> isaacgym_amd/lib/libppenv.so."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + SOURCES
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise PPEnvError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stderr[-4000:])
+    if verbose:
+        print(" ".join(cmd))
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with argtypes set.  Raises PPEnvError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PPEnvError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (needs hipcc). There is no CPU fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise PPEnvError(f"could not load {LIB_PATH}: {e}") from e
+    if L.ppenv_abi_version() != scene.ABI_VERSION:
+        raise PPEnvError("libppenv.so ABI version does not match isaacgym_amd.scene; rebuild the library")
+    vp, sz = C.c_void_p, C.c_size_t
+    cfgp = C.POINTER(scene.Config)
+    L.ppenv_last_error.restype = C.c_char_p
+    L.ppenv_arena_bytes.restype = sz
+    L.ppenv_arena_bytes.argtypes = [cfgp]
+    L.ppenv_create.argtypes = [cfgp, vp, sz, vp, C.POINTER(vp)]
+    L.ppenv_destroy.restype = None
+    L.ppenv_destroy.argtypes = [vp]
+    L.ppenv_buffers_of.argtypes = [vp, C.POINTER(scene.Buffers)]
+    L.ppenv_config_of.argtypes = [vp, cfgp]
+    L.ppenv_step.argtypes = [vp, vp, vp]
+    L.ppenv_reset_all.argtypes = [vp, vp]
+    L.ppenv_post_physics_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    for name in ("ppenv_refresh_root_states", "ppenv_refresh_dof_states", "ppenv_refresh_dof_force",
+                 "ppenv_refresh_rigid_body_states"):
+        getattr(L, name).argtypes = [vp, vp, vp]
+    L.ppenv_set_serve_override.argtypes = [vp, vp, C.c_int, vp]
+    L.ppenv_state_bytes.restype = sz
+    L.ppenv_state_bytes.argtypes = [vp]
+    L.ppenv_get_state.argtypes = [vp, vp, sz]
+    L.ppenv_set_state.argtypes = [vp, vp, sz]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise PPEnvError(f"ppenv error {rc}: {lib().ppenv_last_error().decode()}")

@@ -1,0 +1,593 @@
+// ppenv.hip — HIP kernels (gfx950) and the C ABI of include/ppenv.h.
+//
+// Data layout in HBM: simulation state is SoA, [field][num_envs] fp32 (7 dof_pos rows,
+// 7 dof_vel, 7 dof_force, 13 ball rows) + u32 flags/episode + i64 progress/reset, so lane
+// e of a wave reads element e of every row: each state access of a 64-lane wave is one
+// contiguous 256-byte (or 512-byte for i64) segment.  The two row-major tensors the
+// VecTask surface fixes — actions [N,7] in, obs_buf [N,80] out — are transposed through
+// LDS so that they, too, move as contiguous 16-byte-per-lane segments.
+//
+// Mapping: one lane per env, 64-thread workgroups (one wave), so N=16384 gives 256
+// workgroups = one per CU.  There is no inter-env communication and no MFMA: the step is
+// ~10^4 dependent fp32 VALU operations per env on ~0.6 KB of state.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ppenv_device.h"
+
+using namespace pp;
+
+namespace {
+
+constexpr int kBlock = 64;
+constexpr int kObsStride = PPENV_NUM_OBS + 1;   // +1 float: lanes write LDS rows bank-conflict-free
+
+struct DevBuffers {
+    float* obs;
+    float* rew;
+    long long* reset;
+    long long* progress;
+    float* dof_pos;
+    float* dof_vel;
+    float* dof_force;
+    float* ball;
+    uint32_t* flags;
+    uint32_t* episode;
+    float* serve;
+};
+
+// ------------------------------------------------------------- SoA state <-> registers
+__device__ __forceinline__ void load_state(const DevBuffers& b, int n, int i, EnvState& st) {
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+        st.q[d] = b.dof_pos[(size_t)d * n + i];
+        st.qd[d] = b.dof_vel[(size_t)d * n + i];
+    }
+    float bl[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
+    st.ball.p = mk(bl[0], bl[1], bl[2]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) st.ball.quat[k] = bl[3 + k];
+    st.ball.v = mk(bl[7], bl[8], bl[9]);
+    st.ball.w = mk(bl[10], bl[11], bl[12]);
+    st.progress = b.progress[i];
+    st.flags = b.flags[i];
+    st.episode = b.episode[i];
+}
+__device__ __forceinline__ void store_state(const DevBuffers& b, int n, int i, const EnvState& st) {
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+        b.dof_pos[(size_t)d * n + i] = st.q[d];
+        b.dof_vel[(size_t)d * n + i] = st.qd[d];
+        b.dof_force[(size_t)d * n + i] = st.dof_force[d];
+    }
+    const float bl[13] = {st.ball.p.x, st.ball.p.y, st.ball.p.z, st.ball.quat[0], st.ball.quat[1], st.ball.quat[2], st.ball.quat[3],
+                          st.ball.v.x, st.ball.v.y, st.ball.v.z, st.ball.w.x, st.ball.w.y, st.ball.w.z};
+#pragma unroll
+    for (int k = 0; k < 13; k++) b.ball[(size_t)k * n + i] = bl[k];
+    b.progress[i] = st.progress;
+    b.flags[i] = st.flags;
+    b.episode[i] = st.episode;
+}
+
+struct LdsRowStore {
+    float* row;
+    __device__ __forceinline__ void operator()(int k, float v) { row[k] = v; }
+};
+struct GlobalRowStore {
+    float* row;
+    __device__ __forceinline__ void operator()(int k, float v) { row[k] = v; }
+};
+
+// obs rows of one workgroup: LDS [kBlock][kObsStride] -> obs_buf[base*80 ...], 16 B per lane, contiguous
+__device__ __forceinline__ void flush_obs(const float* s_obs, float* obs, int base, int nvalid) {
+    const int total = nvalid * PPENV_NUM_OBS;   // multiple of 4; a float4 never straddles rows (80 % 4 == 0)
+    float4* dst = reinterpret_cast<float4*>(obs + (size_t)base * PPENV_NUM_OBS);
+    for (int k = threadIdx.x * 4; k < total; k += kBlock * 4) {
+        int r = k / PPENV_NUM_OBS, c = k - r * PPENV_NUM_OBS;
+        const float* src = &s_obs[r * kObsStride + c];
+        dst[k >> 2] = make_float4(src[0], src[1], src[2], src[3]);
+    }
+}
+
+// ------------------------------------------------------------------ the fused step
+// K1..K8 of SURVEY.md §2 in one launch: TT:1002-1052.
+template <class T>
+__global__ __launch_bounds__(kBlock) void step_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, const float* __restrict__ actions, int serve_on) {
+    __shared__ float s_obs[kBlock * kObsStride];
+    __shared__ float s_act[kBlock * ND];
+    const ppenv_config& cfg = *cfgp;
+    const int n = cfg.num_envs;
+    const int base = blockIdx.x * kBlock;
+    const int lane = threadIdx.x;
+    const int i = base + lane;
+    const int nvalid = min(kBlock, n - base);
+
+    // actions [N,7] row-major: this workgroup's rows are one contiguous run
+    for (int k = lane; k < nvalid * ND; k += kBlock) s_act[k] = actions[(size_t)base * ND + k];
+    __syncthreads();
+
+    if (i < n) {
+        EnvState st;
+        load_state(b, n, i, st);
+        float act[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) act[d] = s_act[lane * ND + d];
+        BodyState bodies[NB];
+        float pre_vx;
+        simulate_env<T>(cfg, act, st, bodies, pre_vx);
+        V3 ov = mk(0, 0, 0);
+        if (serve_on) ov = mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i]);
+        LdsRowStore store{&s_obs[lane * kObsStride]};
+        float rew;
+        long long reset;
+        post_physics_env(cfg, (uint32_t)(cfg.env_id_offset + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, rew, reset, store);
+        store_state(b, n, i, st);
+        b.rew[i] = rew;
+        b.reset[i] = reset;
+    }
+    __syncthreads();
+    flush_obs(s_obs, b.obs, base, nvalid);
+}
+
+// create (mode 0: creation is episode 0) / reset_all (mode 1: next episode): state as after
+// _create_envs (TT:512-643) plus the observations of that state
+template <class T>
+__global__ __launch_bounds__(kBlock) void init_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, int mode, int serve_on) {
+    __shared__ float s_obs[kBlock * kObsStride];
+    const ppenv_config& cfg = *cfgp;
+    const int n = cfg.num_envs;
+    const int base = blockIdx.x * kBlock;
+    const int lane = threadIdx.x;
+    const int i = base + lane;
+    const int nvalid = min(kBlock, n - base);
+    if (i < n) {
+        EnvState st;
+        st.episode = mode == 0 ? 0u : b.episode[i] + 1u;
+        V3 serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
+                            : serve_velocity(cfg, (uint32_t)(cfg.env_id_offset + i), st.episode);
+        reset_state(cfg, st, serve, true);
+#pragma unroll
+        for (int d = 0; d < ND; d++) st.dof_force[d] = 0.f;
+        st.progress = 0;
+        st.flags = PPENV_FLAG_NO_BOUNCE;
+        BodyState bodies[NB];
+        bodies_of_state<T>(cfg, st.q, st.qd, bodies);
+        V3 bpos[NB], bvel[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
+        LdsRowStore store{&s_obs[lane * kObsStride]};
+        write_obs(bpos, bvel, cfg.humanoid_root_quat, st.q, st.qd, st.ball.p, st.ball.v, store);
+        store_state(b, n, i, st);
+        b.rew[i] = 0.f;
+        b.reset[i] = 1;   // upstream VecTask.allocate_buffers: ones; overwritten by the first step (TT:740)
+    }
+    __syncthreads();
+    flush_obs(s_obs, b.obs, base, nvalid);
+}
+
+// ---------------------------------------- Isaac-Gym tensor-API mode: TT:1022-1039 on caller tensors
+__global__ __launch_bounds__(kBlock) void post_physics_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, const float* __restrict__ rb,
+                                                               float* root, float* dofs, const float* __restrict__ dof_force,
+                                                               const float* __restrict__ pre_vx, int serve_on) {
+    __shared__ float s_obs[kBlock * kObsStride];
+    const ppenv_config& cfg = *cfgp;
+    const int n = cfg.num_envs;
+    const int base = blockIdx.x * kBlock;
+    const int lane = threadIdx.x;
+    const int i = base + lane;
+    const int nvalid = min(kBlock, n - base);
+    if (i < n) {
+        const int body_ids[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};   // bodyStatesId, HumanoidPingpongTiltG1.yaml:47
+        const float* rbe = rb + (size_t)i * PPENV_NUM_BODIES * 13;
+        float* roote = root + (size_t)i * PPENV_NUM_ACTORS * 13;
+        float* dofe = dofs + (size_t)i * ND * 2;
+        V3 bpos[NB], bvel[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const float* r = rbe + body_ids[j] * 13;
+            bpos[j] = mk(r[0], r[1], r[2]);
+            bvel[j] = mk(r[7], r[8], r[9]);
+        }
+        float root_quat[4] = {rbe[3], rbe[4], rbe[5], rbe[6]};
+        EnvState st;
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            st.q[d] = dofe[2 * d];
+            st.qd[d] = dofe[2 * d + 1];
+            st.dof_force[d] = dof_force[(size_t)i * ND + d];
+        }
+        float* be = roote + 2 * 13;
+        st.ball.p = mk(be[0], be[1], be[2]);
+        st.ball.v = mk(be[7], be[8], be[9]);
+        st.progress = b.progress[i] + 1;                                   // TT:1023
+        st.flags = b.flags[i];
+        st.episode = b.episode[i];
+        RewardIn in;
+        in.humanoid_x = roote[0];
+        in.paddle = bpos[NB - 1];
+        in.pre_vx = pre_vx[i];
+        in.bp = st.ball.p;
+        in.vx = st.ball.v.x;
+        float power = 0.f;
+#pragma unroll
+        for (int d = 0; d < ND; d++) power += fabsf(st.dof_force[d] * st.qd[d]);
+        in.power = power;
+        in.progress = st.progress;
+        long long reset;
+        float rew = compute_reward(cfg, in, st.flags, reset);
+        if (reset) {                                                        // TT:847-906
+            st.episode += 1;
+            V3 serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
+                                : serve_velocity(cfg, (uint32_t)(cfg.env_id_offset + i), st.episode);
+            const float* ipos[3] = {cfg.humanoid_root_pos, cfg.table_root_pos, cfg.ball_init_pos};
+            const float* iquat[3] = {cfg.humanoid_root_quat, cfg.table_root_quat, cfg.ball_init_quat};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {                                   // TT:853-855
+#pragma unroll
+                for (int k = 0; k < 3; k++) roote[a * 13 + k] = ipos[a][k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) roote[a * 13 + 3 + k] = iquat[a][k];
+#pragma unroll
+                for (int k = 7; k < 13; k++) roote[a * 13 + k] = 0.f;
+            }
+            be[7] = serve.x; be[8] = serve.y; be[9] = serve.z;              // TT:857-862
+            st.ball.p = ld3(cfg.ball_init_pos);
+            st.ball.v = serve;
+            if (cfg.variant != PPENV_VARIANT_TN) {                          // TN:888-901 keeps the dof state
+#pragma unroll
+                for (int d = 0; d < ND; d++) {
+                    st.q[d] = cfg.init_dof_pos[d]; st.qd[d] = cfg.init_dof_vel[d];
+                    dofe[2 * d] = st.q[d]; dofe[2 * d + 1] = st.qd[d];
+                }
+            }
+            st.progress = 0;
+            st.flags = PPENV_FLAG_NO_BOUNCE;
+        }
+        LdsRowStore store{&s_obs[lane * kObsStride]};
+        write_obs(bpos, bvel, root_quat, st.q, st.qd, st.ball.p, st.ball.v, store);
+        b.progress[i] = st.progress;
+        b.flags[i] = st.flags;
+        b.episode[i] = st.episode;
+        b.rew[i] = rew;
+        b.reset[i] = reset;
+    }
+    __syncthreads();
+    flush_obs(s_obs, b.obs, base, nvalid);
+}
+
+// ------------------------------------------------------------ gym.refresh_* equivalents
+__global__ void refresh_root_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, float* out) {
+    const ppenv_config& cfg = *cfgp;
+    const int n = cfg.num_envs;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* r = out + (size_t)i * 39;
+    for (int k = 0; k < 39; k++) r[k] = 0.f;
+    for (int k = 0; k < 3; k++) { r[k] = cfg.humanoid_root_pos[k]; r[13 + k] = cfg.table_root_pos[k]; }
+    for (int k = 0; k < 4; k++) { r[3 + k] = cfg.humanoid_root_quat[k]; r[16 + k] = cfg.table_root_quat[k]; }
+    for (int k = 0; k < 13; k++) r[26 + k] = b.ball[(size_t)k * n + i];
+}
+__global__ void refresh_dof_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, float* out) {
+    const ppenv_config& cfg = *cfgp;
+    const int n = cfg.num_envs;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int d = 0; d < ND; d++) {
+        out[((size_t)i * ND + d) * 2] = b.dof_pos[(size_t)d * n + i];
+        out[((size_t)i * ND + d) * 2 + 1] = b.dof_vel[(size_t)d * n + i];
+    }
+}
+__global__ void refresh_dof_force_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, float* out) {
+    const ppenv_config& cfg = *cfgp;
+    const int n = cfg.num_envs;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int d = 0; d < ND; d++) out[(size_t)i * ND + d] = b.dof_force[(size_t)d * n + i];
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void refresh_rb_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, float* out) {
+    const ppenv_config& cfg = *cfgp;
+    const int n = cfg.num_envs;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float q[ND], qd[ND];
+    for (int d = 0; d < ND; d++) { q[d] = b.dof_pos[(size_t)d * n + i]; qd[d] = b.dof_vel[(size_t)d * n + i]; }
+    BodyState bodies[NB];
+    bodies_of_state<T>(cfg, q, qd, bodies);
+    float* rb = out + (size_t)i * PPENV_NUM_BODIES * 13;
+    for (int body = 0; body < PPENV_NUM_HUMANOID_BODIES; body++) {
+        float* r = rb + body * 13;
+        for (int k = 0; k < 3; k++) r[k] = cfg.humanoid_root_pos[k];
+        for (int k = 0; k < 4; k++) r[3 + k] = cfg.humanoid_root_quat[k];
+        for (int k = 7; k < 13; k++) r[k] = 0.f;
+    }
+    const int body_ids[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        float* r = rb + body_ids[j] * 13;
+        r[0] = bodies[j].pos.x; r[1] = bodies[j].pos.y; r[2] = bodies[j].pos.z;
+        float qt[4];
+        rot_to_quat(bodies[j].rot, qt);
+        r[3] = qt[0]; r[4] = qt[1]; r[5] = qt[2]; r[6] = qt[3];
+        r[7] = bodies[j].lin.x; r[8] = bodies[j].lin.y; r[9] = bodies[j].lin.z;
+        r[10] = bodies[j].ang.x; r[11] = bodies[j].ang.y; r[12] = bodies[j].ang.z;
+    }
+    float* t = rb + 40 * 13;
+    for (int k = 0; k < 13; k++) t[k] = 0.f;
+    for (int k = 0; k < 3; k++) t[k] = cfg.table_root_pos[k];
+    for (int k = 0; k < 4; k++) t[3 + k] = cfg.table_root_quat[k];
+    float* bl = rb + 41 * 13;
+    for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
+}
+
+// serve override [N,3] row-major -> SoA [3][N]
+__global__ void serve_transpose_kernel(int n, const float* in, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 3; k++) out[(size_t)k * n + i] = in[(size_t)i * 3 + k];
+}
+
+// ------------------------------------------------------------------------- host side
+thread_local char g_err[512] = "";
+void set_err(const char* fmt, const char* a = "", const char* b = "") { snprintf(g_err, sizeof g_err, fmt, a, b); }
+
+#define PP_HIP(call)                                                   \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) {                                        \
+            set_err("%s failed: %s", #call, hipGetErrorString(e_));    \
+            return PPENV_EHIP;                                         \
+        }                                                              \
+    } while (0)
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+    size_t obs, rew, reset, progress, dof_pos, dof_vel, dof_force, ball, flags, episode, serve, cfg, total;
+};
+Layout layout_for(int n) {
+    Layout l;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
+    l.obs = take((size_t)n * PPENV_NUM_OBS * 4);
+    l.rew = take((size_t)n * 4);
+    l.reset = take((size_t)n * 8);
+    l.progress = take((size_t)n * 8);
+    l.dof_pos = take((size_t)n * ND * 4);
+    l.dof_vel = take((size_t)n * ND * 4);
+    l.dof_force = take((size_t)n * ND * 4);
+    l.ball = take((size_t)n * 13 * 4);
+    l.flags = take((size_t)n * 4);
+    l.episode = take((size_t)n * 4);
+    l.serve = take((size_t)n * 3 * 4);
+    l.cfg = take(sizeof(ppenv_config));
+    l.total = o;
+    return l;
+}
+
+bool validate(const ppenv_config* c) {
+    if (!c) { set_err("config is NULL"); return false; }
+    if (c->abi_version != PPENV_ABI_VERSION) { set_err("config.abi_version does not match this library"); return false; }
+    if (c->num_envs <= 0) { set_err("num_envs must be positive"); return false; }
+    if (c->variant < PPENV_VARIANT_T3 || c->variant > PPENV_VARIANT_TN) { set_err("unknown task variant"); return false; }
+    if (c->substeps < 1 || c->substeps > 16 || c->ball_substeps < 1 || c->ball_substeps > 64) { set_err("substeps / ball_substeps out of range"); return false; }
+    if (!(c->dt > 0.f)) { set_err("dt must be positive"); return false; }
+    if (!topo_matches<TopoG1>(*c)) {
+        set_err("chain topology (joint axes / shape links / observed-body frames) has no compiled kernel instantiation; "
+                "this build ships the Unitree G1 right-arm chain (ppenv_device.h TopoG1)");
+        return false;
+    }
+    for (int d = 0; d < ND; d++)
+        if (!(c->joint[d].mass > 0.f) || !(c->joint[d].lower <= c->joint[d].upper)) { set_err("joint table: mass must be > 0 and lower <= upper"); return false; }
+    return true;
+}
+
+int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+}  // namespace
+
+struct ppenv {
+    ppenv_config cfg;
+    ppenv_config* cfg_dev;   // the same, in device memory (kernels read it with scalar loads)
+    DevBuffers buf;
+    Layout lay;
+    void* arena;
+    bool owns_arena;
+    int serve_on;
+};
+
+namespace {
+int use_device(const ppenv* e) {
+    int cur = -1;
+    PP_HIP(hipGetDevice(&cur));
+    if (cur != e->cfg.device_id) PP_HIP(hipSetDevice(e->cfg.device_id));
+    return PPENV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ppenv_abi_version(void) { return PPENV_ABI_VERSION; }
+const char* ppenv_last_error(void) { return g_err; }
+
+size_t ppenv_arena_bytes(const ppenv_config* cfg) {
+    if (!cfg || cfg->num_envs <= 0) return 0;
+    return layout_for(cfg->num_envs).total;
+}
+
+int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, void* stream, ppenv** out) {
+    if (!out) { set_err("out is NULL"); return PPENV_EINVAL; }
+    *out = nullptr;
+    if (!validate(cfg)) return PPENV_EINVAL;
+    int ndev = 0;
+    PP_HIP(hipGetDeviceCount(&ndev));
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) { set_err("device_id out of range"); return PPENV_EINVAL; }
+    ppenv* e = new (std::nothrow) ppenv;
+    if (!e) { set_err("out of host memory"); return PPENV_ENOMEM; }
+    e->cfg = *cfg;
+    e->lay = layout_for(cfg->num_envs);
+    e->serve_on = 0;
+    e->arena = nullptr;
+    e->owns_arena = false;
+    if (hipSetDevice(cfg->device_id) != hipSuccess) { delete e; set_err("hipSetDevice failed"); return PPENV_EHIP; }
+    if (arena_dev) {
+        if (arena_bytes < e->lay.total || ((uintptr_t)arena_dev & 255u)) {
+            delete e;
+            set_err("arena too small or not 256-byte aligned");
+            return PPENV_EINVAL;
+        }
+        e->arena = arena_dev;
+    } else {
+        if (hipMalloc(&e->arena, e->lay.total) != hipSuccess) { delete e; set_err("hipMalloc of the env arena failed"); return PPENV_ENOMEM; }
+        e->owns_arena = true;
+    }
+    char* a = (char*)e->arena;
+    const Layout& l = e->lay;
+    e->buf = DevBuffers{(float*)(a + l.obs), (float*)(a + l.rew), (long long*)(a + l.reset), (long long*)(a + l.progress),
+                        (float*)(a + l.dof_pos), (float*)(a + l.dof_vel), (float*)(a + l.dof_force), (float*)(a + l.ball),
+                        (uint32_t*)(a + l.flags), (uint32_t*)(a + l.episode), (float*)(a + l.serve)};
+    e->cfg_dev = (ppenv_config*)(a + l.cfg);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t err = hipMemsetAsync(e->arena, 0, l.total, s);
+    if (err == hipSuccess) err = hipMemcpyAsync(e->cfg_dev, &e->cfg, sizeof(ppenv_config), hipMemcpyHostToDevice, s);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(init_kernel<TopoG1>, dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->cfg_dev, e->buf, 0, 0);
+        err = hipGetLastError();
+    }
+    if (err != hipSuccess) {
+        set_err("initialising the env state failed: %s", hipGetErrorString(err));
+        if (e->owns_arena) (void)hipFree(e->arena);
+        delete e;
+        return PPENV_EHIP;
+    }
+    *out = e;
+    return PPENV_OK;
+}
+
+void ppenv_destroy(ppenv* e) {
+    if (!e) return;
+    if (e->owns_arena && e->arena) {
+        (void)hipSetDevice(e->cfg.device_id);
+        (void)hipFree(e->arena);
+    }
+    delete e;
+}
+
+int ppenv_buffers_of(ppenv* e, ppenv_buffers* out) {
+    if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
+    out->num_envs = e->cfg.num_envs;
+    out->obs_buf = e->buf.obs; out->rew_buf = e->buf.rew;
+    out->reset_buf = (int64_t*)e->buf.reset; out->progress_buf = (int64_t*)e->buf.progress;
+    out->dof_pos = e->buf.dof_pos; out->dof_vel = e->buf.dof_vel; out->dof_force = e->buf.dof_force; out->ball = e->buf.ball;
+    out->flags = e->buf.flags; out->episode = e->buf.episode; out->serve_override = e->buf.serve;
+    return PPENV_OK;
+}
+
+int ppenv_config_of(ppenv* e, ppenv_config* out) {
+    if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
+    *out = e->cfg;
+    return PPENV_OK;
+}
+
+int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
+    if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    hipLaunchKernelGGL(step_kernel<TopoG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf,
+                       actions_dev, e->serve_on);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+
+int ppenv_reset_all(ppenv* e, void* stream) {
+    if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    hipLaunchKernelGGL(init_kernel<TopoG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf, 1,
+                       e->serve_on);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+
+int ppenv_post_physics_step(ppenv* e, const float* rigid_body_states_dev, float* root_states_dev, float* dof_states_dev,
+                            const float* dof_force_dev, const float* pre_ball_vx_dev, void* stream) {
+    if (!e || !rigid_body_states_dev || !root_states_dev || !dof_states_dev || !dof_force_dev || !pre_ball_vx_dev) {
+        set_err("NULL argument");
+        return PPENV_EINVAL;
+    }
+    if (int rc = use_device(e)) return rc;
+    hipLaunchKernelGGL(post_physics_kernel, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf,
+                       rigid_body_states_dev, root_states_dev, dof_states_dev, dof_force_dev, pre_ball_vx_dev, e->serve_on);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+
+int ppenv_refresh_root_states(ppenv* e, float* out, void* stream) {
+    if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    hipLaunchKernelGGL(refresh_root_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+int ppenv_refresh_dof_states(ppenv* e, float* out, void* stream) {
+    if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    hipLaunchKernelGGL(refresh_dof_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+int ppenv_refresh_dof_force(ppenv* e, float* out, void* stream) {
+    if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    hipLaunchKernelGGL(refresh_dof_force_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+int ppenv_refresh_rigid_body_states(ppenv* e, float* out, void* stream) {
+    if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    hipLaunchKernelGGL(refresh_rb_kernel<TopoG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+
+int ppenv_set_serve_override(ppenv* e, const float* serve_dev, int on, void* stream) {
+    if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    if (on && serve_dev) {
+        hipLaunchKernelGGL(serve_transpose_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->cfg.num_envs,
+                           serve_dev, e->buf.serve);
+        PP_HIP(hipGetLastError());
+    }
+    e->serve_on = on ? 1 : 0;
+    return PPENV_OK;
+}
+
+size_t ppenv_state_bytes(ppenv* e) {
+    if (!e) return 0;
+    return (size_t)e->cfg.num_envs * ((ND * 3 + 13) * 4 + 4 + 4 + 8 + 8);
+}
+
+static int state_io(ppenv* e, char* blob, size_t nbytes, bool to_host) {
+    if (!e || !blob) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (nbytes != ppenv_state_bytes(e)) { set_err("state blob size does not match this handle"); return PPENV_ESTATE; }
+    if (int rc = use_device(e)) return rc;
+    PP_HIP(hipDeviceSynchronize());
+    const size_t n = (size_t)e->cfg.num_envs;
+    struct Part { void* dev; size_t bytes; };
+    const Part parts[] = {{e->buf.dof_pos, n * ND * 4}, {e->buf.dof_vel, n * ND * 4}, {e->buf.dof_force, n * ND * 4}, {e->buf.ball, n * 13 * 4},
+                          {e->buf.flags, n * 4}, {e->buf.episode, n * 4}, {e->buf.progress, n * 8}, {e->buf.reset, n * 8}};
+    for (const Part& p : parts) {
+        if (to_host) PP_HIP(hipMemcpy(blob, p.dev, p.bytes, hipMemcpyDeviceToHost));
+        else PP_HIP(hipMemcpy(p.dev, blob, p.bytes, hipMemcpyHostToDevice));
+        blob += p.bytes;
+    }
+    return PPENV_OK;
+}
+int ppenv_get_state(ppenv* e, void* dst_host, size_t n) { return state_io(e, (char*)dst_host, n, true); }
+int ppenv_set_state(ppenv* e, const void* src_host, size_t n) { return state_io(e, (char*)src_host, n, false); }
+
+}  // extern "C"

@@ -1,0 +1,819 @@
+// ppenv_device.h — per-env arithmetic of the fused HumanoidPingpong step (fp32).
+//
+// One lane owns one env.  Everything here is straight-line inline code on
+// registers: the articulated-body algorithm for the 7-DoF arm in link
+// coordinates (Featherstone, RBDA table 7.1) with the PD drive folded in
+// implicitly, the ball's micro-stepped contact model, and the reference's
+// reward / reset / observation arithmetic (tasks/humanoid_pingpong_3_actor_tilt.py
+// "TT":1105-1270,1640-1708 and the T3 / TN counterparts, cited inline).
+//
+// Functions are PP_HD (host + device) so that tests/csrc/host_shim.cpp can run
+// the identical arithmetic on the CPU next to the oracle; the product only ever
+// calls them from the HIP kernels in ppenv_kernels.hip.
+//
+// The chain topology is a compile-time parameter (joint axes and the links the
+// collision shapes hang on) so that every per-joint loop unrolls into
+// register-resident code; numeric model data comes from ppenv_config, which the
+// kernels receive by value in the kernarg segment (wave-uniform -> SGPRs).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/ppenv.h"
+
+#if defined(__HIPCC__)
+#define PP_HD __host__ __device__ __forceinline__
+#else
+#define PP_HD inline __attribute__((always_inline))
+#endif
+
+namespace pp {
+
+constexpr int ND = PPENV_NUM_DOF;
+constexpr int NB = PPENV_NUM_OBS_BODIES;
+
+// ---- joint-angle trig.  Device: the hardware v_sin/v_cos (abs err ~4e-7 on
+// [-pi, pi], where the limits keep every joint); host shim: libm.
+PP_HD void sincos_joint(float q, float& s, float& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    s = __sinf(q);
+    c = __cosf(q);
+#else
+    s = sinf(q);
+    c = cosf(q);
+#endif
+}
+
+// Model constants live in a ppenv_config in device memory and are wave-uniform, so they are
+// read with scalar loads.  Every per-joint / per-contact block below re-derives its config
+// reference through launder(): an empty asm the optimiser cannot see through, which stops
+// loop-invariant code motion from hoisting ~600 constants out of the substep loops and
+// holding them live (that spilled >1000 SGPRs); loads stay next to their use instead.
+PP_HD const ppenv_config& launder(const ppenv_config& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ppenv_config* p = &c;
+    asm volatile("" : "+s"(p));
+    return *p;
+#else
+    return c;
+#endif
+}
+
+// ------------------------------------------------------------------ small math
+struct V3 { float x, y, z; };
+struct M3 { float m[9]; };                 // row-major
+struct S3 { float xx, yy, zz, xy, xz, yz; }; // symmetric 3x3
+
+PP_HD V3 mk(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+PP_HD V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+PP_HD V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PP_HD V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PP_HD V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+PP_HD V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+PP_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PP_HD V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PP_HD V3 madd(V3 a, V3 b, float s) { return mk(a.x + b.x * s, a.y + b.y * s, a.z + b.z * s); }  // a + b*s
+PP_HD float comp(V3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+PP_HD V3 unit(int k) { return mk(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f); }
+
+PP_HD V3 row(const M3& a, int i) { return mk(a.m[3 * i], a.m[3 * i + 1], a.m[3 * i + 2]); }
+PP_HD V3 col(const M3& a, int j) { return mk(a.m[j], a.m[3 + j], a.m[6 + j]); }
+PP_HD V3 mul(const M3& a, V3 v) { return mk(dot(row(a, 0), v), dot(row(a, 1), v), dot(row(a, 2), v)); }
+PP_HD V3 tmul(const M3& a, V3 v) { return mk(dot(col(a, 0), v), dot(col(a, 1), v), dot(col(a, 2), v)); }  // a^T v
+PP_HD M3 mul(const M3& a, const M3& b) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+    return r;
+}
+PP_HD M3 mul_t(const M3& a, const M3& b) {   // a * b^T
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[3 * i + j] = dot(row(a, i), row(b, j));
+    return r;
+}
+PP_HD M3 ldm(const float* p) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.m[i] = p[i];
+    return r;
+}
+PP_HD M3 from_sym(const S3& s) {
+    M3 r = {{s.xx, s.xy, s.xz, s.xy, s.yy, s.yz, s.xz, s.yz, s.zz}};
+    return r;
+}
+PP_HD V3 mul(const S3& s, V3 v) {
+    return mk(s.xx * v.x + s.xy * v.y + s.xz * v.z, s.xy * v.x + s.yy * v.y + s.yz * v.z, s.xz * v.x + s.yz * v.y + s.zz * v.z);
+}
+PP_HD V3 symcol(const S3& s, int k) { return k == 0 ? mk(s.xx, s.xy, s.xz) : (k == 1 ? mk(s.xy, s.yy, s.yz) : mk(s.xz, s.yz, s.zz)); }
+PP_HD float symdiag(const S3& s, int k) { return k == 0 ? s.xx : (k == 1 ? s.yy : s.zz); }
+// s -= u u^T * k
+PP_HD void sym_rank1_sub(S3& s, V3 u, float k) {
+    V3 uk = u * k;
+    s.xx -= u.x * uk.x; s.yy -= u.y * uk.y; s.zz -= u.z * uk.z;
+    s.xy -= u.x * uk.y; s.xz -= u.x * uk.z; s.yz -= u.y * uk.z;
+}
+// E * S * E^T for symmetric S
+PP_HD S3 rot_sym(const M3& e, const S3& s) {
+    M3 t = mul(e, from_sym(s));
+    S3 r;
+    r.xx = dot(row(t, 0), row(e, 0)); r.yy = dot(row(t, 1), row(e, 1)); r.zz = dot(row(t, 2), row(e, 2));
+    r.xy = dot(row(t, 0), row(e, 1)); r.xz = dot(row(t, 0), row(e, 2)); r.yz = dot(row(t, 1), row(e, 2));
+    return r;
+}
+PP_HD void add_sym(S3& a, const S3& b) { a.xx += b.xx; a.yy += b.yy; a.zz += b.zz; a.xy += b.xy; a.xz += b.xz; a.yz += b.yz; }
+
+// E(q) = origin_rot * Rot(axis, q): child coordinates -> parent coordinates
+template <int AX>
+PP_HD M3 joint_rot(const float* r0, float c, float s) {
+    V3 c0 = mk(r0[0], r0[3], r0[6]), c1 = mk(r0[1], r0[4], r0[7]), c2 = mk(r0[2], r0[5], r0[8]);
+    V3 e0, e1, e2;
+    if (AX == 0) { e0 = c0; e1 = c1 * c + c2 * s; e2 = c2 * c - c1 * s; }
+    else if (AX == 1) { e0 = c0 * c - c2 * s; e1 = c1; e2 = c0 * s + c2 * c; }
+    else { e0 = c0 * c + c1 * s; e1 = c1 * c - c0 * s; e2 = c2; }
+    M3 e = {{e0.x, e1.x, e2.x, e0.y, e1.y, e2.y, e0.z, e1.z, e2.z}};
+    return e;
+}
+
+// rotation matrix -> xyzw quaternion with w >= 0
+PP_HD void rot_to_quat(const M3& r, float q[4]) {
+    float tr = r.m[0] + r.m[4] + r.m[8];
+    float x, y, z, w;
+    if (tr > 0.f) {
+        float s = sqrtf(tr + 1.0f) * 2.f;
+        w = 0.25f * s; x = (r.m[7] - r.m[5]) / s; y = (r.m[2] - r.m[6]) / s; z = (r.m[3] - r.m[1]) / s;
+    } else if (r.m[0] > r.m[4] && r.m[0] > r.m[8]) {
+        float s = sqrtf(1.0f + r.m[0] - r.m[4] - r.m[8]) * 2.f;
+        w = (r.m[7] - r.m[5]) / s; x = 0.25f * s; y = (r.m[1] + r.m[3]) / s; z = (r.m[2] + r.m[6]) / s;
+    } else if (r.m[4] > r.m[8]) {
+        float s = sqrtf(1.0f + r.m[4] - r.m[0] - r.m[8]) * 2.f;
+        w = (r.m[2] - r.m[6]) / s; x = (r.m[1] + r.m[3]) / s; y = 0.25f * s; z = (r.m[5] + r.m[7]) / s;
+    } else {
+        float s = sqrtf(1.0f + r.m[8] - r.m[0] - r.m[4]) * 2.f;
+        w = (r.m[3] - r.m[1]) / s; x = (r.m[2] + r.m[6]) / s; y = (r.m[5] + r.m[7]) / s; z = 0.25f * s;
+    }
+    if (w < 0.f) { x = -x; y = -y; z = -z; w = -w; }
+    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
+
+// ------------------------------------------------------------------------ RNG
+// Counter-based: (seed, global env id, episode, draw) -> U[0,1).  Same function
+// as the oracle's (oracle/ppenv_oracle.c rng_uniform); the reference's host-side
+// Python `random` stream (TT:307-312) cannot be reproduced by a vectorised env.
+PP_HD uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+PP_HD float rng_uniform(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t k) {
+    uint64_t s = mix64(seed + 0x9E3779B97F4A7C15ull * ((uint64_t)gid + 1));
+    uint64_t x = mix64(s + 0x9E3779B97F4A7C15ull * ((uint64_t)episode * 4 + k + 1));
+    return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+// sin / cos of a serve angle (|x| <= ~0.5 rad): Taylor to x^9 / x^8, exact to fp32 there
+PP_HD void sincos_small(float x, float& s, float& c) {
+    float x2 = x * x;
+    s = x * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
+    c = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
+}
+// generate_random_speed_for_ball: TT:296-323 / T3:289-305 / TN:301-328
+PP_HD V3 serve_velocity(const ppenv_config& c, uint32_t gid, uint32_t episode) {
+    const float deg = 0.017453292519943295f;
+    float u0 = rng_uniform(c.seed, gid, episode, 0);
+    float u1 = rng_uniform(c.seed, gid, episode, 1);
+    float u2 = rng_uniform(c.seed, gid, episode, 2);
+    float speed = c.serve_speed_lo + (c.serve_speed_hi - c.serve_speed_lo) * u0;
+    float a = (c.serve_tilt_lo_deg + (c.serve_tilt_hi_deg - c.serve_tilt_lo_deg) * u1) * deg;
+    float az = (c.serve_tilt_z_lo_deg + (c.serve_tilt_z_hi_deg - c.serve_tilt_z_lo_deg) * u2) * deg;
+    float sa, ca, sz, cz;
+    sincos_small(a, sa, ca);
+    sincos_small(az, sz, cz);
+    if (c.variant == PPENV_VARIANT_T3) return mk(-speed * ca, -speed * sa, 0.f);                 // T3:296-300
+    if (c.variant == PPENV_VARIANT_TT) return mk(-speed * ca * cz, -speed * sa * sz, -speed * sa); // TT:307-318 (sic)
+    return mk(-speed * ca * cz, speed * sa * cz, speed * sz);                                     // TN:312-323
+}
+
+// --------------------------------------------------------------- chain topology
+template <uint32_t AXES, uint32_t SHAPE_LINKS, int NSHAPES>
+struct Topo {
+    static constexpr int kShapes = NSHAPES;
+    PP_HD static constexpr int axis(int i) { return (int)((AXES >> (2 * i)) & 3u); }
+    // link a shape hangs on, -1 = static
+    PP_HD static constexpr int shape_link(int s) { return (int)((SHAPE_LINKS >> (4 * s)) & 15u) - 1; }
+};
+
+// world-frame collision geometry of the moving parts, sampled at a substep boundary
+template <int NSHAPES>
+struct ArmGeom {
+    V3 pc, pn;                 // paddle centre, blade normal
+    V3 a[NSHAPES], b[NSHAPES]; // capsule end points (static shapes: constants)
+};
+
+// per-joint quantities pass 1 leaves for passes 2 and 3
+struct JointSave {
+    float c, s;   // cos q, sin q
+    V3 w, v;      // link velocity, link coordinates (angular, linear at the link origin)
+    V3 ua, ub;    // U = I^A S, angular / linear halves
+    float dinv, u;
+};
+
+// world pose + velocity of one observed body: pos3 quat4 lin3 ang3 is the
+// reference's rigid-body row layout (TT:166-168)
+struct BodyState { V3 pos; M3 rot; V3 lin, ang; };
+
+// Forward kinematics sweep base -> tip.  Fills JointSave::{c,s,w,v}; hands every
+// link's world transform to `vis(i, Rw, pw, w_link, v_link)`.
+template <class T, class Visitor>
+PP_HD void fk_sweep(const ppenv_config& cfg, const float* q, const float* qd, JointSave* js, Visitor& vis) {
+    M3 Rp = ldm(cfg.base_rot);
+    V3 pp = ld3(cfg.base_pos);
+    V3 wp = mk(0, 0, 0), vp = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+        const ppenv_joint& J = launder(cfg).joint[i];
+        float s, c;
+        sincos_joint(q[i], s, c);
+        M3 E = T::axis(i) == 0 ? joint_rot<0>(J.origin_rot, c, s) : (T::axis(i) == 1 ? joint_rot<1>(J.origin_rot, c, s) : joint_rot<2>(J.origin_rot, c, s));
+        V3 r = ld3(J.origin_xyz);
+        V3 pw = pp + mul(Rp, r);
+        M3 Rw = mul(Rp, E);
+        V3 w = tmul(E, wp);
+        V3 v = tmul(E, vp + cross(wp, r));
+        if (T::axis(i) == 0) w.x += qd[i]; else if (T::axis(i) == 1) w.y += qd[i]; else w.z += qd[i];
+        js[i].c = c; js[i].s = s; js[i].w = w; js[i].v = v;
+        vis(i, Rw, pw, w, v);
+        Rp = Rw; pp = pw; wp = w; vp = v;
+    }
+}
+
+// collects the moving collision geometry during an FK sweep
+template <class T>
+struct GeomVisitor {
+    const ppenv_config& cfg;
+    ArmGeom<T::kShapes>& g;
+    PP_HD GeomVisitor(const ppenv_config& c, ArmGeom<T::kShapes>& gg) : cfg(c), g(gg) {}
+    PP_HD void operator()(int i, const M3& Rw, V3 pw, V3, V3) {
+        if (i == ND - 1) {   // paddle_link is validated to be the last link at create time
+            const ppenv_config& c = launder(cfg);
+            g.pc = pw + mul(Rw, ld3(c.paddle_center));
+            g.pn = mul(Rw, ld3(c.paddle_normal));
+        }
+#pragma unroll
+        for (int s = 0; s < T::kShapes; s++)
+            if (T::shape_link(s) == i) {
+                const ppenv_shape& sh = launder(cfg).shape[s];
+                g.a[s] = pw + mul(Rw, ld3(sh.a));
+                g.b[s] = pw + mul(Rw, ld3(sh.b));
+            }
+    }
+};
+template <class T>
+PP_HD void static_geometry(const ppenv_config& cfg, ArmGeom<T::kShapes>& g) {
+#pragma unroll
+    for (int s = 0; s < T::kShapes; s++)
+        if (T::shape_link(s) < 0) { g.a[s] = ld3(cfg.shape[s].a); g.b[s] = ld3(cfg.shape[s].b); }
+}
+
+// geometry + the observed bodies (obs_body[1..7] are the chain links, [8],[9] ride on the last link).
+// FULL = false keeps only what the fused step consumes (position + linear velocity: TT:1671-1673 reads
+// body_pos / body_vel, the reward reads the paddle position); FULL = true also keeps orientation and
+// angular velocity for ppenv_refresh_rigid_body_states.
+template <class T, bool FULL>
+struct BodyVisitor {
+    const ppenv_config& cfg;
+    ArmGeom<T::kShapes>& g;
+    BodyState* bodies;   // [NB]
+    PP_HD BodyVisitor(const ppenv_config& c, ArmGeom<T::kShapes>& gg, BodyState* b) : cfg(c), g(gg), bodies(b) {}
+    PP_HD void operator()(int i, const M3& Rw, V3 pw, V3 w, V3 v) {
+        GeomVisitor<T> gv(cfg, g);
+        gv(i, Rw, pw, w, v);
+        V3 ww = mul(Rw, w), vw = mul(Rw, v);
+        bodies[1 + i].pos = pw; bodies[1 + i].lin = vw;
+        if (FULL) { bodies[1 + i].rot = Rw; bodies[1 + i].ang = ww; }
+        if (i == ND - 1) {
+#pragma unroll
+            for (int j = 8; j < NB; j++) {
+                const ppenv_frame& f = launder(cfg).obs_body[j];
+                V3 off = mul(Rw, ld3(f.xyz));
+                bodies[j].pos = pw + off;
+                bodies[j].lin = vw + cross(ww, off);
+                if (FULL) { bodies[j].rot = mul(Rw, ldm(f.rot)); bodies[j].ang = ww; }
+            }
+        }
+    }
+};
+template <bool FULL>
+PP_HD void static_body(const ppenv_config& cfg, BodyState& b) {   // obs_body[0]: the pelvis, fixed at the root pose
+    b.pos = ld3(cfg.obs_body[0].xyz); b.lin = mk(0, 0, 0);
+    if (FULL) { b.rot = ldm(cfg.obs_body[0].rot); b.ang = mk(0, 0, 0); }
+}
+
+// --------------------------------------------------- ABA passes 2 and 3 (RBDA 7.1)
+// tau / arm_eff: drive torque and joint-space inertia added on the diagonal
+// (armature + the implicit PD terms).  Returns qdd.
+template <class T>
+PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, const float* tau, const float* arm_eff, float* qdd) {
+    // articulated inertia / bias force handed down by the child, in this link's coordinates
+    S3 cA = {0, 0, 0, 0, 0, 0}, cD = {0, 0, 0, 0, 0, 0};
+    M3 cB = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    V3 cn = mk(0, 0, 0), cf = mk(0, 0, 0);
+#pragma unroll
+    for (int i = ND - 1; i >= 0; i--) {
+        const ppenv_joint& J = launder(cfg).joint[i];
+        const int ax = T::axis(i);
+        V3 w = js[i].w, v = js[i].v;
+        // rigid-body inertia about the link origin: [[Io, m c x],[m c x^T, m 1]]
+        float m = J.mass;
+        V3 cm = ld3(J.com);
+        V3 mc = cm * m;
+        float cc = dot(cm, cm);
+        S3 A = {J.inertia[0] + m * (cc - cm.x * cm.x), J.inertia[1] + m * (cc - cm.y * cm.y), J.inertia[2] + m * (cc - cm.z * cm.z),
+                J.inertia[3] - m * cm.x * cm.y, J.inertia[4] - m * cm.x * cm.z, J.inertia[5] - m * cm.y * cm.z};
+        V3 h_ang = mul(A, w) + cross(mc, v);
+        V3 h_lin = v * m - cross(mc, w);
+        V3 pn = cross(w, h_ang) + cross(v, h_lin) + cn;
+        V3 pf = cross(w, h_lin) + cf;
+        add_sym(A, cA);
+        M3 B = {{cB.m[0], cB.m[1] - mc.z, cB.m[2] + mc.y, cB.m[3] + mc.z, cB.m[4], cB.m[5] - mc.x, cB.m[6] - mc.y, cB.m[7] + mc.x, cB.m[8]}};
+        S3 D = {cD.xx + m, cD.yy + m, cD.zz + m, cD.xy, cD.xz, cD.yz};
+
+        V3 ua = symcol(A, ax), ub = row(B, ax);
+        float dinv = 1.0f / (symdiag(A, ax) + arm_eff[i]);
+        float u = tau[i] - comp(pn, ax);
+        js[i].ua = ua; js[i].ub = ub; js[i].dinv = dinv; js[i].u = u;
+        if (i > 0) {
+            sym_rank1_sub(A, ua, dinv);
+            sym_rank1_sub(D, ub, dinv);
+            V3 uad = ua * dinv;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                float k = comp(uad, r);
+                B.m[3 * r] -= k * ub.x; B.m[3 * r + 1] -= k * ub.y; B.m[3 * r + 2] -= k * ub.z;
+            }
+            V3 e = unit(ax);
+            V3 cw = cross(w, e) * qd[i], cv = cross(v, e) * qd[i];   // c = v x S qd
+            float ud = u * dinv;
+            V3 pan = pn + mul(A, cw) + mul(B, cv) + ua * ud;
+            V3 paf = pf + tmul(B, cw) + mul(D, cv) + ub * ud;
+            // to the parent's coordinates: rotate by E, shift the origin by r
+            M3 E = ax == 0 ? joint_rot<0>(J.origin_rot, js[i].c, js[i].s) : (ax == 1 ? joint_rot<1>(J.origin_rot, js[i].c, js[i].s) : joint_rot<2>(J.origin_rot, js[i].c, js[i].s));
+            V3 r = ld3(J.origin_xyz);
+            S3 Ar = rot_sym(E, A), Dr = rot_sym(E, D);
+            M3 Br = mul_t(mul(E, B), E);
+            V3 nr = mul(E, pan), fr = mul(E, paf);
+            // Bp = Br + r x Dr  (column-wise cross)
+            M3 Dm = from_sym(Dr);
+            M3 Bp;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                V3 x = cross(r, col(Dm, j));
+                Bp.m[j] = Br.m[j] + x.x; Bp.m[3 + j] = Br.m[3 + j] + x.y; Bp.m[6 + j] = Br.m[6 + j] + x.z;
+            }
+            // Ap[i][j] = Ar[i][j] + (r x row_j(Bp))[i] + (r x row_i(Br))[j]
+            V3 wp0 = cross(r, row(Bp, 0)), wp1 = cross(r, row(Bp, 1)), wp2 = cross(r, row(Bp, 2));
+            V3 wb0 = cross(r, row(Br, 0)), wb1 = cross(r, row(Br, 1)), wb2 = cross(r, row(Br, 2));
+            cA.xx = Ar.xx + wp0.x + wb0.x; cA.yy = Ar.yy + wp1.y + wb1.y; cA.zz = Ar.zz + wp2.z + wb2.z;
+            cA.xy = Ar.xy + wp1.x + wb0.y; cA.xz = Ar.xz + wp2.x + wb0.z; cA.yz = Ar.yz + wp2.y + wb1.z;
+            cB = Bp; cD = Dr;
+            cn = nr + cross(r, fr); cf = fr;
+        }
+    }
+    // pass 3: accelerations base -> tip; the base "accelerates" upward by |g|
+    V3 aw = mk(0, 0, 0);
+    const ppenv_config& cb = launder(cfg);
+    V3 av = tmul(ldm(cb.base_rot), mk(0, 0, -cb.gravity_z));
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+        const ppenv_joint& J = launder(cfg).joint[i];
+        const int ax = T::axis(i);
+        M3 E = ax == 0 ? joint_rot<0>(J.origin_rot, js[i].c, js[i].s) : (ax == 1 ? joint_rot<1>(J.origin_rot, js[i].c, js[i].s) : joint_rot<2>(J.origin_rot, js[i].c, js[i].s));
+        V3 r = ld3(J.origin_xyz);
+        V3 e = unit(ax);
+        V3 aw2 = tmul(E, aw) + cross(js[i].w, e) * qd[i];
+        V3 av2 = tmul(E, av + cross(aw, r)) + cross(js[i].v, e) * qd[i];
+        float a = (js[i].u - dot(js[i].ua, aw2) - dot(js[i].ub, av2)) * js[i].dinv;
+        qdd[i] = a;
+        if (ax == 0) aw2.x += a; else if (ax == 1) aw2.y += a; else aw2.z += a;
+        aw = aw2; av = av2;
+    }
+}
+
+// PD drive (DOF_MODE_POS, TT:414,463) + one semi-implicit Euler substep of the arm.
+// Unsaturated joints are integrated implicitly in the PD terms (adds h Kd + h^2 Kp on
+// the joint-space inertia diagonal); a joint whose explicit PD torque exceeds the
+// effort limit gets the constant limit torque instead.
+template <class T>
+PP_HD void arm_substep(const ppenv_config& cfg, JointSave* js, float* q, float* qd, const float* target, float h, float* tau_drive) {
+    float tau[ND], arm[ND], qdd[ND];
+    bool sat[ND];
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+        const ppenv_joint& J = launder(cfg).joint[d];
+        float err = target[d] - q[d];
+        float t_exp = J.kp * err - J.kd * qd[d];
+        sat[d] = fabsf(t_exp) > J.effort;
+        float t_imp = J.kp * (err - h * qd[d]) - J.kd * qd[d];
+        tau[d] = sat[d] ? copysignf(J.effort, t_exp) : t_imp;
+        arm[d] = sat[d] ? J.armature : J.armature + h * J.kd + h * h * J.kp;
+    }
+    aba_solve<T>(cfg, js, qd, tau, arm, qdd);
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+        const ppenv_joint& J = launder(cfg).joint[d];
+        float err = target[d] - q[d];
+        float vn = qd[d] + h * qdd[d];
+        tau_drive[d] = sat[d] ? tau[d] : J.kp * (err - h * vn) - J.kd * vn;
+        vn = fminf(fmaxf(vn, -J.vel_limit), J.vel_limit);
+        float qn = q[d] + h * vn;
+        if (qn > J.upper) { qn = J.upper; vn = fminf(vn, 0.f); }
+        if (qn < J.lower) { qn = J.lower; vn = fmaxf(vn, 0.f); }
+        q[d] = qn; qd[d] = vn;
+    }
+}
+
+// ---------------------------------------------------------------- ball contacts
+struct Ball { V3 p, v, w; float quat[4]; };
+
+// n: unit normal surface -> ball; s: separation; u: surface velocity at the contact
+PP_HD void contact_resolve(const ppenv_config& c, Ball& b, V3 n, float s, V3 u, float e, float mu, float hb) {
+    if (!(s < c.contact_offset)) return;
+    const float r = c.ball_radius, kappa = c.ball_inertia_factor;
+    V3 vrel = b.v + cross(b.w, n * (-r)) - u;
+    float vn = dot(vrel, n);
+    if (vn < 0.f) {
+        float e_eff = (-vn > c.bounce_threshold) ? e : 0.f;
+        float jn = -(1.f + e_eff) * vn;
+        V3 vt = vrel - n * vn;
+        float vtl = sqrtf(dot(vt, vt));
+        float jt = 0.f;
+        V3 dir = mk(0, 0, 0);
+        if (vtl > 1e-9f) {
+            dir = vt * (1.f / vtl);
+            float stick = vtl / (1.f + 1.f / kappa);
+            jt = fminf(mu * jn, stick);
+        }
+        b.v = b.v + n * jn - dir * jt;
+        b.w = b.w + cross(n, dir) * (jt / (kappa * r));
+    }
+    if (s < 0.f) b.p = madd(b.p, n, fminf(-s, c.max_depenetration_velocity * hb));
+}
+PP_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+PP_HD void contact_box(const ppenv_config& c, Ball& b, const ppenv_box& box, float hb) {
+    V3 d = b.p - ld3(box.center);
+    V3 h = ld3(box.half);
+    // cheap reject: farther than radius + contact offset from the box on some axis
+    float reach = c.ball_radius + c.contact_offset;
+    if (fabsf(d.x) > h.x + reach || fabsf(d.y) > h.y + reach || fabsf(d.z) > h.z + reach) return;
+    V3 q = mk(clampf(d.x, -h.x, h.x), clampf(d.y, -h.y, h.y), clampf(d.z, -h.z, h.z));
+    V3 diff = d - q;
+    float dist = sqrtf(dot(diff, diff));
+    V3 n;
+    float s;
+    if (dist > 1e-12f) { n = diff * (1.f / dist); s = dist - c.ball_radius; }
+    else {   // centre inside the box: leave through the nearest face
+        float px = h.x - fabsf(d.x), py = h.y - fabsf(d.y), pz = h.z - fabsf(d.z);
+        if (px <= py && px <= pz) { n = mk(d.x >= 0.f ? 1.f : -1.f, 0, 0); s = -px - c.ball_radius; }
+        else if (py <= pz) { n = mk(0, d.y >= 0.f ? 1.f : -1.f, 0); s = -py - c.ball_radius; }
+        else { n = mk(0, 0, d.z >= 0.f ? 1.f : -1.f); s = -pz - c.ball_radius; }
+    }
+    contact_resolve(c, b, n, s, mk(0, 0, 0), box.restitution, box.friction, hb);
+}
+PP_HD void contact_capsule(const ppenv_config& c, Ball& b, V3 a, V3 bb, V3 ua, V3 ub, float radius, float e, float mu, float hb) {
+    V3 ab = bb - a;
+    float l2 = dot(ab, ab), t = 0.f;
+    if (l2 > 1e-12f) t = clampf(dot(b.p - a, ab) / l2, 0.f, 1.f);
+    V3 cp = madd(a, ab, t);
+    V3 diff = b.p - cp;
+    float dist = sqrtf(dot(diff, diff));
+    V3 n = dist > 1e-12f ? diff * (1.f / dist) : mk(0, 0, 1);
+    V3 u = madd(ua, ub - ua, t);
+    contact_resolve(c, b, n, dist - radius - c.ball_radius, u, e, mu, hb);
+}
+// the paddle blade: solid disc, centre cc, unit axis nn, centre velocity uc, axis rate nd
+PP_HD void contact_disc(const ppenv_config& c, Ball& b, V3 cc, V3 nn, V3 uc, V3 nd, float hb) {
+    const float R = c.paddle_radius, tp = c.paddle_half_thickness;
+    V3 d = b.p - cc;
+    float hgt = dot(d, nn);
+    V3 radial = d - nn * hgt;
+    float rr = sqrtf(dot(radial, radial));
+    V3 n, closest;
+    float s;
+    if (fabsf(hgt) < tp && rr < R) {   // centre inside the blade: leave through the nearer face
+        float sg = hgt >= 0.f ? 1.f : -1.f;
+        n = nn * sg;
+        s = -(tp - fabsf(hgt)) - c.ball_radius;
+        closest = cc + nn * (sg * tp) + radial;
+    } else {
+        float hc = clampf(hgt, -tp, tp);
+        float rc = fminf(rr, R);
+        V3 rdir = rr > 1e-12f ? radial * (rc / rr) : mk(0, 0, 0);
+        closest = cc + nn * hc + rdir;
+        V3 diff = b.p - closest;
+        float dist = sqrtf(dot(diff, diff));
+        n = dist > 1e-12f ? diff * (1.f / dist) : nn;
+        s = dist - c.ball_radius;
+    }
+    V3 u = uc + cross(cross(nn, nd), closest - cc);
+    contact_resolve(c, b, n, s, u, c.paddle_restitution, c.paddle_friction, hb);
+}
+
+PP_HD V3 lerp(V3 a, V3 b, float f) { return madd(a, b - a, f); }
+
+// one physics substep of the ball: ball_substeps micro-steps against the static scene
+// and the arm geometry interpolated between the substep's two ends (g0 -> g1)
+template <class T>
+PP_HD void ball_substep(const ppenv_config& cfg, Ball& b, const ArmGeom<T::kShapes>& g0, const ArmGeom<T::kShapes>& g1, float h) {
+    const int M = cfg.ball_substeps;
+    const float hb = h / (float)M;
+    const float inv_h = 1.0f / h;
+    for (int m = 0; m < M; m++) {
+        const ppenv_config& c = launder(cfg);
+        float f = (float)m / (float)M;
+        b.v.z += c.gravity_z * hb;
+        b.w = b.w * fmaxf(1.0f - c.ball_angular_damping * hb, 0.f);
+        contact_resolve(c, b, mk(0, 0, 1), b.p.z - c.ground_z - c.ball_radius, mk(0, 0, 0), c.ground_restitution, c.ground_friction, hb);
+        contact_box(c, b, c.table, hb);
+        contact_box(c, b, c.net, hb);
+        V3 db = b.p - ld3(c.humanoid_bound_center);
+        if (dot(db, db) < c.humanoid_bound_radius * c.humanoid_bound_radius) {
+            V3 cc = lerp(g0.pc, g1.pc, f);
+            V3 nn = lerp(g0.pn, g1.pn, f);
+            nn = nn * (1.f / sqrtf(dot(nn, nn)));
+            contact_disc(c, b, cc, nn, (g1.pc - g0.pc) * inv_h, (g1.pn - g0.pn) * inv_h, hb);
+#pragma unroll
+            for (int s = 0; s < T::kShapes; s++) {
+                const ppenv_shape& sh = launder(cfg).shape[s];
+                if (T::shape_link(s) < 0)
+                    contact_capsule(c, b, g0.a[s], g0.b[s], mk(0, 0, 0), mk(0, 0, 0), sh.radius, sh.restitution, sh.friction, hb);
+                else
+                    contact_capsule(c, b, lerp(g0.a[s], g1.a[s], f), lerp(g0.b[s], g1.b[s], f), (g1.a[s] - g0.a[s]) * inv_h,
+                                    (g1.b[s] - g0.b[s]) * inv_h, sh.radius, sh.restitution, sh.friction, hb);
+            }
+        }
+        b.p = madd(b.p, b.v, hb);
+    }
+    // orientation: q <- normalize(q + h/2 (w,0) (x) q), xyzw
+    float wx = b.w.x, wy = b.w.y, wz = b.w.z, x = b.quat[0], y = b.quat[1], z = b.quat[2], w = b.quat[3];
+    float k = 0.5f * h;
+    float nx = x + k * (wx * w + wy * z - wz * y);
+    float ny = y + k * (wy * w + wz * x - wx * z);
+    float nz = z + k * (wz * w + wx * y - wy * x);
+    float nw = w + k * (-wx * x - wy * y - wz * z);
+    float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+    b.quat[0] = nx * inv; b.quat[1] = ny * inv; b.quat[2] = nz * inv; b.quat[3] = nw * inv;
+}
+
+// ------------------------------------------------------ reward / reset decision
+// my_quat_rotate (isaacgymenvs.utils.torch_jit_utils, xyzw): a = v(2w^2-1), b = 2w(qv x v), c = 2 qv (qv.v)
+PP_HD V3 quat_rotate(const float q[4], V3 v) {
+    float qw = q[3];
+    V3 qv = mk(q[0], q[1], q[2]);
+    float s = 2.0f * (qw * qw) - 1.0f;
+    V3 cr = cross(qv, v);
+    float d = dot(qv, v);
+    return mk(v.x * s + cr.x * qw * 2.0f + qv.x * d * 2.0f, v.y * s + cr.y * qw * 2.0f + qv.y * d * 2.0f,
+              v.z * s + cr.z * qw * 2.0f + qv.z * d * 2.0f);
+}
+// calc_heading_quat_inv (same module): rotation by -heading about z
+PP_HD void heading_quat_inv(const float q[4], float out[4]) {
+    V3 rd = quat_rotate(q, mk(1, 0, 0));
+    float heading = atan2f(rd.y, rd.x);
+    float theta = (-heading) / 2.0f;
+    float sz = sinf(theta), w = cosf(theta);
+    float nrm = fmaxf(sqrtf(sz * sz + w * w), 1e-9f);
+    out[0] = 0.f; out[1] = 0.f; out[2] = sz / nrm; out[3] = w / nrm;
+}
+
+struct RewardIn {
+    float humanoid_x;   // humanoid1_root_states[..., 0]
+    V3 paddle;          // humanoid1_paddle_rb_states[..., 0:3]
+    float pre_vx;       // pre_ball2_root_states[..., 7]
+    V3 bp;              // ball position
+    float vx;           // ball vx
+    float power;        // sum_j |dof_force_j * dof_vel_j|
+    long long progress; // already incremented (TT:1023)
+};
+
+// compute_pingpong_reward_nv TT:1105-1270 / compute_pingpong_reward T3:1080-1173 /
+// compute_pingpong_reward_only_paddle TN:1115-1322.  flags is read-modify-write.
+PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& flags, long long& reset) {
+    const float Bx = in.bp.x, By = in.bp.y, Bz = in.bp.z, vx = in.vx, pre_vx = in.pre_vx;
+    const float alpha = c.alpha_velocity_reward, penalty = c.penalty, threshold = 0.1f;
+    const float power_reward = -c.power_coefficient * in.power;
+    uint32_t f = flags;
+    float reward;
+    long long die = 0;
+    if (c.variant == PPENV_VARIANT_T3) {
+        V3 dp = in.paddle - in.bp;
+        float dist = sqrtf(dp.x * dp.x + dp.y * dp.y + dp.z * dp.z);
+        float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                                 // T3:1117
+        float vel_reward = (pre_vx < 0.f && vx > 0.f) ? alpha * fabsf(vx) : 0.f;               // T3:1126-1128
+        reward = pos_reward + power_reward + vel_reward;                                        // T3:1141
+        bool missed = Bx < in.paddle.x - 1e-3f;                                                 // T3:1146
+        if (missed) { reward = reward + penalty; die = 1; }                                     // T3:1149,1158
+        if (Bz < threshold) die = 1;                                                            // T3:1161
+    } else if (c.variant == PPENV_VARIANT_TT) {
+        V3 dp = in.paddle - in.bp;
+        float dist = sqrtf(dp.x * dp.x + dp.y * dp.y + dp.z * dp.z);                            // TT:1144-1146
+        float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                                  // TT:1147
+        bool cond = pre_vx < 0.f && vx > 0.f;                                                   // TT:1153
+        float vel_reward = (cond && !(f & PPENV_FLAG_COND_CALC)) ? alpha * fabsf(vx) : 0.f;     // TT:1156-1160
+        if (cond) f |= PPENV_FLAG_COND_CALC;                                                    // TT:1163
+        bool missed = Bx < in.humanoid_x - 0.05f;                                               // TT:1169
+        reward = missed ? 0.f + penalty : 0.f;                                                  // TT:1172-1173
+        bool bounce = Bz < 0.83f && vx > 0.f && By < 0.6f && By > -0.6f;                        // TT:1184
+        float hit = 0.f;
+        bool early = Bx < 2.44f && bounce;
+        if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.not_hit_table_penalty;              // TT:1187-1191
+        if (early) { f |= PPENV_FLAG_REWARD_CALC; f &= ~PPENV_FLAG_NO_BOUNCE; }                 // TT:1192,1196
+        bool inx = Bx > 2.44f && Bx < 3.1f;                                                     // TT:1199
+        bool good = inx && bounce && (f & PPENV_FLAG_NO_BOUNCE);
+        if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.hit_table_reward;                    // TT:1201-1205
+        if (good) f |= PPENV_FLAG_REWARD_CALC;                                                  // TT:1206
+        if (Bx >= 3.1f && vx > 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.not_hit_table_penalty;   // TT:1209-1213
+        if (Bx >= 3.1f) f |= PPENV_FLAG_REWARD_CALC;                                            // TT:1214 (no vx guard)
+        float net = (Bx > 1.7f && Bx < 1.8f && vx > 0.f && By < 0.4f && By > -0.4f && Bz > 0.98f && Bz < 1.14f) ? 400.f : 0.f;  // TT:1226-1244
+        reward += (((pos_reward + power_reward) + vel_reward) + hit) + net;                     // TT:1251
+        if (Bz < threshold) die = 1;                                                            // TT:1263
+    } else {
+        bool hit_paddle = pre_vx < 0.f && vx > 1.0f;                                            // TN:1160
+        bool missed = (Bx < in.humanoid_x - 0.05f) || (Bx < in.paddle.x - 0.1f);                // TN:1165
+        reward = (!(f & PPENV_FLAG_MISSED_CALC) && missed) ? 0.f + penalty : 0.f;               // TN:1172-1176
+        if (missed) f |= PPENV_FLAG_MISSED_CALC;                                                // TN:1178
+        float dy = in.paddle.y - By, dz = in.paddle.z - Bz;
+        float dist = sqrtf(dy * dy + dz * dz);                                                  // TN:1185-1186
+        float pos_reward = 0.f;
+        if (!(f & PPENV_FLAG_COND_CALC) || (Bx < in.humanoid_x - 0.05f)) pos_reward = 1.0f * expf(-20.0f * dist * dist);  // TN:1188-1192
+        float vel_reward = (hit_paddle && !(f & PPENV_FLAG_COND_CALC)) ? alpha * fabsf(vx) : 0.f;   // TN:1198-1202
+        if (hit_paddle) f |= PPENV_FLAG_COND_CALC;                                              // TN:1204
+        reward += (pos_reward + power_reward) + vel_reward;                                     // TN:1299
+        if (Bz < threshold) reward = -800.f + reward;                                           // TN:1313-1315
+    }
+    flags = f;
+    reset = (in.progress >= (long long)c.max_episode_length - 1) ? 1 : die;                     // TT:1265
+    return reward;
+}
+
+// ------------------------------------------------------------- the fused step
+struct EnvState {
+    float q[ND], qd[ND], dof_force[ND];
+    Ball ball;
+    long long progress;
+    uint32_t flags, episode;
+};
+
+// Physics part of one VecTask.step for one env (pre_physics_step + gym.simulate):
+// updates st in place, returns the pre-reset observed-body states and pre_vx.
+template <class T>
+PP_HD void simulate_env(const ppenv_config& cfg, const float* actions, EnvState& st, BodyState* bodies, float& pre_vx) {
+    float target[ND];
+#pragma unroll
+    for (int d = 0; d < ND; d++) {   // VecTask.step clamp + TT:1008 (offset/scale TT:664-665)
+        const ppenv_config& c = launder(cfg);
+        float a = fminf(fmaxf(actions[d], -c.clip_actions), c.clip_actions);
+        float lo = c.joint[d].lower, hi = c.joint[d].upper;
+        target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;
+    }
+    pre_vx = st.ball.v.x;   // TT:1020
+    const float h = cfg.dt / (float)cfg.substeps;
+    JointSave js[ND];
+    ArmGeom<T::kShapes> g0, g1;
+    static_geometry<T>(cfg, g0);
+    static_geometry<T>(cfg, g1);
+    {
+        GeomVisitor<T> gv(cfg, g0);
+        fk_sweep<T>(cfg, st.q, st.qd, js, gv);
+    }
+    for (int s = 0; s < cfg.substeps; s++) {
+        arm_substep<T>(cfg, js, st.q, st.qd, target, h, st.dof_force);
+        if (s + 1 < cfg.substeps) {
+            GeomVisitor<T> gv(cfg, g1);
+            fk_sweep<T>(cfg, st.q, st.qd, js, gv);
+        } else {
+            BodyVisitor<T, false> bv(cfg, g1, bodies);
+            fk_sweep<T>(cfg, st.q, st.qd, js, bv);
+        }
+        ball_substep<T>(cfg, st.ball, g0, g1, h);
+        g0 = g1;
+    }
+    static_body<false>(cfg, bodies[0]);
+}
+
+// FK only (create / reset_all / refresh): observed-body states of the current dof state
+template <class T>
+PP_HD void bodies_of_state(const ppenv_config& cfg, const float* q, const float* qd, BodyState* bodies) {
+    JointSave js[ND];
+    ArmGeom<T::kShapes> g;
+    BodyVisitor<T, true> bv(cfg, g, bodies);
+    fk_sweep<T>(cfg, q, qd, js, bv);
+    static_body<true>(cfg, bodies[0]);
+}
+
+// initial simulation state of an env with the serve of `episode` (TT:853-867)
+PP_HD void reset_state(const ppenv_config& cfg, EnvState& st, V3 serve, bool reset_dofs) {
+    st.ball.p = ld3(cfg.ball_init_pos);
+#pragma unroll
+    for (int k = 0; k < 4; k++) st.ball.quat[k] = cfg.ball_init_quat[k];
+    st.ball.v = serve;
+    st.ball.w = mk(0, 0, 0);
+    if (reset_dofs) {
+#pragma unroll
+        for (int d = 0; d < ND; d++) { st.q[d] = cfg.init_dof_pos[d]; st.qd[d] = cfg.init_dof_vel[d]; }
+    }
+}
+
+// Observation row: TT:770-799 -> compute_humanoid_observations TT:1669-1708 +
+// compute_pingpong_observations TT:1640-1666.  `obs` is indexed obs[k * stride].
+template <class Store>
+PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float root_quat[4], const float* q, const float* qd,
+                     V3 ball_p, V3 ball_v, Store& store) {
+    float hinv[4];
+    heading_quat_inv(root_quat, hinv);
+    V3 root = body_pos[0];
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        V3 lp = quat_rotate(hinv, body_pos[j] - root);   // TT:1696
+        V3 lv = quat_rotate(hinv, body_vel[j]);          // TT:1697
+        store(3 * j, lp.x); store(3 * j + 1, lp.y); store(3 * j + 2, lp.z);
+        store(3 * NB + 3 * j, lv.x); store(3 * NB + 3 * j + 1, lv.y); store(3 * NB + 3 * j + 2, lv.z);
+    }
+#pragma unroll
+    for (int d = 0; d < ND; d++) {                       // TT:1702-1703
+        store(6 * NB + d, q[d]);
+        store(6 * NB + ND + d, qd[d] * 0.1f);
+    }
+    V3 lb = quat_rotate(hinv, ball_p - root);            // TT:1657-1659
+    V3 lbv = quat_rotate(hinv, ball_v);                  // TT:1660
+    store(6 * NB + 2 * ND, lb.x); store(6 * NB + 2 * ND + 1, lb.y); store(6 * NB + 2 * ND + 2, lb.z);
+    store(6 * NB + 2 * ND + 3, lbv.x); store(6 * NB + 2 * ND + 4, lbv.y); store(6 * NB + 2 * ND + 5, lbv.z);
+}
+
+// post_physics_step for one env of the fused path (TT:1022-1039): progress, reward,
+// masked reset, observations.  serve_override: used instead of the RNG when non-null.
+template <class Store>
+PP_HD void post_physics_env(const ppenv_config& cfg, uint32_t gid, EnvState& st, const BodyState* bodies, float pre_vx,
+                            const V3* serve_override, float& rew, long long& reset, Store& store) {
+    st.progress += 1;                                                            // TT:1023
+    RewardIn in;
+    in.humanoid_x = cfg.humanoid_root_pos[0];
+    in.paddle = bodies[NB - 1].pos;
+    in.pre_vx = pre_vx;
+    in.bp = st.ball.p;
+    in.vx = st.ball.v.x;
+    float power = 0.f;
+#pragma unroll
+    for (int d = 0; d < ND; d++) power += fabsf(st.dof_force[d] * st.qd[d]);     // TT:1246
+    in.power = power;
+    in.progress = st.progress;
+    rew = compute_reward(cfg, in, st.flags, reset);
+    if (reset) {                                                                 // TT:1034-1036 -> 847-906
+        st.episode += 1;
+        V3 serve = serve_override ? *serve_override : serve_velocity(cfg, gid, st.episode);
+        reset_state(cfg, st, serve, cfg.variant != PPENV_VARIANT_TN);            // TN:888-901 keeps the dof state
+        st.progress = 0;                                                         // TT:902
+        st.flags = PPENV_FLAG_NO_BOUNCE;                                         // TT:903-905
+    }
+    // TT:1039: dof / ball already show the reset state, body states are the pre-reset ones
+    V3 bpos[NB], bvel[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
+    write_obs(bpos, bvel, cfg.humanoid_root_quat, st.q, st.qd, st.ball.p, st.ball.v, store);
+}
+
+}  // namespace pp
+
+// ------------------------------------------------------- instantiated topologies
+namespace pp {
+// Unitree G1 right arm: shoulder pitch(y) roll(x) yaw(z), elbow(y), wrist roll(x) pitch(y) yaw(z)
+// (TT:427-431); shapes: hand on link 6, forearm on 3, upper arm on 1, then three static ones.
+constexpr uint32_t kAxesG1 = 1u | (0u << 2) | (2u << 4) | (1u << 6) | (0u << 8) | (1u << 10) | (2u << 12);
+constexpr uint32_t kShapeLinksG1 = 7u | (4u << 4) | (2u << 8) | (0u << 12) | (0u << 16) | (0u << 20);
+using TopoG1 = Topo<kAxesG1, kShapeLinksG1, 6>;
+
+// does a config have the topology `T` was compiled for?
+template <class T>
+inline bool topo_matches(const ppenv_config& c) {
+    if (c.num_shapes != T::kShapes || c.paddle_link != ND - 1 || c.paddle_obs_index != NB - 1) return false;
+    for (int i = 0; i < ND; i++)
+        if (c.joint[i].axis != T::axis(i)) return false;
+    for (int s = 0; s < T::kShapes; s++)
+        if (c.shape[s].link != T::shape_link(s)) return false;
+    if (c.obs_body[0].link != -1) return false;
+    for (int j = 1; j <= ND; j++) {
+        const ppenv_frame& f = c.obs_body[j];
+        if (f.link != j - 1 || f.xyz[0] != 0.f || f.xyz[1] != 0.f || f.xyz[2] != 0.f) return false;
+        for (int k = 0; k < 9; k++)
+            if (f.rot[k] != ((k % 4 == 0) ? 1.f : 0.f)) return false;
+    }
+    for (int j = ND + 1; j < NB; j++)
+        if (c.obs_body[j].link != ND - 1) return false;
+    return true;
+}
+}  // namespace pp

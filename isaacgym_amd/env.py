@@ -1,0 +1,125 @@
+"""Low-level handle on the native environment: one `ppenv` per GPU, buffers wrapped as torch tensors.
+
+The analogue of the reference's `gymtorch.wrap_tensor(acquire_*_tensor(sim))` block
+(tasks/humanoid_pingpong_3_actor_tilt.py:131-134,153-208): the simulator owns nothing the
+Python side copies — every tensor below aliases the device arena the library steps in place.
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, scene
+
+
+class PPEnv:
+    def __init__(self, config, device=None):
+        self.config = config
+        self.L = _lib.lib()   # raises when the HIP extension is missing: no fallback
+        if not torch.cuda.is_available():
+            raise _lib.PPEnvError("no ROCm GPU visible to PyTorch; the native environment runs on an MI355X only")
+        self.device = torch.device(device if device is not None else f"cuda:{config.device_id}")
+        if self.device.type != "cuda":
+            raise _lib.PPEnvError(f"sim device must be a GPU, got {self.device}")
+        config.device_id = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        n = self.num_envs = config.num_envs
+        nbytes = self.L.ppenv_arena_bytes(C.byref(config))
+        # torch owns the arena (256-byte aligned by the caching allocator); the library steps it in place
+        self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.ppenv_create(C.byref(config), self.arena.data_ptr(), nbytes, self._stream(), C.byref(self.h)))
+        b = scene.Buffers()
+        _lib.check(self.L.ppenv_buffers_of(self.h, C.byref(b)))
+        base = self.arena.data_ptr()
+
+        def view(ptr, count, dtype, shape):
+            off = ptr - base
+            itemsize = torch.empty((), dtype=dtype).element_size()
+            return self.arena[off: off + count * itemsize].view(dtype).view(*shape)
+
+        nd = scene.NUM_DOF
+        self.obs_buf = view(b.obs_buf, n * scene.NUM_OBS, torch.float32, (n, scene.NUM_OBS))
+        self.rew_buf = view(b.rew_buf, n, torch.float32, (n,))
+        self.reset_buf = view(b.reset_buf, n, torch.int64, (n,))
+        self.progress_buf = view(b.progress_buf, n, torch.int64, (n,))
+        self.dof_pos = view(b.dof_pos, nd * n, torch.float32, (nd, n))       # SoA [7][N]
+        self.dof_vel = view(b.dof_vel, nd * n, torch.float32, (nd, n))
+        self.dof_force = view(b.dof_force, nd * n, torch.float32, (nd, n))
+        self.ball = view(b.ball, 13 * n, torch.float32, (13, n))             # SoA [13][N]
+        self.flags = view(b.flags, n, torch.int32, (n,))
+        self.episode = view(b.episode, n, torch.int32, (n,))
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            torch.cuda.synchronize(self.device)
+            self.L.ppenv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- hot path
+    def step(self, actions):
+        """actions: float32 [N, 7] on this device, contiguous.  One fused kernel launch, no sync."""
+        if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous() \
+                or tuple(actions.shape) != (self.num_envs, scene.NUM_DOF):
+            actions = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, scene.NUM_DOF).contiguous()
+        _lib.check(self.L.ppenv_step(self.h, actions.data_ptr(), self._stream()))
+
+    def reset_all(self):
+        _lib.check(self.L.ppenv_reset_all(self.h, self._stream()))
+
+    # ---- Isaac-Gym tensor-API mode
+    def post_physics_step(self, rigid_body_states, root_states, dof_states, dof_force, pre_ball_vx):
+        for t in (rigid_body_states, root_states, dof_states, dof_force, pre_ball_vx):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
+        n = self.num_envs
+        assert rigid_body_states.numel() == n * scene.NUM_BODIES * 13 and root_states.numel() == n * scene.NUM_ACTORS * 13
+        assert dof_states.numel() == n * scene.NUM_DOF * 2 and dof_force.numel() == n * scene.NUM_DOF and pre_ball_vx.numel() == n
+        _lib.check(self.L.ppenv_post_physics_step(self.h, rigid_body_states.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(),
+                                                  dof_force.data_ptr(), pre_ball_vx.data_ptr(), self._stream()))
+
+    def _refresh(self, fn, shape):
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        _lib.check(fn(self.h, out.data_ptr(), self._stream()))
+        return out
+
+    def refresh_root_states(self):
+        return self._refresh(self.L.ppenv_refresh_root_states, (self.num_envs, scene.NUM_ACTORS, 13))
+
+    def refresh_dof_states(self):
+        return self._refresh(self.L.ppenv_refresh_dof_states, (self.num_envs, scene.NUM_DOF, 2))
+
+    def refresh_dof_force(self):
+        return self._refresh(self.L.ppenv_refresh_dof_force, (self.num_envs, scene.NUM_DOF))
+
+    def refresh_rigid_body_states(self):
+        return self._refresh(self.L.ppenv_refresh_rigid_body_states, (self.num_envs, scene.NUM_BODIES, 13))
+
+    # ---- state I/O
+    def set_serve_override(self, serve, on=True):
+        """serve: [N,3] tensor/array of serve velocities used at the next resets instead of the RNG."""
+        if serve is None or not on:
+            _lib.check(self.L.ppenv_set_serve_override(self.h, None, int(bool(on)), self._stream()))
+            return
+        s = torch.as_tensor(serve, dtype=torch.float32).to(self.device).reshape(self.num_envs, 3).contiguous()
+        _lib.check(self.L.ppenv_set_serve_override(self.h, s.data_ptr(), 1, self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()   # `s` must outlive the transpose kernel
+
+    def get_state(self):
+        n = self.L.ppenv_state_bytes(self.h)
+        buf = np.empty(n, np.uint8)
+        _lib.check(self.L.ppenv_get_state(self.h, buf.ctypes.data, n))
+        return buf
+
+    def set_state(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        _lib.check(self.L.ppenv_set_state(self.h, blob.ctypes.data, blob.size))

@@ -1,0 +1,245 @@
+"""The VecTask buffer surface the reference's training stack drives, over the native environment.
+
+Mirrors the interface of `isaacgymenvs.tasks.base.vec_task.VecTask` as the reference task classes
+use it (tasks/humanoid_pingpong_3_actor_tilt.py:60,118-123,1023-1037 — the base class itself is not
+part of the reference): constructor signature, `num_envs / num_obs / num_actions / device`,
+`obs_buf, rew_buf, reset_buf, progress_buf, randomize_buf, reset_buf_force, extras`,
+`step(actions) -> (obs_dict, rew, reset, extras)` and `reset() -> obs_dict`, so that
+`RLGPUEnv` / rl_games (reference train.py:147-167) can drive it unchanged.
+
+Where the reference runs pre_physics_step -> gym.simulate -> post_physics_step as ~900 separate
+torch dispatches plus PhysX, this class issues ONE kernel launch per step through the C ABI
+(include/ppenv.h).  No host synchronisation happens inside step().
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import scene
+from .env import PPEnv
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency here); rl_games reads .shape/.low/.high."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.shape = tuple(shape) if shape is not None else np.shape(low)
+        self.low = np.full(self.shape, low, dtype=dtype) if np.isscalar(low) else np.asarray(low, dtype=dtype)
+        self.high = np.full(self.shape, high, dtype=dtype) if np.isscalar(high) else np.asarray(high, dtype=dtype)
+        self.dtype = np.dtype(dtype)
+
+    def __repr__(self):
+        return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})"
+
+
+def _parse_device(sim_device):
+    s = str(sim_device)
+    if s.startswith("cpu"):
+        raise ValueError("sim_device='cpu' is not supported: the native environment has no CPU pipeline "
+                         "(the CPU restatement under oracle/ is test infrastructure, not a backend)")
+    if ":" in s:
+        return torch.device("cuda", int(s.split(":")[1]))
+    return torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+
+
+class VecTask:
+    VARIANT = None   # 'T3' | 'TT' | 'TN', set by subclasses
+
+    def __init__(self, config, rl_device, sim_device, graphics_device_id=-1, headless=True, virtual_screen_capture=False,
+                 force_render=False):
+        self.cfg = config
+        env_cfg = config["env"]
+        self.device = _parse_device(sim_device)
+        self.device_id = self.device.index
+        self.rl_device = torch.device(rl_device) if rl_device is not None else self.device
+        self.graphics_device_id = graphics_device_id
+        self.headless = True          # no viewer: rendering is out of scope
+        self.viewer = None
+        self.enable_viewer_sync = False
+        self.force_render = force_render
+        self.physics_engine = "ppenv"
+
+        self.num_envs = int(env_cfg["numEnvs"])
+        self.num_agents = 1
+        self.num_observations = self.num_obs = int(env_cfg["numObservations"])
+        self.num_states = int(env_cfg.get("numStates", 0))
+        self.num_actions = self.num_acts = int(env_cfg["numActions"])
+        self.control_freq_inv = int(env_cfg.get("controlFrequencyInv", 1))
+        self.clip_obs = float(env_cfg.get("clipObservations", np.inf))
+        self.clip_actions = float(env_cfg.get("clipActions", np.inf))
+        self.obs_space = self.observation_space = Box(-np.inf, np.inf, (self.num_obs,))
+        self.state_space = Box(-np.inf, np.inf, (self.num_states,))
+        self.act_space = self.action_space = Box(-1.0, 1.0, (self.num_actions,))
+        self.extras = {}
+        self.obs_dict = {}
+        self.control_steps = 0
+        self.randomize = bool(config.get("task", {}).get("randomize", False))
+        if self.randomize:
+            raise NotImplementedError("domain randomisation is disabled in every reference config "
+                                      "(cfg/task/HumanoidPingpongTiltG1.yaml:101) and not implemented")
+
+        self.sim = self.create_sim()       # the reference's VecTask.__init__ calls back create_sim (TT:325)
+        self.allocate_buffers()
+
+    # -- hooks the task class fills in
+    def create_sim(self):
+        raise NotImplementedError
+
+    def allocate_buffers(self):
+        """obs/rew/reset/progress alias the native arena; the rest are plain torch buffers (VecTask.allocate_buffers)."""
+        e = self.env
+        self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf = e.obs_buf, e.rew_buf, e.reset_buf, e.progress_buf
+        self.states_buf = torch.zeros((self.num_envs, self.num_states), device=self.device, dtype=torch.float)
+        self.timeout_buf = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
+        self.randomize_buf = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
+        self.reset_buf_force = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)   # TT:1037
+
+    # -- the surface rl_games drives
+    def step(self, actions):
+        """One control step: K1..K8 in a single kernel launch (TT:1002-1052)."""
+        for _ in range(self.control_freq_inv):
+            self.env.step(actions)          # action clamp (clipActions) happens inside the kernel
+        self.control_steps += 1
+        # upstream: timeout_buf = (progress_buf >= max_episode_length - 1) & (reset_buf != 0), evaluated after
+        # post_physics_step.  These tasks zero progress_buf inside post_physics_step on every reset (TT:902), so
+        # upstream's time_outs is identically False for them; keep the (constant) tensor instead of two launches.
+        self.extras["time_outs"] = self.timeout_buf if self.rl_device == self.device else self.timeout_buf.to(self.rl_device)
+        return self._obs_dict(), self._to_rl(self.rew_buf), self._to_rl(self.reset_buf), self.extras
+
+    def reset(self):
+        """Observation dictionary of the current state (upstream VecTask.reset does not step the simulator)."""
+        return self._obs_dict()
+
+    def reset_idx(self, env_ids=None):
+        """Full reset of every env (the per-env masked reset lives inside the step kernel, TT:847-906)."""
+        self.env.reset_all()
+
+    def reset_done(self):
+        return self._obs_dict(), torch.nonzero(self.reset_buf, as_tuple=False).flatten()
+
+    def zero_actions(self):
+        return torch.zeros((self.num_envs, self.num_actions), dtype=torch.float32, device=self.rl_device)
+
+    def get_number_of_agents(self):
+        return self.num_agents
+
+    def get_env_info(self):
+        return {"action_space": self.action_space, "observation_space": self.observation_space, "state_space": self.state_space,
+                "agents": self.num_agents}
+
+    def _to_rl(self, t):
+        return t if self.rl_device == self.device else t.to(self.rl_device)
+
+    def _obs_dict(self):
+        obs = self.obs_buf if not np.isfinite(self.clip_obs) else torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs)
+        self.obs_dict["obs"] = self._to_rl(obs)
+        if self.num_states > 0:
+            self.obs_dict["states"] = self._to_rl(self.states_buf)
+        return self.obs_dict
+
+
+class _HumanoidPingpongBase(VecTask):
+    """Shared body of the three 7-DoF task classes; cfg keys are the reference yamls' (cfg/task/*.yaml)."""
+
+    def __init__(self, cfg, rl_device, sim_device, graphics_device_id=-1, headless=True, virtual_screen_capture=False,
+                 force_render=False):
+        cfg = copy.deepcopy(cfg) if cfg is not None else scene.default_task_cfg(self.VARIANT)
+        defaults = scene.default_task_cfg(self.VARIANT)
+        cfg.setdefault("sim", defaults["sim"])
+        cfg.setdefault("scene", defaults["scene"])
+        for k, v in defaults["env"].items():
+            if k not in cfg["env"] and k in ("bodyStatesId", "plane", "clipActions"):
+                cfg["env"][k] = v
+        env = cfg["env"]
+        self.max_episode_length = env["episodeLength"]            # TT:84
+        env["numObservations"] = scene.NUM_OBS                    # TT:98  30+30+7+7+3+3
+        env["numActions"] = scene.NUM_DOF                         # TT:101
+        # the reference reads these unconditionally (TT:103-107); a missing key is the same KeyError
+        self.alpha = env["alphaVelocityReward"]
+        self.power_coefficient = env["powerCoefficient"]
+        self.penalty = env["penalty"]
+        if self.VARIANT != "T3":
+            self.hit_table_reward = env["hitTableReward"]
+            self.not_hit_table_penalty = env["nothitTablePenalty"]
+        else:
+            env.setdefault("hitTableReward", 0.0)
+            env.setdefault("nothitTablePenalty", 0.0)
+        self.initial_speed_range = tuple(cfg["scene"]["serve_speed"])
+        self.tilt_angle_range = tuple(cfg["scene"]["serve_tilt"])
+        self.tilt_z_angle_range = tuple(cfg["scene"]["serve_tilt_z"])
+        self.actors_per_env, self.dofs_per_env, self.rigid_bodies_per_env = scene.NUM_ACTORS, scene.NUM_DOF, scene.NUM_BODIES
+        self.num_humanoid_bodies = 40
+        self._seed = int(cfg.get("seed", 0))
+        self._env_id_offset = int(cfg.get("env_id_offset", 0))
+        self.dt = cfg["sim"]["dt"]
+        super().__init__(config=cfg, rl_device=rl_device, sim_device=sim_device, graphics_device_id=graphics_device_id,
+                         headless=headless, virtual_screen_capture=virtual_screen_capture, force_render=force_render)
+        off, scale = scene.pd_action_offset_scale(self.native_config)
+        self._pd_action_offset = torch.tensor(off, device=self.device)   # TT:664-668
+        self._pd_action_scale = torch.tensor(scale, device=self.device)
+        self.body_states_id = torch.tensor(env["bodyStatesId"], dtype=torch.long, device=self.device)
+        self.num_steps = 0
+
+    def create_sim(self):
+        """TT:325-344: build the scene.  Here: scene constants -> ppenv_config -> native handle."""
+        self.up_axis_idx = 2
+        self.native_config = scene.build_config(self.VARIANT, cfg=self.cfg, num_envs=self.num_envs, seed=self._seed,
+                                                device_id=self.device_id, env_id_offset=self._env_id_offset)
+        self.env = PPEnv(self.native_config, device=self.device)
+        return self.env
+
+    # gym.refresh_* equivalents (TT:801-807) in the reference's tensor layouts, materialised on demand
+    def refresh_sim_tensors(self):
+        self.root_states = self.env.refresh_root_states()
+        self.vec_root_states = self.root_states
+        self.humanoid1_root_states = self.root_states[:, 0, :]
+        self.table_root_states = self.root_states[:, 1, :]
+        self.ball2_root_states = self.root_states[:, 2, :]
+        self.vec_dof_states = self.env.refresh_dof_states()
+        self.dof_pos, self.dof_vel = self.vec_dof_states[..., 0], self.vec_dof_states[..., 1]
+        self.body_states = self.vec_rb_states = self.env.refresh_rigid_body_states()
+        self.humanoid1_paddle_rb_states = self.body_states[:, 39, :]
+        self.dof_force_tensor = self.env.refresh_dof_force()
+
+    def step(self, actions):
+        out = super().step(actions)
+        self.num_steps += 1
+        return out
+
+    # sticky flags as the reference's bool tensors (TT:241-243, TN:244-248), decoded on demand
+    def _flag(self, bit):
+        return (self.env.flags & bit) != 0
+
+    @property
+    def reward_calculated(self):
+        return self._flag(scene.FLAG_REWARD_CALC)
+
+    @property
+    def condition_calculated(self):
+        return self._flag(scene.FLAG_COND_CALC)
+
+    paddle_condition_calculated = condition_calculated
+
+    @property
+    def no_bounce_before_half_mask(self):
+        return self._flag(scene.FLAG_NO_BOUNCE)
+
+    @property
+    def missed_ball_calculated(self):
+        return self._flag(scene.FLAG_MISSED_CALC)
+
+
+class HumanoidPingpong(_HumanoidPingpongBase):
+    """HumanoidPingpongG1 — tasks/humanoid_interos_edit_pingpong_only_3_actor.py (T3)."""
+    VARIANT = "T3"
+
+
+class HumanoidPingpongTilt(_HumanoidPingpongBase):
+    """HumanoidPingpongTiltG1 — tasks/humanoid_pingpong_3_actor_tilt.py:58 (TT)."""
+    VARIANT = "TT"
+
+
+class HumanoidPingpongTiltNoEarlyStop(_HumanoidPingpongBase):
+    """HumanoidPingpongTiltNoEarlyStopG1 — tasks/humanoid_pingpong_3_actor_tilt_no_earlystop.py (TN)."""
+    VARIANT = "TN"

@@ -43,3 +43,48 @@ def assert_close(actual, expected, what, rtol=RTOL, atol=ATOL):
         idx = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(f"{what}: {int(bad.sum())}/{bad.size} beyond rtol={rtol} atol={atol}; worst at {idx}: "
                              f"got {actual[idx]!r} want {expected[idx]!r}")
+
+
+# Characteristic magnitude of each state tensor.  The fp32 parity bar is rtol 1e-4; for values that
+# are the small difference of large ones (a joint velocity swinging from the 37 rad/s limit to ~0 in
+# one step, a ball leaving a paddle that moves at 15 m/s) the absolute error is bounded by
+# 1e-4 x the tensor's range, which is what `atol = RTOL * scale` expresses.
+SCALES = {
+    "dof_pos": 3.1416,    # rad, joint limits
+    "dof_vel": 37.0,      # rad/s, velocity limit
+    "dof_force": 25.0,    # N m, effort limit
+    "ball_pos": 3.0,      # m
+    "ball_quat": 1.0,
+    "ball_vel": 10.0,     # m/s
+    "ball_spin": 100.0,   # rad/s
+}
+BALL_ROWS = {"ball_pos": slice(0, 3), "ball_quat": slice(3, 7), "ball_vel": slice(7, 10), "ball_spin": slice(10, 13)}
+
+
+def assert_state_close(got, want, what):
+    """got / want: objects with SoA arrays dof_pos, dof_vel, dof_force [7,N], ball [13,N]."""
+    for name in ("dof_pos", "dof_vel", "dof_force"):
+        assert_close(getattr(got, name), getattr(want, name), f"{what}: {name}", atol=RTOL * SCALES[name])
+    for name, rows in BALL_ROWS.items():
+        a, b = got.ball[rows], want.ball[rows]
+        if name == "ball_quat":   # q and -q are the same rotation
+            sign = np.sign(np.sum(a * b, axis=0, keepdims=True))
+            a = a * np.where(sign == 0, 1, sign)
+        assert_close(a, b, f"{what}: {name}", atol=RTOL * SCALES[name])
+
+
+def obs_atol():
+    """Per-column atol of an obs row: body pos (30), body vel (30), dof_pos (7), 0.1*dof_vel (7), ball pos (3), ball vel (3)."""
+    a = np.empty(scene.NUM_OBS, np.float64)
+    a[0:30] = RTOL * 1.0        # arm reach ~1 m
+    a[30:60] = RTOL * 20.0      # link velocities up to ~20 m/s when the arm flails at the velocity limits
+    a[60:67] = RTOL * SCALES["dof_pos"]
+    a[67:74] = RTOL * SCALES["dof_vel"] * 0.1
+    a[74:77] = RTOL * SCALES["ball_pos"]
+    a[77:80] = RTOL * SCALES["ball_vel"]
+    return a
+
+
+def reward_atol(config):
+    """Reward scale: alpha * |vx| dominates (TT:1159); the power term is c * sum|tau qd| <= c * 7 * 25 * 37."""
+    return RTOL * max(1.0, abs(config.alpha_velocity_reward) * SCALES["ball_vel"], abs(config.power_coefficient) * 6475.0)

@@ -1,0 +1,78 @@
+"""ctypes binding of tests/csrc/libppenv_hostshim.so — the HIP kernels' per-env arithmetic compiled for the host.
+TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from isaacgym_amd import scene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "csrc", "host_shim.cpp")
+_HDR = os.path.join(_HERE, "..", "isaacgym_amd", "csrc", "ppenv_device.h")
+_LIB = os.path.join(_HERE, "csrc", "libppenv_hostshim.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < max(os.path.getmtime(_SRC), os.path.getmtime(_HDR)):
+            subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=fast", "-Wno-unknown-pragmas",
+                            "-o", _LIB, _SRC], check=True, capture_output=True)
+        _lib = C.CDLL(_LIB)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class ShimEnv:
+    """Same SoA state layout as the oracle / the HIP handle; stepped by the kernel arithmetic on the CPU."""
+
+    def __init__(self, config):
+        self.L = lib()
+        self.config = config
+        assert self.L.shim_topo_matches(C.byref(config)) == 1
+        n = self.num_envs = config.num_envs
+        self.obs_buf = np.zeros((n, scene.NUM_OBS), np.float32)
+        self.rew_buf = np.zeros(n, np.float32)
+        self.reset_buf = np.zeros(n, np.int64)
+        self.progress_buf = np.zeros(n, np.int64)
+        self.dof_pos = np.zeros((scene.NUM_DOF, n), np.float32)
+        self.dof_vel = np.zeros((scene.NUM_DOF, n), np.float32)
+        self.dof_force = np.zeros((scene.NUM_DOF, n), np.float32)
+        self.ball = np.zeros((13, n), np.float32)
+        self.flags = np.zeros(n, np.uint32)
+        self.episode = np.zeros(n, np.uint32)
+        self.serve = None
+        self.bodies = np.zeros((n, scene.NUM_OBS_BODIES, 13), np.float32)
+
+    def copy_state_from(self, other):
+        for name in ("dof_pos", "dof_vel", "dof_force", "ball", "flags", "episode", "progress_buf", "reset_buf"):
+            getattr(self, name)[...] = getattr(other, name)
+
+    def set_serve_override(self, serve, on=True):
+        self.serve = np.ascontiguousarray(np.asarray(serve, np.float32).T) if (on and serve is not None) else None
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, np.float32)
+        self.L.shim_step(C.byref(self.config), _p(a), _p(self.dof_pos), _p(self.dof_vel), _p(self.dof_force), _p(self.ball),
+                         _p(self.progress_buf), _p(self.flags), _p(self.episode),
+                         _p(self.serve) if self.serve is not None else None,
+                         _p(self.obs_buf), _p(self.rew_buf), _p(self.reset_buf), _p(self.bodies))
+
+
+def arm_qdd(config, q, qd, tau, arm_eff):
+    q, qd, tau, arm_eff = (np.ascontiguousarray(x, np.float32) for x in (q, qd, tau, arm_eff))
+    out = np.zeros(scene.NUM_DOF, np.float32)
+    lib().shim_arm_qdd(C.byref(config), _p(q), _p(qd), _p(tau), _p(arm_eff), _p(out))
+    return out
+
+
+def serve_velocity(config, gid, episode):
+    out = np.zeros(3, np.float32)
+    lib().shim_serve_velocity(C.byref(config), C.c_uint32(gid), C.c_uint32(episode), _p(out))
+    return out
