@@ -56,7 +56,7 @@ SCALES = {
     "ball_pos": 3.0,      # m
     "ball_quat": 1.0,
     "ball_vel": 10.0,     # m/s
-    "ball_spin": 100.0,   # rad/s
+    "ball_spin": 500.0,   # rad/s: surface speed / radius = 10 m/s / 0.02 m, i.e. the same bound as ball_vel
 }
 BALL_ROWS = {"ball_pos": slice(0, 3), "ball_quat": slice(3, 7), "ball_vel": slice(7, 10), "ball_spin": slice(10, 13)}
 

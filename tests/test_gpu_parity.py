@@ -69,7 +69,7 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant)
     env = make_env(scene.build_config(variant, num_envs=n, seed=7))
     rng = np.random.default_rng(1)
     oa, ra = obs_atol(), reward_atol(cfg)
-    steps = 180 if variant == "TN" else 100
+    steps = 180 if variant == "TN" else 120
     resets = 0
     for t in range(steps):
         actions = rng.uniform(-1.2, 1.2, (n, 7)).astype(np.float32)
@@ -85,7 +85,7 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant)
         assert_close(v.obs_buf, o.obs_buf, f"obs step {t}", atol=oa)
         assert_close(v.rew_buf, o.rew_buf, f"rew step {t}", atol=ra)
         resets += int(o.reset_buf.sum())
-    assert resets > 100
+    assert resets > 50   # the masked-reset path was exercised
     env.close()
 
 
