@@ -45,20 +45,42 @@ PP_HD void sincos_joint(float q, float& s, float& c) {
 #endif
 }
 
-// Model constants live in a ppenv_config in device memory and are wave-uniform, so they are
-// read with scalar loads.  Every per-joint / per-contact block below re-derives its config
-// reference through launder(): an empty asm the optimiser cannot see through, which stops
-// loop-invariant code motion from hoisting ~600 constants out of the substep loops and
-// holding them live (that spilled >1000 SGPRs); loads stay next to their use instead.
-PP_HD const ppenv_config& launder(const ppenv_config& c) {
+// Model constants live in a ppenv_config in device memory and are wave-uniform.  They are read
+// through the constant address space so the compiler emits scalar loads (s_load -> SGPRs) instead
+// of 64-lane vector loads:
+//   ldc(field): copy of a sub-struct (a joint, a shape ...) whose address goes through an empty asm
+//               first.  The asm stops loop-invariant code motion from hoisting the ~600 constants of
+//               the arm model out of the substep loop and holding them live (that spilled >1000
+//               SGPRs); each block of constants is fetched right where it is used instead.
+//   ldu(field): plain scalar read the optimiser may hoist and CSE (the few dozen hot scalars).
 #if defined(__HIP_DEVICE_COMPILE__)
-    const ppenv_config* p = &c;
+#define PP_CONST_AS __attribute__((address_space(4)))
+template <class S>
+PP_HD S ldc(const S& f) {
+    const S* p = &f;
     asm volatile("" : "+s"(p));
-    return *p;
-#else
-    return c;
-#endif
+    S out;
+    __builtin_memcpy(&out, (const PP_CONST_AS S*)p, sizeof(S));
+    return out;
 }
+template <class S>
+PP_HD S ldu(const S& f) {
+    S out;
+    __builtin_memcpy(&out, (const PP_CONST_AS S*)&f, sizeof(S));
+    return out;
+}
+// 1-ulp hardware reciprocal / reciprocal square root for the physics (reward and observations keep
+// IEEE division and sqrt so that thresholds and roundings follow the reference's torch arithmetic)
+PP_HD float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+PP_HD float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+template <class S>
+PP_HD S ldc(const S& f) { return f; }
+template <class S>
+PP_HD S ldu(const S& f) { return f; }
+PP_HD float rcp_fast(float x) { return 1.0f / x; }
+PP_HD float rsq_fast(float x) { return 1.0f / sqrtf(x); }
+#endif
 
 // ------------------------------------------------------------------ small math
 struct V3 { float x, y, z; };
@@ -231,12 +253,12 @@ struct BodyState { V3 pos; M3 rot; V3 lin, ang; };
 // link's world transform to `vis(i, Rw, pw, w_link, v_link)`.
 template <class T, class Visitor>
 PP_HD void fk_sweep(const ppenv_config& cfg, const float* q, const float* qd, JointSave* js, Visitor& vis) {
-    M3 Rp = ldm(cfg.base_rot);
-    V3 pp = ld3(cfg.base_pos);
+    M3 Rp = ldu(*reinterpret_cast<const M3*>(cfg.base_rot));
+    V3 pp = ldu(*reinterpret_cast<const V3*>(cfg.base_pos));
     V3 wp = mk(0, 0, 0), vp = mk(0, 0, 0);
 #pragma unroll
     for (int i = 0; i < ND; i++) {
-        const ppenv_joint& J = launder(cfg).joint[i];
+        const ppenv_joint J = ldc(cfg.joint[i]);
         float s, c;
         sincos_joint(q[i], s, c);
         M3 E = T::axis(i) == 0 ? joint_rot<0>(J.origin_rot, c, s) : (T::axis(i) == 1 ? joint_rot<1>(J.origin_rot, c, s) : joint_rot<2>(J.origin_rot, c, s));
@@ -260,14 +282,13 @@ struct GeomVisitor {
     PP_HD GeomVisitor(const ppenv_config& c, ArmGeom<T::kShapes>& gg) : cfg(c), g(gg) {}
     PP_HD void operator()(int i, const M3& Rw, V3 pw, V3, V3) {
         if (i == ND - 1) {   // paddle_link is validated to be the last link at create time
-            const ppenv_config& c = launder(cfg);
-            g.pc = pw + mul(Rw, ld3(c.paddle_center));
-            g.pn = mul(Rw, ld3(c.paddle_normal));
+            g.pc = pw + mul(Rw, ldc(*reinterpret_cast<const V3*>(cfg.paddle_center)));
+            g.pn = mul(Rw, ldc(*reinterpret_cast<const V3*>(cfg.paddle_normal)));
         }
 #pragma unroll
         for (int s = 0; s < T::kShapes; s++)
             if (T::shape_link(s) == i) {
-                const ppenv_shape& sh = launder(cfg).shape[s];
+                const ppenv_shape sh = ldc(cfg.shape[s]);
                 g.a[s] = pw + mul(Rw, ld3(sh.a));
                 g.b[s] = pw + mul(Rw, ld3(sh.b));
             }
@@ -277,7 +298,7 @@ template <class T>
 PP_HD void static_geometry(const ppenv_config& cfg, ArmGeom<T::kShapes>& g) {
 #pragma unroll
     for (int s = 0; s < T::kShapes; s++)
-        if (T::shape_link(s) < 0) { g.a[s] = ld3(cfg.shape[s].a); g.b[s] = ld3(cfg.shape[s].b); }
+        if (T::shape_link(s) < 0) { const ppenv_shape sh = ldc(cfg.shape[s]); g.a[s] = ld3(sh.a); g.b[s] = ld3(sh.b); }
 }
 
 // geometry + the observed bodies (obs_body[1..7] are the chain links, [8],[9] ride on the last link).
@@ -299,7 +320,7 @@ struct BodyVisitor {
         if (i == ND - 1) {
 #pragma unroll
             for (int j = 8; j < NB; j++) {
-                const ppenv_frame& f = launder(cfg).obs_body[j];
+                const ppenv_frame f = ldc(cfg.obs_body[j]);
                 V3 off = mul(Rw, ld3(f.xyz));
                 bodies[j].pos = pw + off;
                 bodies[j].lin = vw + cross(ww, off);
@@ -310,8 +331,9 @@ struct BodyVisitor {
 };
 template <bool FULL>
 PP_HD void static_body(const ppenv_config& cfg, BodyState& b) {   // obs_body[0]: the pelvis, fixed at the root pose
-    b.pos = ld3(cfg.obs_body[0].xyz); b.lin = mk(0, 0, 0);
-    if (FULL) { b.rot = ldm(cfg.obs_body[0].rot); b.ang = mk(0, 0, 0); }
+    const ppenv_frame f = ldc(cfg.obs_body[0]);
+    b.pos = ld3(f.xyz); b.lin = mk(0, 0, 0);
+    if (FULL) { b.rot = ldm(f.rot); b.ang = mk(0, 0, 0); }
 }
 
 // --------------------------------------------------- ABA passes 2 and 3 (RBDA 7.1)
@@ -325,7 +347,7 @@ PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, co
     V3 cn = mk(0, 0, 0), cf = mk(0, 0, 0);
 #pragma unroll
     for (int i = ND - 1; i >= 0; i--) {
-        const ppenv_joint& J = launder(cfg).joint[i];
+        const ppenv_joint J = ldc(cfg.joint[i]);
         const int ax = T::axis(i);
         V3 w = js[i].w, v = js[i].v;
         // rigid-body inertia about the link origin: [[Io, m c x],[m c x^T, m 1]]
@@ -344,7 +366,7 @@ PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, co
         S3 D = {cD.xx + m, cD.yy + m, cD.zz + m, cD.xy, cD.xz, cD.yz};
 
         V3 ua = symcol(A, ax), ub = row(B, ax);
-        float dinv = 1.0f / (symdiag(A, ax) + arm_eff[i]);
+        float dinv = rcp_fast(symdiag(A, ax) + arm_eff[i]);
         float u = tau[i] - comp(pn, ax);
         js[i].ua = ua; js[i].ub = ub; js[i].dinv = dinv; js[i].u = u;
         if (i > 0) {
@@ -386,11 +408,10 @@ PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, co
     }
     // pass 3: accelerations base -> tip; the base "accelerates" upward by |g|
     V3 aw = mk(0, 0, 0);
-    const ppenv_config& cb = launder(cfg);
-    V3 av = tmul(ldm(cb.base_rot), mk(0, 0, -cb.gravity_z));
+    V3 av = tmul(ldc(*reinterpret_cast<const M3*>(cfg.base_rot)), mk(0, 0, -ldu(cfg.gravity_z)));
 #pragma unroll
     for (int i = 0; i < ND; i++) {
-        const ppenv_joint& J = launder(cfg).joint[i];
+        const ppenv_joint J = ldc(cfg.joint[i]);
         const int ax = T::axis(i);
         M3 E = ax == 0 ? joint_rot<0>(J.origin_rot, js[i].c, js[i].s) : (ax == 1 ? joint_rot<1>(J.origin_rot, js[i].c, js[i].s) : joint_rot<2>(J.origin_rot, js[i].c, js[i].s));
         V3 r = ld3(J.origin_xyz);
@@ -414,7 +435,7 @@ PP_HD void arm_substep(const ppenv_config& cfg, JointSave* js, float* q, float* 
     bool sat[ND];
 #pragma unroll
     for (int d = 0; d < ND; d++) {
-        const ppenv_joint& J = launder(cfg).joint[d];
+        const ppenv_joint J = ldc(cfg.joint[d]);
         float err = target[d] - q[d];
         float t_exp = J.kp * err - J.kd * qd[d];
         sat[d] = fabsf(t_exp) > J.effort;
@@ -425,7 +446,7 @@ PP_HD void arm_substep(const ppenv_config& cfg, JointSave* js, float* q, float* 
     aba_solve<T>(cfg, js, qd, tau, arm, qdd);
 #pragma unroll
     for (int d = 0; d < ND; d++) {
-        const ppenv_joint& J = launder(cfg).joint[d];
+        const ppenv_joint J = ldc(cfg.joint[d]);
         float err = target[d] - q[d];
         float vn = qd[d] + h * qdd[d];
         tau_drive[d] = sat[d] ? tau[d] : J.kp * (err - h * vn) - J.kd * vn;
@@ -440,88 +461,98 @@ PP_HD void arm_substep(const ppenv_config& cfg, JointSave* js, float* q, float* 
 // ---------------------------------------------------------------- ball contacts
 struct Ball { V3 p, v, w; float quat[4]; };
 
+// hot scalars of the contact model, fetched / derived once per substep
+struct BallConsts {
+    float contact_offset, bounce_threshold, depen_cap, r;
+    float inv_kr;        // 1 / (k r):  spin change per unit tangential impulse, I = k m r^2
+    float stick_factor;  // 1 / (1 + 1/k): tangential impulse that stops slipping, per unit slip speed
+};
+
 // n: unit normal surface -> ball; s: separation; u: surface velocity at the contact
-PP_HD void contact_resolve(const ppenv_config& c, Ball& b, V3 n, float s, V3 u, float e, float mu, float hb) {
-    if (!(s < c.contact_offset)) return;
-    const float r = c.ball_radius, kappa = c.ball_inertia_factor;
-    V3 vrel = b.v + cross(b.w, n * (-r)) - u;
+PP_HD void contact_resolve(const BallConsts& k, Ball& b, V3 n, float s, V3 u, float e, float mu) {
+    if (!(s < k.contact_offset)) return;
+    V3 vrel = b.v + cross(b.w, n * (-k.r)) - u;
     float vn = dot(vrel, n);
     if (vn < 0.f) {
-        float e_eff = (-vn > c.bounce_threshold) ? e : 0.f;
+        float e_eff = (-vn > k.bounce_threshold) ? e : 0.f;
         float jn = -(1.f + e_eff) * vn;
         V3 vt = vrel - n * vn;
-        float vtl = sqrtf(dot(vt, vt));
-        float jt = 0.f;
-        V3 dir = mk(0, 0, 0);
-        if (vtl > 1e-9f) {
-            dir = vt * (1.f / vtl);
-            float stick = vtl / (1.f + 1.f / kappa);
-            jt = fminf(mu * jn, stick);
+        float vt2 = dot(vt, vt);
+        if (vt2 > 1e-18f) {
+            float inv = rsq_fast(vt2);
+            V3 dir = vt * inv;
+            float jt = fminf(mu * jn, vt2 * inv * k.stick_factor);
+            b.v = b.v - dir * jt;
+            b.w = b.w + cross(n, dir) * (jt * k.inv_kr);
         }
-        b.v = b.v + n * jn - dir * jt;
-        b.w = b.w + cross(n, dir) * (jt / (kappa * r));
+        b.v = b.v + n * jn;
     }
-    if (s < 0.f) b.p = madd(b.p, n, fminf(-s, c.max_depenetration_velocity * hb));
+    if (s < 0.f) b.p = madd(b.p, n, fminf(-s, k.depen_cap));
 }
 PP_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-PP_HD void contact_box(const ppenv_config& c, Ball& b, const ppenv_box& box, float hb) {
+PP_HD void contact_box(const BallConsts& k, Ball& b, const ppenv_box& box) {
     V3 d = b.p - ld3(box.center);
     V3 h = ld3(box.half);
     // cheap reject: farther than radius + contact offset from the box on some axis
-    float reach = c.ball_radius + c.contact_offset;
+    float reach = k.r + k.contact_offset;
     if (fabsf(d.x) > h.x + reach || fabsf(d.y) > h.y + reach || fabsf(d.z) > h.z + reach) return;
     V3 q = mk(clampf(d.x, -h.x, h.x), clampf(d.y, -h.y, h.y), clampf(d.z, -h.z, h.z));
     V3 diff = d - q;
-    float dist = sqrtf(dot(diff, diff));
+    float d2 = dot(diff, diff);
     V3 n;
     float s;
-    if (dist > 1e-12f) { n = diff * (1.f / dist); s = dist - c.ball_radius; }
+    if (d2 > 1e-24f) { float inv = rsq_fast(d2); n = diff * inv; s = d2 * inv - k.r; }
     else {   // centre inside the box: leave through the nearest face
         float px = h.x - fabsf(d.x), py = h.y - fabsf(d.y), pz = h.z - fabsf(d.z);
-        if (px <= py && px <= pz) { n = mk(d.x >= 0.f ? 1.f : -1.f, 0, 0); s = -px - c.ball_radius; }
-        else if (py <= pz) { n = mk(0, d.y >= 0.f ? 1.f : -1.f, 0); s = -py - c.ball_radius; }
-        else { n = mk(0, 0, d.z >= 0.f ? 1.f : -1.f); s = -pz - c.ball_radius; }
+        if (px <= py && px <= pz) { n = mk(d.x >= 0.f ? 1.f : -1.f, 0, 0); s = -px - k.r; }
+        else if (py <= pz) { n = mk(0, d.y >= 0.f ? 1.f : -1.f, 0); s = -py - k.r; }
+        else { n = mk(0, 0, d.z >= 0.f ? 1.f : -1.f); s = -pz - k.r; }
     }
-    contact_resolve(c, b, n, s, mk(0, 0, 0), box.restitution, box.friction, hb);
+    contact_resolve(k, b, n, s, mk(0, 0, 0), box.restitution, box.friction);
 }
-PP_HD void contact_capsule(const ppenv_config& c, Ball& b, V3 a, V3 bb, V3 ua, V3 ub, float radius, float e, float mu, float hb) {
+PP_HD void contact_capsule(const BallConsts& k, Ball& b, V3 a, V3 bb, V3 ua, V3 ub, float radius, float e, float mu) {
     V3 ab = bb - a;
     float l2 = dot(ab, ab), t = 0.f;
-    if (l2 > 1e-12f) t = clampf(dot(b.p - a, ab) / l2, 0.f, 1.f);
+    if (l2 > 1e-12f) t = clampf(dot(b.p - a, ab) * rcp_fast(l2), 0.f, 1.f);
     V3 cp = madd(a, ab, t);
     V3 diff = b.p - cp;
-    float dist = sqrtf(dot(diff, diff));
-    V3 n = dist > 1e-12f ? diff * (1.f / dist) : mk(0, 0, 1);
+    float d2 = dot(diff, diff);
+    if (d2 > (radius + k.r + k.contact_offset) * (radius + k.r + k.contact_offset)) return;   // not touching
+    float inv = d2 > 1e-24f ? rsq_fast(d2) : 0.f;
+    V3 n = d2 > 1e-24f ? diff * inv : mk(0, 0, 1);
     V3 u = madd(ua, ub - ua, t);
-    contact_resolve(c, b, n, dist - radius - c.ball_radius, u, e, mu, hb);
+    contact_resolve(k, b, n, d2 * inv - radius - k.r, u, e, mu);
 }
 // the paddle blade: solid disc, centre cc, unit axis nn, centre velocity uc, axis rate nd
-PP_HD void contact_disc(const ppenv_config& c, Ball& b, V3 cc, V3 nn, V3 uc, V3 nd, float hb) {
-    const float R = c.paddle_radius, tp = c.paddle_half_thickness;
+PP_HD void contact_disc(const BallConsts& k, Ball& b, V3 cc, V3 nn, V3 uc, V3 nd, float R, float tp, float e, float mu) {
     V3 d = b.p - cc;
     float hgt = dot(d, nn);
     V3 radial = d - nn * hgt;
-    float rr = sqrtf(dot(radial, radial));
+    float rr2 = dot(radial, radial);
+    float reach = k.r + k.contact_offset;
+    if (fabsf(hgt) > tp + reach || rr2 > (R + reach) * (R + reach)) return;   // not touching
+    float rr = sqrtf(rr2);
     V3 n, closest;
     float s;
     if (fabsf(hgt) < tp && rr < R) {   // centre inside the blade: leave through the nearer face
         float sg = hgt >= 0.f ? 1.f : -1.f;
         n = nn * sg;
-        s = -(tp - fabsf(hgt)) - c.ball_radius;
+        s = -(tp - fabsf(hgt)) - k.r;
         closest = cc + nn * (sg * tp) + radial;
     } else {
         float hc = clampf(hgt, -tp, tp);
         float rc = fminf(rr, R);
-        V3 rdir = rr > 1e-12f ? radial * (rc / rr) : mk(0, 0, 0);
+        V3 rdir = rr > 1e-12f ? radial * (rc * rcp_fast(rr)) : mk(0, 0, 0);
         closest = cc + nn * hc + rdir;
         V3 diff = b.p - closest;
-        float dist = sqrtf(dot(diff, diff));
-        n = dist > 1e-12f ? diff * (1.f / dist) : nn;
-        s = dist - c.ball_radius;
+        float d2 = dot(diff, diff);
+        float inv = d2 > 1e-24f ? rsq_fast(d2) : 0.f;
+        n = d2 > 1e-24f ? diff * inv : nn;
+        s = d2 * inv - k.r;
     }
     V3 u = uc + cross(cross(nn, nd), closest - cc);
-    contact_resolve(c, b, n, s, u, c.paddle_restitution, c.paddle_friction, hb);
+    contact_resolve(k, b, n, s, u, e, mu);
 }
 
 PP_HD V3 lerp(V3 a, V3 b, float f) { return madd(a, b - a, f); }
@@ -530,43 +561,63 @@ PP_HD V3 lerp(V3 a, V3 b, float f) { return madd(a, b - a, f); }
 // and the arm geometry interpolated between the substep's two ends (g0 -> g1)
 template <class T>
 PP_HD void ball_substep(const ppenv_config& cfg, Ball& b, const ArmGeom<T::kShapes>& g0, const ArmGeom<T::kShapes>& g1, float h) {
-    const int M = cfg.ball_substeps;
-    const float hb = h / (float)M;
-    const float inv_h = 1.0f / h;
+    const int M = ldu(cfg.ball_substeps);
+    const float inv_m = rcp_fast((float)M);
+    const float hb = h * inv_m;
+    const float inv_h = rcp_fast(h);
+    BallConsts k;
+    k.contact_offset = ldu(cfg.contact_offset);
+    k.bounce_threshold = ldu(cfg.bounce_threshold);
+    k.depen_cap = ldu(cfg.max_depenetration_velocity) * hb;
+    k.r = ldu(cfg.ball_radius);
+    const float kappa = ldu(cfg.ball_inertia_factor);
+    k.inv_kr = rcp_fast(kappa * k.r);
+    k.stick_factor = kappa * rcp_fast(kappa + 1.f);
+    const float gdv = ldu(cfg.gravity_z) * hb;
+    const float damp = fmaxf(1.0f - ldu(cfg.ball_angular_damping) * hb, 0.f);
+    const float ground_z = ldu(cfg.ground_z), ground_e = ldu(cfg.ground_restitution), ground_mu = ldu(cfg.ground_friction);
+    const V3 bc = ldu(*reinterpret_cast<const V3*>(cfg.humanoid_bound_center));
+    const float br = ldu(cfg.humanoid_bound_radius);
     for (int m = 0; m < M; m++) {
-        const ppenv_config& c = launder(cfg);
-        float f = (float)m / (float)M;
-        b.v.z += c.gravity_z * hb;
-        b.w = b.w * fmaxf(1.0f - c.ball_angular_damping * hb, 0.f);
-        contact_resolve(c, b, mk(0, 0, 1), b.p.z - c.ground_z - c.ball_radius, mk(0, 0, 0), c.ground_restitution, c.ground_friction, hb);
-        contact_box(c, b, c.table, hb);
-        contact_box(c, b, c.net, hb);
-        V3 db = b.p - ld3(c.humanoid_bound_center);
-        if (dot(db, db) < c.humanoid_bound_radius * c.humanoid_bound_radius) {
+        float f = (float)m * inv_m;
+        b.v.z += gdv;
+        b.w = b.w * damp;
+        contact_resolve(k, b, mk(0, 0, 1), b.p.z - ground_z - k.r, mk(0, 0, 0), ground_e, ground_mu);
+        {
+            const ppenv_box table = ldc(cfg.table);
+            contact_box(k, b, table);
+        }
+        {
+            const ppenv_box net = ldc(cfg.net);
+            contact_box(k, b, net);
+        }
+        V3 db = b.p - bc;
+        if (dot(db, db) < br * br) {
             V3 cc = lerp(g0.pc, g1.pc, f);
             V3 nn = lerp(g0.pn, g1.pn, f);
-            nn = nn * (1.f / sqrtf(dot(nn, nn)));
-            contact_disc(c, b, cc, nn, (g1.pc - g0.pc) * inv_h, (g1.pn - g0.pn) * inv_h, hb);
+            nn = nn * rsq_fast(dot(nn, nn));
+            contact_disc(k, b, cc, nn, (g1.pc - g0.pc) * inv_h, (g1.pn - g0.pn) * inv_h, ldu(cfg.paddle_radius),
+                         ldu(cfg.paddle_half_thickness), ldu(cfg.paddle_restitution), ldu(cfg.paddle_friction));
 #pragma unroll
             for (int s = 0; s < T::kShapes; s++) {
-                const ppenv_shape& sh = launder(cfg).shape[s];
+                const float radius = ldu(cfg.shape[s].radius), e = ldu(cfg.shape[s].restitution), mu = ldu(cfg.shape[s].friction);
                 if (T::shape_link(s) < 0)
-                    contact_capsule(c, b, g0.a[s], g0.b[s], mk(0, 0, 0), mk(0, 0, 0), sh.radius, sh.restitution, sh.friction, hb);
+                    contact_capsule(k, b, g0.a[s], g0.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
                 else
-                    contact_capsule(c, b, lerp(g0.a[s], g1.a[s], f), lerp(g0.b[s], g1.b[s], f), (g1.a[s] - g0.a[s]) * inv_h,
-                                    (g1.b[s] - g0.b[s]) * inv_h, sh.radius, sh.restitution, sh.friction, hb);
+                    contact_capsule(k, b, lerp(g0.a[s], g1.a[s], f), lerp(g0.b[s], g1.b[s], f), (g1.a[s] - g0.a[s]) * inv_h,
+                                    (g1.b[s] - g0.b[s]) * inv_h, radius, e, mu);
             }
         }
         b.p = madd(b.p, b.v, hb);
     }
     // orientation: q <- normalize(q + h/2 (w,0) (x) q), xyzw
     float wx = b.w.x, wy = b.w.y, wz = b.w.z, x = b.quat[0], y = b.quat[1], z = b.quat[2], w = b.quat[3];
-    float k = 0.5f * h;
-    float nx = x + k * (wx * w + wy * z - wz * y);
-    float ny = y + k * (wy * w + wz * x - wx * z);
-    float nz = z + k * (wz * w + wx * y - wy * x);
-    float nw = w + k * (-wx * x - wy * y - wz * z);
-    float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+    float kq = 0.5f * h;
+    float nx = x + kq * (wx * w + wy * z - wz * y);
+    float ny = y + kq * (wy * w + wz * x - wx * z);
+    float nz = z + kq * (wz * w + wx * y - wy * x);
+    float nw = w + kq * (-wx * x - wy * y - wz * z);
+    float inv = rsq_fast(nx * nx + ny * ny + nz * nz + nw * nw);
     b.quat[0] = nx * inv; b.quat[1] = ny * inv; b.quat[2] = nz * inv; b.quat[3] = nw * inv;
 }
 
@@ -676,13 +727,14 @@ PP_HD void simulate_env(const ppenv_config& cfg, const float* actions, EnvState&
     float target[ND];
 #pragma unroll
     for (int d = 0; d < ND; d++) {   // VecTask.step clamp + TT:1008 (offset/scale TT:664-665)
-        const ppenv_config& c = launder(cfg);
-        float a = fminf(fmaxf(actions[d], -c.clip_actions), c.clip_actions);
-        float lo = c.joint[d].lower, hi = c.joint[d].upper;
+        const float clip = ldu(cfg.clip_actions);
+        float a = fminf(fmaxf(actions[d], -clip), clip);
+        float lo = ldu(cfg.joint[d].lower), hi = ldu(cfg.joint[d].upper);
         target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;
     }
     pre_vx = st.ball.v.x;   // TT:1020
-    const float h = cfg.dt / (float)cfg.substeps;
+    const int substeps = ldu(cfg.substeps);
+    const float h = ldu(cfg.dt) / (float)substeps;
     JointSave js[ND];
     ArmGeom<T::kShapes> g0, g1;
     static_geometry<T>(cfg, g0);
@@ -691,9 +743,9 @@ PP_HD void simulate_env(const ppenv_config& cfg, const float* actions, EnvState&
         GeomVisitor<T> gv(cfg, g0);
         fk_sweep<T>(cfg, st.q, st.qd, js, gv);
     }
-    for (int s = 0; s < cfg.substeps; s++) {
+    for (int s = 0; s < substeps; s++) {
         arm_substep<T>(cfg, js, st.q, st.qd, target, h, st.dof_force);
-        if (s + 1 < cfg.substeps) {
+        if (s + 1 < substeps) {
             GeomVisitor<T> gv(cfg, g1);
             fk_sweep<T>(cfg, st.q, st.qd, js, gv);
         } else {
