@@ -15,7 +15,7 @@ ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "lib", "libppenv.so")
 SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip")]
 HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(ROOT, "include", "ppenv.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only", "-fPIC", "-shared"]
 
 _lib = None
 

@@ -100,10 +100,18 @@ template <class T>
 __global__ __launch_bounds__(kBlock) void step_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, const float* __restrict__ actions, int serve_on) {
     __shared__ float s_obs[kBlock * kObsStride];
     __shared__ float s_act[kBlock * ND];
+    const int lane = threadIdx.x;
+#if defined(PP_CFG_LDS)
+    // model constants staged once per workgroup; read back as LDS broadcasts (ordered lgkmcnt)
+    __shared__ __attribute__((aligned(16))) uint32_t s_cfg[(sizeof(ppenv_config) + 3) / 4];
+    for (int k = lane; k < (int)(sizeof(ppenv_config) / 4); k += kBlock) s_cfg[k] = reinterpret_cast<const uint32_t*>(cfgp)[k];
+    const ppenv_config& cfg = *reinterpret_cast<const ppenv_config*>(s_cfg);
+    const int n = cfgp->num_envs;
+#else
     const ppenv_config& cfg = *cfgp;
     const int n = cfg.num_envs;
+#endif
     const int base = blockIdx.x * kBlock;
-    const int lane = threadIdx.x;
     const int i = base + lane;
     const int nvalid = min(kBlock, n - base);
 
@@ -377,9 +385,9 @@ bool validate(const ppenv_config* c) {
     if (c->variant < PPENV_VARIANT_T3 || c->variant > PPENV_VARIANT_TN) { set_err("unknown task variant"); return false; }
     if (c->substeps < 1 || c->substeps > 16 || c->ball_substeps < 1 || c->ball_substeps > 64) { set_err("substeps / ball_substeps out of range"); return false; }
     if (!(c->dt > 0.f)) { set_err("dt must be positive"); return false; }
-    if (!topo_matches<TopoG1>(*c)) {
+    if (!model_matches<ModelG1>(*c)) {
         set_err("chain topology (joint axes / shape links / observed-body frames) has no compiled kernel instantiation; "
-                "this build ships the Unitree G1 right-arm chain (ppenv_device.h TopoG1)");
+                "this build ships the Unitree G1 right-arm chain (ppenv_device.h ModelG1)");
         return false;
     }
     for (int d = 0; d < ND; d++)
@@ -456,7 +464,7 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
     hipError_t err = hipMemsetAsync(e->arena, 0, l.total, s);
     if (err == hipSuccess) err = hipMemcpyAsync(e->cfg_dev, &e->cfg, sizeof(ppenv_config), hipMemcpyHostToDevice, s);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL(init_kernel<TopoG1>, dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->cfg_dev, e->buf, 0, 0);
+        hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->cfg_dev, e->buf, 0, 0);
         err = hipGetLastError();
     }
     if (err != hipSuccess) {
@@ -497,7 +505,7 @@ int ppenv_config_of(ppenv* e, ppenv_config* out) {
 int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(step_kernel<TopoG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf,
+    hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf,
                        actions_dev, e->serve_on);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
@@ -506,7 +514,7 @@ int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
 int ppenv_reset_all(ppenv* e, void* stream) {
     if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(init_kernel<TopoG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf, 1,
+    hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf, 1,
                        e->serve_on);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
@@ -549,7 +557,7 @@ int ppenv_refresh_dof_force(ppenv* e, float* out, void* stream) {
 int ppenv_refresh_rigid_body_states(ppenv* e, float* out, void* stream) {
     if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(refresh_rb_kernel<TopoG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
+    hipLaunchKernelGGL(refresh_rb_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }

@@ -18,6 +18,7 @@
 #pragma once
 
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/ppenv.h"
@@ -53,7 +54,7 @@ PP_HD void sincos_joint(float q, float& s, float& c) {
 //               the arm model out of the substep loop and holding them live (that spilled >1000
 //               SGPRs); each block of constants is fetched right where it is used instead.
 //   ldu(field): plain scalar read the optimiser may hoist and CSE (the few dozen hot scalars).
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PP_CFG_LDS)
 #define PP_CONST_AS __attribute__((address_space(4)))
 template <class S>
 PP_HD S ldc(const S& f) {
@@ -71,6 +72,13 @@ PP_HD S ldu(const S& f) {
 }
 // 1-ulp hardware reciprocal / reciprocal square root for the physics (reward and observations keep
 // IEEE division and sqrt so that thresholds and roundings follow the reference's torch arithmetic)
+// fence(cfg): the same config behind an empty asm; scalars read through the result cannot be hoisted
+// above this point (keeps one phase's constants from staying live in SGPRs through the others)
+PP_HD const ppenv_config& fence(const ppenv_config& c) {
+    const ppenv_config* p = &c;
+    asm volatile("" : "+s"(p));
+    return *p;
+}
 PP_HD float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 PP_HD float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
 #else
@@ -78,8 +86,14 @@ template <class S>
 PP_HD S ldc(const S& f) { return f; }
 template <class S>
 PP_HD S ldu(const S& f) { return f; }
+PP_HD const ppenv_config& fence(const ppenv_config& c) { return c; }
+#if defined(__HIP_DEVICE_COMPILE__)
+PP_HD float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+PP_HD float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
 PP_HD float rcp_fast(float x) { return 1.0f / x; }
 PP_HD float rsq_fast(float x) { return 1.0f / sqrtf(x); }
+#endif
 #endif
 
 // ------------------------------------------------------------------ small math
@@ -221,14 +235,18 @@ PP_HD V3 serve_velocity(const ppenv_config& c, uint32_t gid, uint32_t episode) {
     return mk(-speed * ca * cz, speed * sa * cz, speed * sz);                                     // TN:312-323
 }
 
-// --------------------------------------------------------------- chain topology
-template <uint32_t AXES, uint32_t SHAPE_LINKS, int NSHAPES>
-struct Topo {
-    static constexpr int kShapes = NSHAPES;
-    PP_HD static constexpr int axis(int i) { return (int)((AXES >> (2 * i)) & 3u); }
-    // link a shape hangs on, -1 = static
-    PP_HD static constexpr int shape_link(int s) { return (int)((SHAPE_LINKS >> (4 * s)) & 15u) - 1; }
-};
+// Per-joint constant groups of the compiled model: kinematics, PD drive, inertial.
+struct JointKin { float origin_xyz[3]; float origin_rot[9]; };
+struct JointDrive { float lower, upper, kp, kd, effort, vel_limit, armature; };
+struct JointInertial { float mass; float com[3]; float inertia[6]; };
+struct ModelShape { float a[3], b[3]; float radius; };                       // link-attached capsule / sphere
+struct ModelPaddle { float center[3], normal[3]; float radius, half_thickness; };
+
+// --------------------------------------------------------------- compiled arm model
+// Every template parameter `T` below is a model struct generated by isaacgym_amd/modelgen.py
+// (ppenv_model_g1.h): T::axis(i), T::kin(i), T::drive(i), T::inertial(i), T::kShapes,
+// T::shape_link(s), T::shape(s), T::paddle(), T::tip_frame(j) — all constexpr, so with the per-joint
+// loops unrolled they fold into instruction literals and exact zeros / identities drop out.
 
 // world-frame collision geometry of the moving parts, sampled at a substep boundary
 template <int NSHAPES>
@@ -258,7 +276,7 @@ PP_HD void fk_sweep(const ppenv_config& cfg, const float* q, const float* qd, Jo
     V3 wp = mk(0, 0, 0), vp = mk(0, 0, 0);
 #pragma unroll
     for (int i = 0; i < ND; i++) {
-        const ppenv_joint J = ldc(cfg.joint[i]);
+        const JointKin J = T::kin(i);
         float s, c;
         sincos_joint(q[i], s, c);
         M3 E = T::axis(i) == 0 ? joint_rot<0>(J.origin_rot, c, s) : (T::axis(i) == 1 ? joint_rot<1>(J.origin_rot, c, s) : joint_rot<2>(J.origin_rot, c, s));
@@ -282,13 +300,14 @@ struct GeomVisitor {
     PP_HD GeomVisitor(const ppenv_config& c, ArmGeom<T::kShapes>& gg) : cfg(c), g(gg) {}
     PP_HD void operator()(int i, const M3& Rw, V3 pw, V3, V3) {
         if (i == ND - 1) {   // paddle_link is validated to be the last link at create time
-            g.pc = pw + mul(Rw, ldc(*reinterpret_cast<const V3*>(cfg.paddle_center)));
-            g.pn = mul(Rw, ldc(*reinterpret_cast<const V3*>(cfg.paddle_normal)));
+            const ModelPaddle P = T::paddle();
+            g.pc = pw + mul(Rw, ld3(P.center));
+            g.pn = mul(Rw, ld3(P.normal));
         }
 #pragma unroll
         for (int s = 0; s < T::kShapes; s++)
             if (T::shape_link(s) == i) {
-                const ppenv_shape sh = ldc(cfg.shape[s]);
+                const ModelShape sh = T::shape(s);
                 g.a[s] = pw + mul(Rw, ld3(sh.a));
                 g.b[s] = pw + mul(Rw, ld3(sh.b));
             }
@@ -320,11 +339,11 @@ struct BodyVisitor {
         if (i == ND - 1) {
 #pragma unroll
             for (int j = 8; j < NB; j++) {
-                const ppenv_frame f = ldc(cfg.obs_body[j]);
-                V3 off = mul(Rw, ld3(f.xyz));
+                const JointKin f = T::tip_frame(j);
+                V3 off = mul(Rw, ld3(f.origin_xyz));
                 bodies[j].pos = pw + off;
                 bodies[j].lin = vw + cross(ww, off);
-                if (FULL) { bodies[j].rot = mul(Rw, ldm(f.rot)); bodies[j].ang = ww; }
+                if (FULL) { bodies[j].rot = mul(Rw, ldm(f.origin_rot)); bodies[j].ang = ww; }
             }
         }
     }
@@ -347,7 +366,8 @@ PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, co
     V3 cn = mk(0, 0, 0), cf = mk(0, 0, 0);
 #pragma unroll
     for (int i = ND - 1; i >= 0; i--) {
-        const ppenv_joint J = ldc(cfg.joint[i]);
+        const JointKin JK = T::kin(i);
+        const JointInertial J = T::inertial(i);
         const int ax = T::axis(i);
         V3 w = js[i].w, v = js[i].v;
         // rigid-body inertia about the link origin: [[Io, m c x],[m c x^T, m 1]]
@@ -384,8 +404,8 @@ PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, co
             V3 pan = pn + mul(A, cw) + mul(B, cv) + ua * ud;
             V3 paf = pf + tmul(B, cw) + mul(D, cv) + ub * ud;
             // to the parent's coordinates: rotate by E, shift the origin by r
-            M3 E = ax == 0 ? joint_rot<0>(J.origin_rot, js[i].c, js[i].s) : (ax == 1 ? joint_rot<1>(J.origin_rot, js[i].c, js[i].s) : joint_rot<2>(J.origin_rot, js[i].c, js[i].s));
-            V3 r = ld3(J.origin_xyz);
+            M3 E = ax == 0 ? joint_rot<0>(JK.origin_rot, js[i].c, js[i].s) : (ax == 1 ? joint_rot<1>(JK.origin_rot, js[i].c, js[i].s) : joint_rot<2>(JK.origin_rot, js[i].c, js[i].s));
+            V3 r = ld3(JK.origin_xyz);
             S3 Ar = rot_sym(E, A), Dr = rot_sym(E, D);
             M3 Br = mul_t(mul(E, B), E);
             V3 nr = mul(E, pan), fr = mul(E, paf);
@@ -411,7 +431,7 @@ PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, co
     V3 av = tmul(ldc(*reinterpret_cast<const M3*>(cfg.base_rot)), mk(0, 0, -ldu(cfg.gravity_z)));
 #pragma unroll
     for (int i = 0; i < ND; i++) {
-        const ppenv_joint J = ldc(cfg.joint[i]);
+        const JointKin J = T::kin(i);
         const int ax = T::axis(i);
         M3 E = ax == 0 ? joint_rot<0>(J.origin_rot, js[i].c, js[i].s) : (ax == 1 ? joint_rot<1>(J.origin_rot, js[i].c, js[i].s) : joint_rot<2>(J.origin_rot, js[i].c, js[i].s));
         V3 r = ld3(J.origin_xyz);
@@ -435,7 +455,7 @@ PP_HD void arm_substep(const ppenv_config& cfg, JointSave* js, float* q, float* 
     bool sat[ND];
 #pragma unroll
     for (int d = 0; d < ND; d++) {
-        const ppenv_joint J = ldc(cfg.joint[d]);
+        const JointDrive J = T::drive(d);
         float err = target[d] - q[d];
         float t_exp = J.kp * err - J.kd * qd[d];
         sat[d] = fabsf(t_exp) > J.effort;
@@ -446,7 +466,7 @@ PP_HD void arm_substep(const ppenv_config& cfg, JointSave* js, float* q, float* 
     aba_solve<T>(cfg, js, qd, tau, arm, qdd);
 #pragma unroll
     for (int d = 0; d < ND; d++) {
-        const ppenv_joint J = ldc(cfg.joint[d]);
+        const JointDrive J = T::drive(d);
         float err = target[d] - q[d];
         float vn = qd[d] + h * qdd[d];
         tau_drive[d] = sat[d] ? tau[d] : J.kp * (err - h * vn) - J.kd * vn;
@@ -560,7 +580,8 @@ PP_HD V3 lerp(V3 a, V3 b, float f) { return madd(a, b - a, f); }
 // one physics substep of the ball: ball_substeps micro-steps against the static scene
 // and the arm geometry interpolated between the substep's two ends (g0 -> g1)
 template <class T>
-PP_HD void ball_substep(const ppenv_config& cfg, Ball& b, const ArmGeom<T::kShapes>& g0, const ArmGeom<T::kShapes>& g1, float h) {
+PP_HD void ball_substep(const ppenv_config& cfg_in, Ball& b, const ArmGeom<T::kShapes>& g0, const ArmGeom<T::kShapes>& g1, float h) {
+    const ppenv_config& cfg = fence(cfg_in);
     const int M = ldu(cfg.ball_substeps);
     const float inv_m = rcp_fast((float)M);
     const float hb = h * inv_m;
@@ -578,29 +599,25 @@ PP_HD void ball_substep(const ppenv_config& cfg, Ball& b, const ArmGeom<T::kShap
     const float ground_z = ldu(cfg.ground_z), ground_e = ldu(cfg.ground_restitution), ground_mu = ldu(cfg.ground_friction);
     const V3 bc = ldu(*reinterpret_cast<const V3*>(cfg.humanoid_bound_center));
     const float br = ldu(cfg.humanoid_bound_radius);
+    const ppenv_box table = ldu(cfg.table), net = ldu(cfg.net);
     for (int m = 0; m < M; m++) {
         float f = (float)m * inv_m;
         b.v.z += gdv;
         b.w = b.w * damp;
         contact_resolve(k, b, mk(0, 0, 1), b.p.z - ground_z - k.r, mk(0, 0, 0), ground_e, ground_mu);
-        {
-            const ppenv_box table = ldc(cfg.table);
-            contact_box(k, b, table);
-        }
-        {
-            const ppenv_box net = ldc(cfg.net);
-            contact_box(k, b, net);
-        }
+        contact_box(k, b, table);
+        contact_box(k, b, net);
         V3 db = b.p - bc;
         if (dot(db, db) < br * br) {
             V3 cc = lerp(g0.pc, g1.pc, f);
             V3 nn = lerp(g0.pn, g1.pn, f);
             nn = nn * rsq_fast(dot(nn, nn));
-            contact_disc(k, b, cc, nn, (g1.pc - g0.pc) * inv_h, (g1.pn - g0.pn) * inv_h, ldu(cfg.paddle_radius),
-                         ldu(cfg.paddle_half_thickness), ldu(cfg.paddle_restitution), ldu(cfg.paddle_friction));
+            const ModelPaddle P = T::paddle();
+            contact_disc(k, b, cc, nn, (g1.pc - g0.pc) * inv_h, (g1.pn - g0.pn) * inv_h, P.radius, P.half_thickness,
+                         ldu(cfg.paddle_restitution), ldu(cfg.paddle_friction));
 #pragma unroll
             for (int s = 0; s < T::kShapes; s++) {
-                const float radius = ldu(cfg.shape[s].radius), e = ldu(cfg.shape[s].restitution), mu = ldu(cfg.shape[s].friction);
+                const float radius = T::shape(s).radius, e = ldu(cfg.shape[s].restitution), mu = ldu(cfg.shape[s].friction);
                 if (T::shape_link(s) < 0)
                     contact_capsule(k, b, g0.a[s], g0.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
                 else
@@ -729,7 +746,7 @@ PP_HD void simulate_env(const ppenv_config& cfg, const float* actions, EnvState&
     for (int d = 0; d < ND; d++) {   // VecTask.step clamp + TT:1008 (offset/scale TT:664-665)
         const float clip = ldu(cfg.clip_actions);
         float a = fminf(fmaxf(actions[d], -clip), clip);
-        float lo = ldu(cfg.joint[d].lower), hi = ldu(cfg.joint[d].upper);
+        const float lo = T::drive(d).lower, hi = T::drive(d).upper;
         target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;
     }
     pre_vx = st.ball.v.x;   // TT:1020
@@ -841,22 +858,37 @@ PP_HD void post_physics_env(const ppenv_config& cfg, uint32_t gid, EnvState& st,
 
 }  // namespace pp
 
-// ------------------------------------------------------- instantiated topologies
-namespace pp {
-// Unitree G1 right arm: shoulder pitch(y) roll(x) yaw(z), elbow(y), wrist roll(x) pitch(y) yaw(z)
-// (TT:427-431); shapes: hand on link 6, forearm on 3, upper arm on 1, then three static ones.
-constexpr uint32_t kAxesG1 = 1u | (0u << 2) | (2u << 4) | (1u << 6) | (0u << 8) | (1u << 10) | (2u << 12);
-constexpr uint32_t kShapeLinksG1 = 7u | (4u << 4) | (2u << 8) | (0u << 12) | (0u << 16) | (0u << 20);
-using TopoG1 = Topo<kAxesG1, kShapeLinksG1, 6>;
+// ------------------------------------------------------- the compiled model and its runtime check
+#include "ppenv_model_g1.h"
 
-// does a config have the topology `T` was compiled for?
+namespace pp {
+// Does the runtime config describe exactly the arm model `T` was compiled from?  (bitwise on the floats)
 template <class T>
-inline bool topo_matches(const ppenv_config& c) {
+inline bool model_matches(const ppenv_config& c) {
+    auto same = [](const float* a, const float* b, int n) {
+        for (int i = 0; i < n; i++)
+            if (!(a[i] == b[i])) return false;
+        return true;
+    };
     if (c.num_shapes != T::kShapes || c.paddle_link != ND - 1 || c.paddle_obs_index != NB - 1) return false;
-    for (int i = 0; i < ND; i++)
-        if (c.joint[i].axis != T::axis(i)) return false;
-    for (int s = 0; s < T::kShapes; s++)
-        if (c.shape[s].link != T::shape_link(s)) return false;
+    for (int i = 0; i < ND; i++) {
+        const ppenv_joint& j = c.joint[i];
+        const JointKin k = T::kin(i);
+        const JointDrive d = T::drive(i);
+        const JointInertial in = T::inertial(i);
+        if (j.axis != T::axis(i) || !same(j.origin_xyz, k.origin_xyz, 3) || !same(j.origin_rot, k.origin_rot, 9)) return false;
+        if (!same(&j.lower, &d.lower, 7)) return false;
+        if (j.mass != in.mass || !same(j.com, in.com, 3) || !same(j.inertia, in.inertia, 6)) return false;
+    }
+    for (int s = 0; s < T::kShapes; s++) {
+        const ModelShape m = T::shape(s);
+        if (c.shape[s].link != T::shape_link(s) || c.shape[s].radius != m.radius) return false;
+        if (T::shape_link(s) >= 0 && (!same(c.shape[s].a, m.a, 3) || !same(c.shape[s].b, m.b, 3))) return false;
+    }
+    const ModelPaddle p = T::paddle();
+    if (!same(c.paddle_center, p.center, 3) || !same(c.paddle_normal, p.normal, 3) || c.paddle_radius != p.radius ||
+        c.paddle_half_thickness != p.half_thickness)
+        return false;
     if (c.obs_body[0].link != -1) return false;
     for (int j = 1; j <= ND; j++) {
         const ppenv_frame& f = c.obs_body[j];
@@ -864,8 +896,10 @@ inline bool topo_matches(const ppenv_config& c) {
         for (int k = 0; k < 9; k++)
             if (f.rot[k] != ((k % 4 == 0) ? 1.f : 0.f)) return false;
     }
-    for (int j = ND + 1; j < NB; j++)
-        if (c.obs_body[j].link != ND - 1) return false;
+    for (int j = ND + 1; j < NB; j++) {
+        const JointKin t = T::tip_frame(j);
+        if (c.obs_body[j].link != ND - 1 || !same(c.obs_body[j].xyz, t.origin_xyz, 3) || !same(c.obs_body[j].rot, t.origin_rot, 9)) return false;
+    }
     return true;
 }
 }  // namespace pp

@@ -137,6 +137,9 @@ def _inertia_vec(m):
 def composite_inertial(parts):
     """Merge rigidly attached bodies.  parts: list of (mass, com[3], I_com[3x3], R[3x3] link<-part).
     Returns (mass, com, I about composite com in link axes)."""
+    if len(parts) == 1:   # nothing to merge: keep the table values exactly (zeros stay zeros)
+        mass, c, i_com, rot = parts[0]
+        return mass, np.asarray(c, dtype=np.float64), rot @ np.asarray(i_com, dtype=np.float64) @ rot.T
     m = sum(p[0] for p in parts)
     com = sum(p[0] * np.asarray(p[1], dtype=np.float64) for p in parts) / m
     inertia = np.zeros((3, 3))

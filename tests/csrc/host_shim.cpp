@@ -7,7 +7,7 @@
 #include "../../isaacgym_amd/csrc/ppenv_device.h"
 
 using namespace pp;
-using T = TopoG1;
+using T = ModelG1;
 
 namespace {
 struct RowStore {
@@ -35,7 +35,7 @@ void store_state(int n, int i, float* dof_pos, float* dof_vel, float* dof_force,
 
 extern "C" {
 
-int shim_topo_matches(const ppenv_config* cfg) { return topo_matches<T>(*cfg) ? 1 : 0; }
+int shim_model_matches(const ppenv_config* cfg) { return model_matches<T>(*cfg) ? 1 : 0; }
 
 // one fused step over SoA arrays laid out like ppenv_buffers
 void shim_step(const ppenv_config* cfg, const float* actions /*[N,7]*/, float* dof_pos, float* dof_vel, float* dof_force,

@@ -19,7 +19,7 @@ def lib():
     global _lib
     if _lib is None:
         if (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < max(os.path.getmtime(_SRC), os.path.getmtime(_HDR)):
-            subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=fast", "-Wno-unknown-pragmas",
+            subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=fast", "-fno-signed-zeros", "-ffinite-math-only", "-Wno-unknown-pragmas",
                             "-o", _LIB, _SRC], check=True, capture_output=True)
         _lib = C.CDLL(_LIB)
     return _lib
@@ -35,7 +35,7 @@ class ShimEnv:
     def __init__(self, config):
         self.L = lib()
         self.config = config
-        assert self.L.shim_topo_matches(C.byref(config)) == 1
+        assert self.L.shim_model_matches(C.byref(config)) == 1
         n = self.num_envs = config.num_envs
         self.obs_buf = np.zeros((n, scene.NUM_OBS), np.float32)
         self.rew_buf = np.zeros(n, np.float32)
