@@ -12,7 +12,7 @@ from . import scene
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "lib", "libppenv.so")
+LIB_PATH = os.environ.get("PPENV_LIB", os.path.join(_PKG, "lib", "libppenv.so"))   # PPENV_LIB: profiling builds only
 SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip")]
 HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(ROOT, "include", "ppenv.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only", "-fPIC", "-shared"]

@@ -16,6 +16,12 @@
 #include <cstring>
 #include <new>
 
+#ifndef PP_ABLATE
+#define PP_ABLATE 0
+#endif
+#if defined(PP_STAMP)
+__device__ unsigned long long pp_stamp_buf[4096 * 32];
+#endif
 #include "ppenv_device.h"
 
 using namespace pp;
@@ -97,57 +103,70 @@ __device__ __forceinline__ void flush_obs(const float* s_obs, float* obs, int ba
 // ------------------------------------------------------------------ the fused step
 // K1..K8 of SURVEY.md §2 in one launch: TT:1002-1052.
 template <class T>
-__global__ __launch_bounds__(kBlock) void step_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, const float* __restrict__ actions, int serve_on) {
+__global__ __launch_bounds__(kBlock) void step_kernel(const ppenv_config* __restrict__ cfgp, const float* __restrict__ hinv, DevBuffers b, const float* __restrict__ actions,
+                 int serve_on) {
     __shared__ float s_obs[kBlock * kObsStride];
-    __shared__ float s_act[kBlock * ND];
     const int lane = threadIdx.x;
-#if defined(PP_CFG_LDS)
-    // model constants staged once per workgroup; read back as LDS broadcasts (ordered lgkmcnt)
-    __shared__ __attribute__((aligned(16))) uint32_t s_cfg[(sizeof(ppenv_config) + 3) / 4];
-    for (int k = lane; k < (int)(sizeof(ppenv_config) / 4); k += kBlock) s_cfg[k] = reinterpret_cast<const uint32_t*>(cfgp)[k];
-    const ppenv_config& cfg = *reinterpret_cast<const ppenv_config*>(s_cfg);
-    const int n = cfgp->num_envs;
-#else
+    PP_STAMP_AT(0);
     const ppenv_config& cfg = *cfgp;
     const int n = cfg.num_envs;
-#endif
     const int base = blockIdx.x * kBlock;
     const int i = base + lane;
     const int nvalid = min(kBlock, n - base);
 
-    // actions [N,7] row-major: this workgroup's rows are one contiguous run
-    for (int k = lane; k < nvalid * ND; k += kBlock) s_act[k] = actions[(size_t)base * ND + k];
-    __syncthreads();
-
     if (i < n) {
-        EnvState st;
-        load_state(b, n, i, st);
+        // actions [N,7] row-major: the wave's 64 rows are one contiguous 1792-byte run, so the seven
+        // strided dword loads of a lane hit the same 28 cache lines (L1 serves the re-touches)
         float act[ND];
 #pragma unroll
-        for (int d = 0; d < ND; d++) act[d] = s_act[lane * ND + d];
+        for (int d = 0; d < ND; d++) act[d] = actions[(size_t)i * ND + d];
+        EnvState st;
+        load_state(b, n, i, st);
+#if defined(PP_STAMP)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // attribute the load latency to phase 0->1
+#endif
+        PP_STAMP_AT(1);
         BodyState bodies[NB];
         float pre_vx;
+#if PP_ABLATE >= 2   // profiling builds only (tools/gpu_ablate.sh): skip the physics
+        pre_vx = st.ball.v.x;
+#pragma unroll
+        for (int j = 0; j < NB; j++) { bodies[j].pos = mk(act[0], act[1], (float)j); bodies[j].lin = mk(act[2], act[3], act[4]); }
+#else
         simulate_env<T>(cfg, act, st, bodies, pre_vx);
+#endif
         V3 ov = mk(0, 0, 0);
         if (serve_on) ov = mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i]);
         LdsRowStore store{&s_obs[lane * kObsStride]};
         float rew;
         long long reset;
-        post_physics_env(cfg, (uint32_t)(cfg.env_id_offset + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, rew, reset, store);
+#if PP_ABLATE >= 3   // skip reward / reset / observations as well: loads + stores only
+        rew = pre_vx; reset = 0;
+#pragma unroll
+        for (int k = 0; k < PPENV_NUM_OBS; k++) store(k, bodies[k % NB].pos.x);
+#else
+        post_physics_env(cfg, hinv, (uint32_t)(ldu(cfg.env_id_offset) + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, rew, reset, store);
+#endif
+        PP_STAMP_AT(9);
         store_state(b, n, i, st);
         b.rew[i] = rew;
         b.reset[i] = reset;
     }
     __syncthreads();
     flush_obs(s_obs, b.obs, base, nvalid);
+    PP_STAMP_AT(10);
 }
 
 // create (mode 0: creation is episode 0) / reset_all (mode 1: next episode): state as after
 // _create_envs (TT:512-643) plus the observations of that state
 template <class T>
-__global__ __launch_bounds__(kBlock) void init_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, int mode, int serve_on) {
+__global__ __launch_bounds__(kBlock) void init_kernel(const ppenv_config* __restrict__ cfgp, float* hinv_out, DevBuffers b, int mode, int serve_on) {
     __shared__ float s_obs[kBlock * kObsStride];
     const ppenv_config& cfg = *cfgp;
+    float hinv[4];
+    heading_quat_inv(cfg.humanoid_root_quat, hinv);   // calc_heading_quat_inv of the fixed pelvis, once
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int k = 0; k < 4; k++) hinv_out[k] = hinv[k];
     const int n = cfg.num_envs;
     const int base = blockIdx.x * kBlock;
     const int lane = threadIdx.x;
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const ppenv_config* __rest
 #pragma unroll
         for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
         LdsRowStore store{&s_obs[lane * kObsStride]};
-        write_obs(bpos, bvel, cfg.humanoid_root_quat, st.q, st.qd, st.ball.p, st.ball.v, store);
+        write_obs(bpos, bvel, hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
         store_state(b, n, i, st);
         b.rew[i] = 0.f;
         b.reset[i] = 1;   // upstream VecTask.allocate_buffers: ones; overwritten by the first step (TT:740)
@@ -257,7 +276,9 @@ __global__ __launch_bounds__(kBlock) void post_physics_kernel(const ppenv_config
             st.flags = PPENV_FLAG_NO_BOUNCE;
         }
         LdsRowStore store{&s_obs[lane * kObsStride]};
-        write_obs(bpos, bvel, root_quat, st.q, st.qd, st.ball.p, st.ball.v, store);
+        float hinv[4];
+        heading_quat_inv(root_quat, hinv);
+        write_obs(bpos, bvel, hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
         b.progress[i] = st.progress;
         b.flags[i] = st.flags;
         b.episode[i] = st.episode;
@@ -356,7 +377,7 @@ void set_err(const char* fmt, const char* a = "", const char* b = "") { snprintf
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t obs, rew, reset, progress, dof_pos, dof_vel, dof_force, ball, flags, episode, serve, cfg, total;
+    size_t obs, rew, reset, progress, dof_pos, dof_vel, dof_force, ball, flags, episode, serve, cfg, hinv, total;
 };
 Layout layout_for(int n) {
     Layout l;
@@ -374,6 +395,7 @@ Layout layout_for(int n) {
     l.episode = take((size_t)n * 4);
     l.serve = take((size_t)n * 3 * 4);
     l.cfg = take(sizeof(ppenv_config));
+    l.hinv = take(4 * sizeof(float));
     l.total = o;
     return l;
 }
@@ -402,6 +424,7 @@ int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 struct ppenv {
     ppenv_config cfg;
     ppenv_config* cfg_dev;   // the same, in device memory (kernels read it with scalar loads)
+    float* hinv_dev;         // calc_heading_quat_inv(humanoid_root_quat), computed once by init_kernel
     DevBuffers buf;
     Layout lay;
     void* arena;
@@ -460,11 +483,12 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
                         (float*)(a + l.dof_pos), (float*)(a + l.dof_vel), (float*)(a + l.dof_force), (float*)(a + l.ball),
                         (uint32_t*)(a + l.flags), (uint32_t*)(a + l.episode), (float*)(a + l.serve)};
     e->cfg_dev = (ppenv_config*)(a + l.cfg);
+    e->hinv_dev = (float*)(a + l.hinv);
     hipStream_t s = (hipStream_t)stream;
     hipError_t err = hipMemsetAsync(e->arena, 0, l.total, s);
     if (err == hipSuccess) err = hipMemcpyAsync(e->cfg_dev, &e->cfg, sizeof(ppenv_config), hipMemcpyHostToDevice, s);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->cfg_dev, e->buf, 0, 0);
+        hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->cfg_dev, e->hinv_dev, e->buf, 0, 0);
         err = hipGetLastError();
     }
     if (err != hipSuccess) {
@@ -505,8 +529,8 @@ int ppenv_config_of(ppenv* e, ppenv_config* out) {
 int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf,
-                       actions_dev, e->serve_on);
+    hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->hinv_dev,
+                       e->buf, actions_dev, e->serve_on);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
@@ -514,8 +538,8 @@ int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
 int ppenv_reset_all(ppenv* e, void* stream) {
     if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf, 1,
-                       e->serve_on);
+    hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->hinv_dev,
+                       e->buf, 1, e->serve_on);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
@@ -573,6 +597,14 @@ int ppenv_set_serve_override(ppenv* e, const float* serve_dev, int on, void* str
     e->serve_on = on ? 1 : 0;
     return PPENV_OK;
 }
+
+#if defined(PP_STAMP)
+// diagnostic builds only: copy the phase stamps of the last launch to the host
+int ppenv_debug_read_stamps(unsigned long long* dst, size_t count) {
+    if (hipDeviceSynchronize() != hipSuccess) return PPENV_EHIP;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pp_stamp_buf), count * sizeof(unsigned long long)) == hipSuccess ? 0 : PPENV_EHIP;
+}
+#endif
 
 size_t ppenv_state_bytes(ppenv* e) {
     if (!e) return 0;

@@ -29,6 +29,22 @@
 #define PP_HD inline __attribute__((always_inline))
 #endif
 
+// Diagnostic builds only (-DPP_STAMP, tools/gpu_stamps.sh): PP_STAMP_AT(k) records the shader clock of
+// phase boundary k for lane 0 of each wave.  Product builds compile this to nothing.
+#if defined(PP_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+#define PP_STAMP_AT(k)                                                                      \
+    do {                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        unsigned long long t_;                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if (threadIdx.x == 0) pp_stamp_buf[blockIdx.x * 32 + (k)] = t_;                      \
+    } while (0)
+extern __device__ unsigned long long pp_stamp_buf[];
+#else
+#define PP_STAMP_AT(k) do { } while (0)
+#endif
+
 namespace pp {
 
 constexpr int ND = PPENV_NUM_DOF;
@@ -54,7 +70,7 @@ PP_HD void sincos_joint(float q, float& s, float& c) {
 //               the arm model out of the substep loop and holding them live (that spilled >1000
 //               SGPRs); each block of constants is fetched right where it is used instead.
 //   ldu(field): plain scalar read the optimiser may hoist and CSE (the few dozen hot scalars).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PP_CFG_LDS)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define PP_CONST_AS __attribute__((address_space(4)))
 template <class S>
 PP_HD S ldc(const S& f) {
@@ -221,17 +237,22 @@ PP_HD void sincos_small(float x, float& s, float& c) {
 // generate_random_speed_for_ball: TT:296-323 / T3:289-305 / TN:301-328
 PP_HD V3 serve_velocity(const ppenv_config& c, uint32_t gid, uint32_t episode) {
     const float deg = 0.017453292519943295f;
-    float u0 = rng_uniform(c.seed, gid, episode, 0);
-    float u1 = rng_uniform(c.seed, gid, episode, 1);
-    float u2 = rng_uniform(c.seed, gid, episode, 2);
-    float speed = c.serve_speed_lo + (c.serve_speed_hi - c.serve_speed_lo) * u0;
-    float a = (c.serve_tilt_lo_deg + (c.serve_tilt_hi_deg - c.serve_tilt_lo_deg) * u1) * deg;
-    float az = (c.serve_tilt_z_lo_deg + (c.serve_tilt_z_hi_deg - c.serve_tilt_z_lo_deg) * u2) * deg;
+    const uint64_t seed = ldu(c.seed);
+    const int variant = ldu(c.variant);
+    float u0 = rng_uniform(seed, gid, episode, 0);
+    float u1 = rng_uniform(seed, gid, episode, 1);
+    float u2 = rng_uniform(seed, gid, episode, 2);
+    const float s_lo = ldu(c.serve_speed_lo), s_hi = ldu(c.serve_speed_hi);
+    const float t_lo = ldu(c.serve_tilt_lo_deg), t_hi = ldu(c.serve_tilt_hi_deg);
+    const float z_lo = ldu(c.serve_tilt_z_lo_deg), z_hi = ldu(c.serve_tilt_z_hi_deg);
+    float speed = s_lo + (s_hi - s_lo) * u0;
+    float a = (t_lo + (t_hi - t_lo) * u1) * deg;
+    float az = (z_lo + (z_hi - z_lo) * u2) * deg;
     float sa, ca, sz, cz;
     sincos_small(a, sa, ca);
     sincos_small(az, sz, cz);
-    if (c.variant == PPENV_VARIANT_T3) return mk(-speed * ca, -speed * sa, 0.f);                 // T3:296-300
-    if (c.variant == PPENV_VARIANT_TT) return mk(-speed * ca * cz, -speed * sa * sz, -speed * sa); // TT:307-318 (sic)
+    if (variant == PPENV_VARIANT_T3) return mk(-speed * ca, -speed * sa, 0.f);                 // T3:296-300
+    if (variant == PPENV_VARIANT_TT) return mk(-speed * ca * cz, -speed * sa * sz, -speed * sa); // TT:307-318 (sic)
     return mk(-speed * ca * cz, speed * sa * cz, speed * sz);                                     // TN:312-323
 }
 
@@ -600,6 +621,24 @@ PP_HD void ball_substep(const ppenv_config& cfg_in, Ball& b, const ArmGeom<T::kS
     const V3 bc = ldu(*reinterpret_cast<const V3*>(cfg.humanoid_bound_center));
     const float br = ldu(cfg.humanoid_bound_radius);
     const ppenv_box table = ldu(cfg.table), net = ldu(cfg.net);
+    // broad-phase spheres of the humanoid shapes for this substep
+    const ModelPaddle P = T::paddle();
+    const float pad_e = ldu(cfg.paddle_restitution), pad_mu = ldu(cfg.paddle_friction);
+    const V3 pdc = g1.pc - g0.pc;
+    const float reach = k.r + k.contact_offset + 1e-4f;
+    const float pad_rr = sqrtf(P.radius * P.radius + P.half_thickness * P.half_thickness) + reach;
+    const float pad_r2 = pad_rr * pad_rr;
+    V3 sc0[T::kShapes], sdc[T::kShapes];
+    float sr2[T::kShapes];
+#pragma unroll
+    for (int s = 0; s < T::kShapes; s++) {
+        V3 c0 = (g0.a[s] + g0.b[s]) * 0.5f;
+        sc0[s] = c0;
+        sdc[s] = T::shape_link(s) < 0 ? mk(0, 0, 0) : (g1.a[s] + g1.b[s]) * 0.5f - c0;
+        V3 hl = (g0.b[s] - g0.a[s]) * 0.5f;   // rigid shape: the half length is the same at both ends of the substep
+        float rr = sqrtf(dot(hl, hl)) + T::shape(s).radius + reach;
+        sr2[s] = rr * rr;
+    }
     for (int m = 0; m < M; m++) {
         float f = (float)m * inv_m;
         b.v.z += gdv;
@@ -608,21 +647,33 @@ PP_HD void ball_substep(const ppenv_config& cfg_in, Ball& b, const ArmGeom<T::kS
         contact_box(k, b, table);
         contact_box(k, b, net);
         V3 db = b.p - bc;
+#if defined(PP_ABLATE) && PP_ABLATE == 1   // profiling build: no humanoid shapes
+        if (false) {
+#else
         if (dot(db, db) < br * br) {
-            V3 cc = lerp(g0.pc, g1.pc, f);
-            V3 nn = lerp(g0.pn, g1.pn, f);
-            nn = nn * rsq_fast(dot(nn, nn));
-            const ModelPaddle P = T::paddle();
-            contact_disc(k, b, cc, nn, (g1.pc - g0.pc) * inv_h, (g1.pn - g0.pn) * inv_h, P.radius, P.half_thickness,
-                         ldu(cfg.paddle_restitution), ldu(cfg.paddle_friction));
+#endif
+            // Broad phase: one bounding sphere per shape (centre moves linearly over the substep).  The
+            // narrow phase behind it is unchanged, and a ball outside the sphere cannot touch the shape,
+            // so results are identical; but some lane of a wave is nearly always near the arm, and the
+            // wave then pays ~10 instructions per shape instead of the full closest-point code.
+            V3 dpc = b.p - madd(g0.pc, pdc, f);
+            if (dot(dpc, dpc) < pad_r2) {
+                V3 nn = lerp(g0.pn, g1.pn, f);
+                nn = nn * rsq_fast(dot(nn, nn));
+                contact_disc(k, b, madd(g0.pc, pdc, f), nn, pdc * inv_h, (g1.pn - g0.pn) * inv_h, P.radius, P.half_thickness,
+                             pad_e, pad_mu);
+            }
 #pragma unroll
             for (int s = 0; s < T::kShapes; s++) {
-                const float radius = T::shape(s).radius, e = ldu(cfg.shape[s].restitution), mu = ldu(cfg.shape[s].friction);
-                if (T::shape_link(s) < 0)
-                    contact_capsule(k, b, g0.a[s], g0.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
-                else
-                    contact_capsule(k, b, lerp(g0.a[s], g1.a[s], f), lerp(g0.b[s], g1.b[s], f), (g1.a[s] - g0.a[s]) * inv_h,
-                                    (g1.b[s] - g0.b[s]) * inv_h, radius, e, mu);
+                V3 dsc = b.p - madd(sc0[s], sdc[s], f);
+                if (dot(dsc, dsc) < sr2[s]) {
+                    const float radius = T::shape(s).radius, e = ldu(cfg.shape[s].restitution), mu = ldu(cfg.shape[s].friction);
+                    if (T::shape_link(s) < 0)
+                        contact_capsule(k, b, g0.a[s], g0.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
+                    else
+                        contact_capsule(k, b, lerp(g0.a[s], g1.a[s], f), lerp(g0.b[s], g1.b[s], f), (g1.a[s] - g0.a[s]) * inv_h,
+                                        (g1.b[s] - g0.b[s]) * inv_h, radius, e, mu);
+                }
             }
         }
         b.p = madd(b.p, b.v, hb);
@@ -673,12 +724,13 @@ struct RewardIn {
 // compute_pingpong_reward_only_paddle TN:1115-1322.  flags is read-modify-write.
 PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& flags, long long& reset) {
     const float Bx = in.bp.x, By = in.bp.y, Bz = in.bp.z, vx = in.vx, pre_vx = in.pre_vx;
-    const float alpha = c.alpha_velocity_reward, penalty = c.penalty, threshold = 0.1f;
-    const float power_reward = -c.power_coefficient * in.power;
+    const float alpha = ldu(c.alpha_velocity_reward), penalty = ldu(c.penalty), threshold = 0.1f;
+    const float power_reward = -ldu(c.power_coefficient) * in.power;
+    const int variant = ldu(c.variant);
     uint32_t f = flags;
     float reward;
     long long die = 0;
-    if (c.variant == PPENV_VARIANT_T3) {
+    if (variant == PPENV_VARIANT_T3) {
         V3 dp = in.paddle - in.bp;
         float dist = sqrtf(dp.x * dp.x + dp.y * dp.y + dp.z * dp.z);
         float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                                 // T3:1117
@@ -687,7 +739,7 @@ PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& 
         bool missed = Bx < in.paddle.x - 1e-3f;                                                 // T3:1146
         if (missed) { reward = reward + penalty; die = 1; }                                     // T3:1149,1158
         if (Bz < threshold) die = 1;                                                            // T3:1161
-    } else if (c.variant == PPENV_VARIANT_TT) {
+    } else if (variant == PPENV_VARIANT_TT) {
         V3 dp = in.paddle - in.bp;
         float dist = sqrtf(dp.x * dp.x + dp.y * dp.y + dp.z * dp.z);                            // TT:1144-1146
         float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                                  // TT:1147
@@ -699,13 +751,13 @@ PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& 
         bool bounce = Bz < 0.83f && vx > 0.f && By < 0.6f && By > -0.6f;                        // TT:1184
         float hit = 0.f;
         bool early = Bx < 2.44f && bounce;
-        if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.not_hit_table_penalty;              // TT:1187-1191
+        if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = ldu(c.not_hit_table_penalty);              // TT:1187-1191
         if (early) { f |= PPENV_FLAG_REWARD_CALC; f &= ~PPENV_FLAG_NO_BOUNCE; }                 // TT:1192,1196
         bool inx = Bx > 2.44f && Bx < 3.1f;                                                     // TT:1199
         bool good = inx && bounce && (f & PPENV_FLAG_NO_BOUNCE);
-        if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.hit_table_reward;                    // TT:1201-1205
+        if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = ldu(c.hit_table_reward);                    // TT:1201-1205
         if (good) f |= PPENV_FLAG_REWARD_CALC;                                                  // TT:1206
-        if (Bx >= 3.1f && vx > 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.not_hit_table_penalty;   // TT:1209-1213
+        if (Bx >= 3.1f && vx > 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = ldu(c.not_hit_table_penalty);   // TT:1209-1213
         if (Bx >= 3.1f) f |= PPENV_FLAG_REWARD_CALC;                                            // TT:1214 (no vx guard)
         float net = (Bx > 1.7f && Bx < 1.8f && vx > 0.f && By < 0.4f && By > -0.4f && Bz > 0.98f && Bz < 1.14f) ? 400.f : 0.f;  // TT:1226-1244
         reward += (((pos_reward + power_reward) + vel_reward) + hit) + net;                     // TT:1251
@@ -725,7 +777,7 @@ PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& 
         if (Bz < threshold) reward = -800.f + reward;                                           // TN:1313-1315
     }
     flags = f;
-    reset = (in.progress >= (long long)c.max_episode_length - 1) ? 1 : die;                     // TT:1265
+    reset = (in.progress >= (long long)ldu(c.max_episode_length) - 1) ? 1 : die;                     // TT:1265
     return reward;
 }
 
@@ -760,8 +812,10 @@ PP_HD void simulate_env(const ppenv_config& cfg, const float* actions, EnvState&
         GeomVisitor<T> gv(cfg, g0);
         fk_sweep<T>(cfg, st.q, st.qd, js, gv);
     }
+    PP_STAMP_AT(2);
     for (int s = 0; s < substeps; s++) {
         arm_substep<T>(cfg, js, st.q, st.qd, target, h, st.dof_force);
+        PP_STAMP_AT(3 + 3 * s);
         if (s + 1 < substeps) {
             GeomVisitor<T> gv(cfg, g1);
             fk_sweep<T>(cfg, st.q, st.qd, js, gv);
@@ -769,7 +823,9 @@ PP_HD void simulate_env(const ppenv_config& cfg, const float* actions, EnvState&
             BodyVisitor<T, false> bv(cfg, g1, bodies);
             fk_sweep<T>(cfg, st.q, st.qd, js, bv);
         }
+        PP_STAMP_AT(4 + 3 * s);
         ball_substep<T>(cfg, st.ball, g0, g1, h);
+        PP_STAMP_AT(5 + 3 * s);
         g0 = g1;
     }
     static_body<false>(cfg, bodies[0]);
@@ -787,24 +843,24 @@ PP_HD void bodies_of_state(const ppenv_config& cfg, const float* q, const float*
 
 // initial simulation state of an env with the serve of `episode` (TT:853-867)
 PP_HD void reset_state(const ppenv_config& cfg, EnvState& st, V3 serve, bool reset_dofs) {
-    st.ball.p = ld3(cfg.ball_init_pos);
+    st.ball.p = ldu(*reinterpret_cast<const V3*>(cfg.ball_init_pos));
 #pragma unroll
-    for (int k = 0; k < 4; k++) st.ball.quat[k] = cfg.ball_init_quat[k];
+    for (int k = 0; k < 4; k++) st.ball.quat[k] = ldu(cfg.ball_init_quat[k]);
     st.ball.v = serve;
     st.ball.w = mk(0, 0, 0);
     if (reset_dofs) {
 #pragma unroll
-        for (int d = 0; d < ND; d++) { st.q[d] = cfg.init_dof_pos[d]; st.qd[d] = cfg.init_dof_vel[d]; }
+        for (int d = 0; d < ND; d++) { st.q[d] = ldu(cfg.init_dof_pos[d]); st.qd[d] = ldu(cfg.init_dof_vel[d]); }
     }
 }
 
 // Observation row: TT:770-799 -> compute_humanoid_observations TT:1669-1708 +
 // compute_pingpong_observations TT:1640-1666.  `obs` is indexed obs[k * stride].
+// `hinv` = calc_heading_quat_inv(root_rot) (TT:1684).  The fused path passes the value computed once
+// at create time (the pelvis is fixed); tensor-API mode computes it per env from the caller's tensor.
 template <class Store>
-PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float root_quat[4], const float* q, const float* qd,
+PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float hinv[4], const float* q, const float* qd,
                      V3 ball_p, V3 ball_v, Store& store) {
-    float hinv[4];
-    heading_quat_inv(root_quat, hinv);
     V3 root = body_pos[0];
 #pragma unroll
     for (int j = 0; j < NB; j++) {
@@ -827,11 +883,11 @@ PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float root_qu
 // post_physics_step for one env of the fused path (TT:1022-1039): progress, reward,
 // masked reset, observations.  serve_override: used instead of the RNG when non-null.
 template <class Store>
-PP_HD void post_physics_env(const ppenv_config& cfg, uint32_t gid, EnvState& st, const BodyState* bodies, float pre_vx,
-                            const V3* serve_override, float& rew, long long& reset, Store& store) {
+PP_HD void post_physics_env(const ppenv_config& cfg, const float* hinv_dev, uint32_t gid, EnvState& st, const BodyState* bodies,
+                            float pre_vx, const V3* serve_override, float& rew, long long& reset, Store& store) {
     st.progress += 1;                                                            // TT:1023
     RewardIn in;
-    in.humanoid_x = cfg.humanoid_root_pos[0];
+    in.humanoid_x = ldu(cfg.humanoid_root_pos[0]);
     in.paddle = bodies[NB - 1].pos;
     in.pre_vx = pre_vx;
     in.bp = st.ball.p;
@@ -845,7 +901,7 @@ PP_HD void post_physics_env(const ppenv_config& cfg, uint32_t gid, EnvState& st,
     if (reset) {                                                                 // TT:1034-1036 -> 847-906
         st.episode += 1;
         V3 serve = serve_override ? *serve_override : serve_velocity(cfg, gid, st.episode);
-        reset_state(cfg, st, serve, cfg.variant != PPENV_VARIANT_TN);            // TN:888-901 keeps the dof state
+        reset_state(cfg, st, serve, ldu(cfg.variant) != PPENV_VARIANT_TN);            // TN:888-901 keeps the dof state
         st.progress = 0;                                                         // TT:902
         st.flags = PPENV_FLAG_NO_BOUNCE;                                         // TT:903-905
     }
@@ -853,7 +909,10 @@ PP_HD void post_physics_env(const ppenv_config& cfg, uint32_t gid, EnvState& st,
     V3 bpos[NB], bvel[NB];
 #pragma unroll
     for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
-    write_obs(bpos, bvel, cfg.humanoid_root_quat, st.q, st.qd, st.ball.p, st.ball.v, store);
+    float hinv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) hinv[k] = ldu(hinv_dev[k]);
+    write_obs(bpos, bvel, hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
 }
 
 }  // namespace pp

@@ -62,7 +62,9 @@ void shim_step(const ppenv_config* cfg, const float* actions /*[N,7]*/, float* d
         RowStore rs{&obs[(size_t)i * PPENV_NUM_OBS]};
         float r;
         long long rst;
-        post_physics_env(*cfg, (uint32_t)(cfg->env_id_offset + i), st, bodies, pre_vx, ovp, r, rst, rs);
+        float hinv[4];
+        heading_quat_inv(cfg->humanoid_root_quat, hinv);
+        post_physics_env(*cfg, hinv, (uint32_t)(cfg->env_id_offset + i), st, bodies, pre_vx, ovp, r, rst, rs);
         rew[i] = r; reset[i] = rst;
         store_state(n, i, dof_pos, dof_vel, dof_force, ball, progress, flags, episode, st);
     }
