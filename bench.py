@@ -70,6 +70,7 @@ def main():
 
     import torch
     from isaacgym_amd import _lib, scene
+    from isaacgym_amd import distributed as D
     from isaacgym_amd.env import PPEnv
 
     _lib.lib()   # fail loudly when the HIP extension is missing
@@ -90,18 +91,15 @@ def main():
     torch.cuda.set_device(device)
 
     n = args.num_envs
-    env = PPEnv(scene.build_config(VARIANT, num_envs=n, seed=0, device_id=local_rank, env_id_offset=rank * n), device=device)
+    off, cnt = D.shard_range(n * world, rank, world)   # contiguous global env ids; trajectories do not depend on the split
+    env = PPEnv(scene.build_config(VARIANT, num_envs=cnt, seed=0, device_id=local_rank, env_id_offset=off), device=device)
     gen = torch.Generator(device=device).manual_seed(rank)
     pool = [(torch.rand(n, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
-    stats = torch.zeros(3, device=device, dtype=torch.float64)
+    stats = [torch.zeros(3, device=device, dtype=torch.float64)]
 
     def horizon_stats():
-        # what the reference prints every 40 steps (TT:763-766) + finished episodes; 3 scalars over RCCL
-        stats[0] = env.rew_buf.mean()
-        stats[1] = env.progress_buf.float().mean()
-        stats[2] = env.episode.sum()
-        if dist is not None:
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        # what the reference prints every 40 steps (TT:763-766) + finished episodes: one small all-reduce over RCCL
+        stats[0] = D.horizon_stats(env.rew_buf, env.progress_buf, env.episode)
 
     def run(k):
         for s in range(k):
@@ -131,7 +129,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     horizon_stats()
-    final_stats = stats.cpu().tolist()
+    final_stats = stats[0].cpu().tolist()
 
     if rank == 0:
         total_env_steps = n * world * args.steps
@@ -158,7 +156,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "step_kernel<TopoG1>", "avg_kernel_us": kernel_us,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n},
-            "episode_stats": {"mean_reward_last_step": final_stats[0] / world, "mean_progress": final_stats[1] / world,
+            "episode_stats": {"mean_reward_last_step": final_stats[0], "mean_progress": final_stats[1],
                               "episodes_finished": final_stats[2]},
         }
         if not args.no_cpu_baseline and world == 1:

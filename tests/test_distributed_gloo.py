@@ -1,0 +1,81 @@
+"""The N>1 path on CPU: world_size-2 gloo processes, each owning an env shard (stepped by the CPU oracle here,
+since no GPU exists in this container), exchanging only what isaacgym_amd.distributed exchanges."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_GLOBAL, STEPS, SEED = 101, 60, 5     # 101: ragged split (51 + 50)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _actions(step):
+    return np.random.default_rng(1000 + step).uniform(-1, 1, (N_GLOBAL, 7)).astype(np.float32)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from isaacgym_amd import distributed as D
+    from isaacgym_amd import scene
+    from oracle import binding as ob
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert D.rank_info() == (rank, rank, world)
+    off, cnt = D.shard_range(N_GLOBAL, rank, world)
+    env = ob.OracleEnv(scene.build_config("TT", num_envs=cnt, seed=SEED, env_id_offset=off))
+    stats = []
+    for t in range(STEPS):
+        env.step(_actions(t)[off:off + cnt])
+        if (t + 1) % 20 == 0:
+            stats.append(D.horizon_stats(torch.from_numpy(env.rew_buf.copy()), torch.from_numpy(env.progress_buf.copy()),
+                                         torch.from_numpy(env.episode.astype(np.int64))).numpy())
+    obs = D.gather_rollout(torch.from_numpy(env.obs_buf.copy()))
+    rew = D.gather_rollout(torch.from_numpy(env.rew_buf.copy()))
+    reset = D.gather_rollout(torch.from_numpy(env.reset_buf.copy()))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "gathered.npz"), obs=obs.numpy(), rew=rew.numpy(), reset=reset.numpy(), stats=np.stack(stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_reproduces_the_single_process_run(oracle_lib, tmp_path):
+    from isaacgym_amd import distributed as D
+    from isaacgym_amd import scene
+    assert D.shard_range(101, 0, 2) == (0, 51) and D.shard_range(101, 1, 2) == (51, 50)
+    assert sum(D.shard_range(65536, r, 8)[1] for r in range(8)) == 65536 and D.shard_range(65536, 3, 8) == (3 * 8192, 8192)
+    with pytest.raises(ValueError):
+        D.shard_range(10, 2, 2)
+    oracle_lib.build()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "gathered.npz")
+    # single process, all envs in one handle
+    env = oracle_lib.OracleEnv(scene.build_config("TT", num_envs=N_GLOBAL, seed=SEED))
+    stats = []
+    for t in range(STEPS):
+        env.step(_actions(t))
+        if (t + 1) % 20 == 0:
+            stats.append([env.rew_buf.astype(np.float64).mean(), env.progress_buf.astype(np.float64).mean(), float(env.episode.sum())])
+    np.testing.assert_array_equal(got["obs"], env.obs_buf)       # env i's trajectory does not depend on the sharding
+    np.testing.assert_array_equal(got["rew"], env.rew_buf)
+    np.testing.assert_array_equal(got["reset"], env.reset_buf)
+    np.testing.assert_allclose(got["stats"], np.array(stats), rtol=1e-12, atol=1e-9)
+    assert got["obs"].shape == (N_GLOBAL, 80)
+
+
+def test_single_process_helpers_are_identity():
+    from isaacgym_amd import distributed as D
+    x = torch.arange(12.0).view(6, 2)
+    assert D.gather_rollout(x) is x
+    s = D.horizon_stats(torch.tensor([1.0, 3.0]), torch.tensor([4, 6]), torch.tensor([2, 5]))
+    assert s.tolist() == [2.0, 5.0, 7.0]
