@@ -59,6 +59,19 @@ def cpu_baseline(num_envs, target_seconds=12.0):
             "sample": f"{steps} steps of the {VARIANT} variant at num_envs={num_envs}, OpenMP over envs, {dt:.1f} s"}
 
 
+def pmc_traffic(num_envs):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).
+    bench.py cannot collect counters itself; null when no profile of this workload size is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        d = json.load(open(f))
+        if d.get("num_envs") == num_envs:
+            best = d["hbm_bytes_per_launch"]
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,13 +141,20 @@ def main():
         t = torch.tensor([wall], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    # roofline: average duration of step_kernel alone — a region of back-to-back launches with nothing else on
+    # the stream, bracketed by HIP events on the stream the kernel is launched on (torch's current stream)
+    kreg = min(args.steps, 500)
+    ev0.record()
+    for s in range(kreg):
+        env.step(pool[s & 7])
+    ev1.record()
+    torch.cuda.synchronize(device)
+    kernel_us = ev0.elapsed_time(ev1) * 1e3 / kreg
     horizon_stats()
     final_stats = stats[0].cpu().tolist()
 
     if rank == 0:
         total_env_steps = n * world * args.steps
-        # the timed region holds K launches of step_kernel back to back on this stream: HIP-event time / K
-        kernel_us = dev_ms * 1e3 / args.steps
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_us * 1e-6) / 1e9
         out = {
             "metric": "env-steps/sec at N_envs=16384 (1/2/4/8 GPUs) + achieved HBM GB/s vs roofline",
@@ -154,7 +174,8 @@ def main():
                        "num_envs_per_gpu": n, "global_envs": n * world, "horizon_stats_every": HORIZON,
                        "parallelism": f"env-shard x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "step_kernel<TopoG1>", "avg_kernel_us": kernel_us,
+                         "traffic": pmc_traffic(n), "kernel": "step_kernel<ModelG1>", "avg_kernel_us": kernel_us,
+                         "timed_region_us_per_step": dev_ms * 1e3 / args.steps,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n},
             "episode_stats": {"mean_reward_last_step": final_stats[0], "mean_progress": final_stats[1],
                               "episodes_finished": final_stats[2]},
