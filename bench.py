@@ -112,7 +112,7 @@ def main():
 
     def horizon_stats():
         # what the reference prints every 40 steps (TT:763-766) + finished episodes: one small all-reduce over RCCL
-        stats[0] = D.horizon_stats(env.rew_buf, env.progress_buf, env.episode)
+        stats[0] = D.env_horizon_stats(env)
 
     def run(k):
         for s in range(k):

@@ -233,6 +233,11 @@ int ppenv_step(struct ppenv* env, const float* actions_dev, void* stream);
  * observations (VecTask.reset()). */
 int ppenv_reset_all(struct ppenv* env, void* stream);
 
+/* What the reference prints every 40 steps (mean reward, mean progress: TT:763-766) plus the number of
+ * finished episodes, as sums over this handle's envs: out_dev[4] (f64) = { sum rew_buf, sum progress_buf,
+ * sum episode, num_envs }.  One small reduction launch; the caller all-reduces it across ranks. */
+int ppenv_reduce_stats(struct ppenv* env, double* out_dev, void* stream);
+
 /* ---- Isaac-Gym tensor-API mode --------------------------------------------- */
 
 /* post_physics_step on caller-supplied simulator tensors in the reference's own

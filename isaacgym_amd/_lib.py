@@ -73,6 +73,7 @@ def lib():
     L.ppenv_config_of.argtypes = [vp, cfgp]
     L.ppenv_step.argtypes = [vp, vp, vp]
     L.ppenv_reset_all.argtypes = [vp, vp]
+    L.ppenv_reduce_stats.argtypes = [vp, vp, vp]
     L.ppenv_post_physics_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     for name in ("ppenv_refresh_root_states", "ppenv_refresh_dof_states", "ppenv_refresh_dof_force",
                  "ppenv_refresh_rigid_body_states"):

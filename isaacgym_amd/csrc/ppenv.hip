@@ -12,9 +12,12 @@
 // ~10^4 dependent fp32 VALU operations per env on ~0.6 KB of state.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
+
+using std::min;
 
 #ifndef PP_ABLATE
 #define PP_ABLATE 0
@@ -354,6 +357,29 @@ __global__ __launch_bounds__(kBlock) void refresh_rb_kernel(const ppenv_config* 
     for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
 }
 
+// sums of rew / progress / episode over the envs (ppenv_reduce_stats): wave reduction + one atomic per wave
+__global__ __launch_bounds__(256) void stats_kernel(int n, const float* __restrict__ rew, const long long* __restrict__ progress,
+                                                     const uint32_t* __restrict__ episode, double* out) {
+    double r = 0.0, p = 0.0, e = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        r += (double)rew[i];
+        p += (double)progress[i];
+        e += (double)episode[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off, 64);
+        p += __shfl_down(p, off, 64);
+        e += __shfl_down(e, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], r);
+        atomicAdd(&out[1], p);
+        atomicAdd(&out[2], e);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[3] = (double)n;
+}
+
 // serve override [N,3] row-major -> SoA [3][N]
 __global__ void serve_transpose_kernel(int n, const float* in, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -540,6 +566,17 @@ int ppenv_reset_all(ppenv* e, void* stream) {
     if (int rc = use_device(e)) return rc;
     hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->hinv_dev,
                        e->buf, 1, e->serve_on);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+
+int ppenv_reduce_stats(ppenv* e, double* out_dev, void* stream) {
+    if (!e || !out_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    PP_HIP(hipMemsetAsync(out_dev, 0, 4 * sizeof(double), (hipStream_t)stream));
+    const int blocks = min(256, (e->cfg.num_envs + 255) / 256);
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e->cfg.num_envs, e->buf.rew, e->buf.progress,
+                       e->buf.episode, out_dev);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }

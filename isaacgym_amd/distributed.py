@@ -35,6 +35,14 @@ def rank_info():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def env_horizon_stats(env, group=None):
+    """`horizon_stats` of a native PPEnv: one reduction launch (ppenv_reduce_stats) + one 4-double all-reduce."""
+    s = env.reduce_stats()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    return torch.stack([s[0] / s[3], s[1] / s[3], s[2]])
+
+
 def horizon_stats(rew_buf, progress_buf, episode, group=None):
     """[mean reward, mean progress, finished episodes] over ALL ranks' envs (tensor of 3 float64)."""
     n = torch.tensor(float(rew_buf.numel()), dtype=torch.float64, device=rew_buf.device)

@@ -77,6 +77,13 @@ class PPEnv:
     def reset_all(self):
         _lib.check(self.L.ppenv_reset_all(self.h, self._stream()))
 
+    def reduce_stats(self):
+        """float64[4] on the device: sum rew_buf, sum progress_buf, sum episode, num_envs (one reduction launch)."""
+        if not hasattr(self, "_stats"):
+            self._stats = torch.zeros(4, dtype=torch.float64, device=self.device)
+        _lib.check(self.L.ppenv_reduce_stats(self.h, self._stats.data_ptr(), self._stream()))
+        return self._stats
+
     # ---- Isaac-Gym tensor-API mode
     def post_physics_step(self, rigid_body_states, root_states, dof_states, dof_force, pre_ball_vx):
         for t in (rigid_body_states, root_states, dof_states, dof_force, pre_ball_vx):

@@ -200,6 +200,10 @@ def test_vec_task_surface(torch_cuda):
     assert float(obs0.abs().sum()) > 0
     for _ in range(10):
         obs, rew, reset, extras = task.step(torch.rand(512, 7, device="cuda") * 2 - 1)
+    from isaacgym_amd import distributed as D
+    got = D.env_horizon_stats(task.env).cpu().numpy()
+    want = D.horizon_stats(task.rew_buf, task.progress_buf, task.env.episode).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-9)
     assert obs["obs"].shape == (512, 80) and rew.shape == (512,) and reset.shape == (512,)
     assert "time_outs" in extras
     assert int(task.progress_buf.max()) == 10
