@@ -263,6 +263,63 @@ int ppenv_refresh_dof_force(struct ppenv* env, float* dof_force_dev /* [N,7] */,
  * meaningful; the other humanoid rows are written as the static root pose. */
 int ppenv_refresh_rigid_body_states(struct ppenv* env, float* rb_states_dev /* [N,42,13] */, void* stream);
 
+/* ---- 27-DoF variant (HumanoidPingpongTiltNESSparse27DOF), tensor-API mode only ------------------
+ * tasks/humanoid_pingpong_3_actor_all_dof.py ("TA"): post_physics_step TA:1145-1192 on caller-supplied
+ * simulator tensors — compute_pingpong_reward_nv TA:1440-1690 (+ compute_gradient_penalty TA:1245-1301,
+ * compute_imitation_reward TA:1313-1418), _reset_idx TA:965-1028, compute_observations TA:867-904
+ * (-> TA:1811-1927, 313 values).  The rigid-body step of this variant (free-floating 27-DoF humanoid
+ * with ground contact) is not built yet; this entry is stateless: every buffer is the caller's. */
+#define PPENV_TA_NUM_DOF 27
+#define PPENV_TA_NUM_OBS 313          /* TA:106: 60 + 54 + 7 + 138 + 54 */
+#define PPENV_TA_NUM_BALANCE_BODIES 23 /* bodyStatesIdBalance, HumanoidPingpongTiltNESSparse27DOFG1.yaml:57 */
+/* sticky flags (TA:279-286) and diagnostic "count" flags (TA:289-293), one uint32 per env */
+#define PPENV_TA_FLAG_PADDLE_COND 1u
+#define PPENV_TA_FLAG_HIT_TABLE_CALC 2u
+#define PPENV_TA_FLAG_DIE_PENALTY_CALC 4u
+#define PPENV_TA_FLAG_HUMANOID_DIE_CALC 8u
+#define PPENV_TA_COUNT_CLOSER 16u
+#define PPENV_TA_COUNT_HIT_PADDLE 32u
+#define PPENV_TA_COUNT_CROSS_NET 64u
+#define PPENV_TA_COUNT_HIT_TABLE 128u
+#define PPENV_TA_COUNT_FALL_DOWN 256u
+#define PPENV_TA_COUNT_MASK 0x1F0u
+
+typedef struct ppenv_ta_params {
+    int32_t num_envs;
+    int32_t max_episode_length;              /* 160 */
+    int32_t is_train;                        /* termination_distance 0.32 when set (TA:1407-1413) */
+    int32_t env_id_offset;
+    uint64_t seed;
+    float alpha_velocity_reward;             /* 3000 */
+    float power_coefficient;                 /* 0.002 */
+    float hit_paddle_reward;                 /* 200 */
+    float miss_paddle_penalty_coefficient;   /* -100 */
+    float cross_net_reward;                  /* 1000 */
+    float hit_table_reward;                  /* 3000 */
+    float not_hit_table_penalty;             /* -1000 */
+    float die_penalty;                       /* -3000 */
+    float init_root[PPENV_NUM_ACTORS][7];    /* initial pos3 + quat4 of humanoid, table, ball (TA:578-579,678-680) */
+    float init_dof_pos[PPENV_TA_NUM_DOF];    /* zeros (TA:249-251) */
+    float init_dof_vel[PPENV_TA_NUM_DOF];
+    float serve_speed_lo, serve_speed_hi;            /* 5.0 .. 5.4   (TA:129) */
+    float serve_tilt_lo_deg, serve_tilt_hi_deg;      /* -8 .. 3      (TA:130) */
+    float serve_tilt_z_lo_deg, serve_tilt_z_hi_deg;  /* 14 .. 24     (TA:131) */
+    float ball_y_lo, ball_y_hi, ball_z_lo, ball_z_hi; /* (-0.5, 0.1), (0.96, 1.05)  (TA:133-134) */
+} ppenv_ta_params;
+
+/* One post_physics_step (TA:1145-1192).  Tensors in the reference's layouts, all device pointers:
+ *   rb_states, initial_rb_states [N,42,13]; root_states [N,3,13] and dof_states [N,27,2] are updated in
+ *   place for reset envs (TA:969-983); dof_force [N,27]; pre_ball_vx [N];
+ *   reset_override [N,5] = ball y, z, vx, vy, vz to use at resets instead of the RNG, or NULL;
+ *   flags, episode [N] u32 and progress [N] i64 are read-modify-write; obs [N,313], rew [N], reset [N] i64 out.
+ * As in the reference, the diagnostic count flags of ALL envs are cleared whenever any env resets
+ * (TA:1162-1166); this is the only cross-env effect and is done by a second small launch. */
+int ppenv_ta_post_physics_step(const ppenv_ta_params* params, const float* rb_states_dev, const float* initial_rb_states_dev,
+                               float* root_states_dev, float* dof_states_dev, const float* dof_force_dev,
+                               const float* pre_ball_vx_dev, const float* reset_override_dev, uint32_t* flags_dev,
+                               uint32_t* episode_dev, int64_t* progress_dev, float* obs_dev, float* rew_dev, int64_t* reset_dev,
+                               uint32_t* scratch_any_reset_dev /* 1 word */, void* stream);
+
 /* ---- state I/O (parity tests, checkpoint) ----------------------------------- */
 
 /* Serve velocities to use at the next resets instead of the RNG

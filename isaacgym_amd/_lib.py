@@ -13,8 +13,8 @@ from . import scene
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("PPENV_LIB", os.path.join(_PKG, "lib", "libppenv.so"))   # PPENV_LIB: profiling builds only
-SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip")]
-HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(ROOT, "include", "ppenv.h")]
+SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip"), os.path.join(_PKG, "csrc", "ppenv_ta.hip")]
+HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1.h"), os.path.join(ROOT, "include", "ppenv.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only", "-fPIC", "-shared"]
 
 _lib = None
@@ -79,6 +79,7 @@ def lib():
                  "ppenv_refresh_rigid_body_states"):
         getattr(L, name).argtypes = [vp, vp, vp]
     L.ppenv_set_serve_override.argtypes = [vp, vp, C.c_int, vp]
+    L.ppenv_ta_post_physics_step.argtypes = [C.POINTER(scene.TAParams)] + [vp] * 15
     L.ppenv_state_bytes.restype = sz
     L.ppenv_state_bytes.argtypes = [vp]
     L.ppenv_get_state.argtypes = [vp, vp, sz]

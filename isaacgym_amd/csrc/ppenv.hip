@@ -390,6 +390,9 @@ __global__ void serve_transpose_kernel(int n, const float* in, float* out) {
 // ------------------------------------------------------------------------- host side
 thread_local char g_err[512] = "";
 void set_err(const char* fmt, const char* a = "", const char* b = "") { snprintf(g_err, sizeof g_err, fmt, a, b); }
+}  // namespace
+void ppenv_set_error(const char* msg) { set_err("%s", msg); }   // for the other translation units of the library
+namespace {
 
 #define PP_HIP(call)                                                   \
     do {                                                               \

@@ -105,6 +105,46 @@ class Buffers(C.Structure):
     ]
 
 
+# 27-DoF variant (tensor-API mode only): ppenv_ta_params
+TA_NUM_DOF, TA_NUM_OBS, TA_NUM_BALANCE = 27, 313, 23
+
+
+class TAParams(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32), ("max_episode_length", C.c_int32), ("is_train", C.c_int32), ("env_id_offset", C.c_int32),
+        ("seed", C.c_uint64),
+        ("alpha_velocity_reward", C.c_float), ("power_coefficient", C.c_float), ("hit_paddle_reward", C.c_float),
+        ("miss_paddle_penalty_coefficient", C.c_float), ("cross_net_reward", C.c_float), ("hit_table_reward", C.c_float),
+        ("not_hit_table_penalty", C.c_float), ("die_penalty", C.c_float),
+        ("init_root", (C.c_float * 7) * NUM_ACTORS), ("init_dof_pos", C.c_float * TA_NUM_DOF), ("init_dof_vel", C.c_float * TA_NUM_DOF),
+        ("serve_speed_lo", C.c_float), ("serve_speed_hi", C.c_float), ("serve_tilt_lo_deg", C.c_float), ("serve_tilt_hi_deg", C.c_float),
+        ("serve_tilt_z_lo_deg", C.c_float), ("serve_tilt_z_hi_deg", C.c_float),
+        ("ball_y_lo", C.c_float), ("ball_y_hi", C.c_float), ("ball_z_lo", C.c_float), ("ball_z_hi", C.c_float),
+    ]
+
+
+def build_ta_params(num_envs, env=None, seed=0, env_id_offset=0, is_train=True):
+    """ppenv_ta_params from the HumanoidPingpongTiltNESSparse27DOFG1.yaml keys (defaults = the yaml's resolve_default values)."""
+    e = dict(episodeLength=160, alphaVelocityReward=3000.0, powerCoefficient=0.002, hitTableReward=3000.0, nothitTablePenalty=-1000.0,
+             crossNetRewardFloat=1000.0, diePenaltyFloat=-3000.0, hitPaddleReward=200.0, missPaddlePenaltyCoefficient=-100.0)
+    e.update(env or {})
+    p = TAParams()
+    p.num_envs, p.max_episode_length, p.is_train, p.env_id_offset, p.seed = int(num_envs), int(e["episodeLength"]), int(is_train), int(env_id_offset), int(seed)
+    p.alpha_velocity_reward, p.power_coefficient = e["alphaVelocityReward"], e["powerCoefficient"]
+    p.hit_paddle_reward, p.miss_paddle_penalty_coefficient = e["hitPaddleReward"], e["missPaddlePenaltyCoefficient"]
+    p.cross_net_reward, p.hit_table_reward = e["crossNetRewardFloat"], e["hitTableReward"]
+    p.not_hit_table_penalty, p.die_penalty = e["nothitTablePenalty"], e["diePenaltyFloat"]
+    roots = [(0.0, 0.0, 1.0, 0, 0, 0, 1), (1.75, 0.0, 0.0, 0, 0, 0, 1), (2.9, -0.2, 1.0, 0, 0, 0, 1)]   # TA:578-579,  table, TA:678-680
+    for a in range(NUM_ACTORS):
+        for k in range(7):
+            p.init_root[a][k] = roots[a][k]
+    p.serve_speed_lo, p.serve_speed_hi = 5.0, 5.4                 # TA:129
+    p.serve_tilt_lo_deg, p.serve_tilt_hi_deg = -8.0, 3.0          # TA:130
+    p.serve_tilt_z_lo_deg, p.serve_tilt_z_hi_deg = 14.0, 24.0     # TA:131
+    p.ball_y_lo, p.ball_y_hi, p.ball_z_lo, p.ball_z_hi = -0.5, 0.1, 0.96, 1.05   # TA:133-134
+    return p
+
+
 # ------------------------------------------------------------------ math helpers
 def rpy_to_rot(r, p, y):
     """URDF fixed-axis roll-pitch-yaw -> rotation matrix (parent <- child)."""

@@ -221,3 +221,23 @@ def compute_obs(bodies, dof_pos, dof_vel, ball):
     out = np.zeros(scene.NUM_OBS, np.float32)
     lib().ppo_compute_obs(bodies.ctypes.data, dof_pos.ctypes.data, dof_vel.ctypes.data, ball.ctypes.data, out.ctypes.data)
     return out
+
+
+# ---- 27-DoF variant, tensor-API mode -------------------------------------------------------------
+def ta_post_physics_step(params, rb, irb, root, dof, dof_force, pre_vx, reset_override, flags, episode, progress):
+    """numpy in / numpy out wrapper of ppo_ta_post_physics_step.  root, dof, flags, episode, progress are updated in place."""
+    L = lib()
+    n = params.num_envs
+    obs = np.zeros((n, scene.TA_NUM_OBS), np.float32)
+    rew = np.zeros(n, np.float32)
+    reset = np.zeros(n, np.int64)
+    for a in (rb, irb, root, dof, dof_force, pre_vx):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    ov = None if reset_override is None else np.ascontiguousarray(reset_override, np.float32)
+    L.ppo_ta_post_physics_step.argtypes = [C.POINTER(scene.TAParams)] + [C.c_void_p] * 13
+    L.ppo_ta_post_physics_step.restype = None
+    L.ppo_ta_post_physics_step(C.byref(params), rb.ctypes.data, irb.ctypes.data, root.ctypes.data, dof.ctypes.data,
+                               dof_force.ctypes.data, pre_vx.ctypes.data, ov.ctypes.data if ov is not None else None,
+                               flags.ctypes.data, episode.ctypes.data, progress.ctypes.data, obs.ctypes.data, rew.ctypes.data,
+                               reset.ctypes.data)
+    return obs, rew, reset

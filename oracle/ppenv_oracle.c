@@ -899,3 +899,174 @@ void ppo_serve_velocity(const ppenv_config* c, uint32_t gid, uint32_t episode, f
 void ppo_compute_obs(const float* bodies /* [10][13] */, const float* dof_pos, const float* dof_vel, const float* ball, float* obs) {
     compute_obs((const float(*)[13])bodies, dof_pos, dof_vel, ball, obs);
 }
+
+/* ================================================================================================
+ * 27-DoF variant, tensor-API mode: post_physics_step of tasks/humanoid_pingpong_3_actor_all_dof.py
+ * ("TA") TA:1145-1192 on caller tensors.  fp32 in the reference's operation order.
+ * ================================================================================================ */
+#define TA_ND PPENV_TA_NUM_DOF
+#define TA_NBAL PPENV_TA_NUM_BALANCE_BODIES
+static const int ta_obs_ids[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};          /* bodyStatesIdPingpong, yaml:56 */
+static const int ta_bal_ids[TA_NBAL] = {0, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 27}; /* yaml:57 */
+
+/* compute_imitation_reward TA:1313-1418 with is_g1 = True */
+static float ta_imitation_reward(const ppenv_ta_params* p, const float* rb, const float* irb, const float* dof_pos,
+                                 const float* dof_vel, int* has_fallen) {
+    const float k_pos = 50.f, k_vel = 4.0f, k_dof_pos = 5.0f, k_dof_vel = 0.05f;
+    const float w_pos = 0.4f, w_vel = 0.2f, w_dof_pos = 0.2f, w_dof_vel = 0.2f;
+    float pos_acc = 0.f, vel_acc = 0.f, norm_acc = 0.f;
+    for (int j = 0; j < TA_NBAL; j++) {
+        const float* b = &rb[ta_bal_ids[j] * 13];
+        const float* r = &irb[ta_bal_ids[j] * 13];
+        float dp0 = r[0] - b[0], dp1 = r[1] - b[1], dp2 = r[2] - b[2];
+        float dv0 = r[7] - b[7], dv1 = r[8] - b[8], dv2 = r[9] - b[9];
+        pos_acc += (dp0 * dp0 + dp1 * dp1 + dp2 * dp2) / 3.0f;      /* (diff**2).mean(-1) */
+        vel_acc += (dv0 * dv0 + dv1 * dv1 + dv2 * dv2) / 3.0f;
+        float e0 = b[0] - r[0], e1 = b[1] - r[1], e2 = b[2] - r[2];
+        norm_acc += sqrtf(e0 * e0 + e1 * e1 + e2 * e2);             /* torch.norm(body_pos - ref_body_pos, dim=-1) */
+    }
+    float r_body_pos = expf(-k_pos * (pos_acc / (float)TA_NBAL));    /* TA:1349-1351 */
+    float r_body_vel = expf(-k_vel * (vel_acc / (float)TA_NBAL));    /* TA:1354-1356 */
+    float s22 = 0.f, s5 = 0.f, sv = 0.f;
+    for (int d = 0; d < 22; d++) { float e = p->init_dof_pos[d] - dof_pos[d]; s22 += e * e; }
+    for (int d = 22; d < TA_ND; d++) { float e = p->init_dof_pos[d] - dof_pos[d]; s5 += e * e; }
+    for (int d = 0; d < 22; d++) { float e = p->init_dof_vel[d] - dof_vel[d]; sv += e * e; }
+    float r22 = (w_dof_pos * 50.0f) * expf(-(k_dof_pos * 500.0f) * (s22 / 22.0f));   /* TA:1372-1380 */
+    float r5 = w_dof_pos * expf(-k_dof_pos * (s5 / 5.0f));                             /* TA:1383-1387 */
+    float r_dof_vel = expf(-k_dof_vel * (sv / 22.0f));                                 /* TA:1393,1401 */
+    float ref = r22 + r5 + w_dof_vel * r_dof_vel + w_pos * r_body_pos + w_vel * r_body_vel;   /* TA:1403 */
+    float term = p->is_train ? 0.32f : 1e6f;                                           /* TA:1407-1413 */
+    *has_fallen = (norm_acc / (float)TA_NBAL) > term;                                  /* TA:1415 */
+    if (*has_fallen) ref = 1.0f * -50.0f;                                              /* TA:1416-1417 */
+    return ref;
+}
+
+void ppo_ta_post_physics_step(const ppenv_ta_params* p, const float* rb_states, const float* initial_rb_states,
+                              float* root_states, float* dof_states, const float* dof_force, const float* pre_ball_vx,
+                              const float* reset_override, uint32_t* flags, uint32_t* episode, int64_t* progress,
+                              float* obs, float* rew, int64_t* reset_out) {
+    const int n = p->num_envs;
+    int any_reset = 0;
+    for (int i = 0; i < n; i++) {
+        const float* rb = &rb_states[(size_t)i * PPENV_NUM_BODIES * 13];
+        const float* irb = &initial_rb_states[(size_t)i * PPENV_NUM_BODIES * 13];
+        float* root = &root_states[(size_t)i * PPENV_NUM_ACTORS * 13];
+        float* dofs = &dof_states[(size_t)i * TA_ND * 2];
+        float* ball = &root[2 * 13];
+        float q[TA_ND], qd[TA_ND];
+        for (int d = 0; d < TA_ND; d++) { q[d] = dofs[2 * d]; qd[d] = dofs[2 * d + 1]; }
+        int64_t prog = progress[i] + 1;                                      /* TA:1146 */
+        uint32_t f = flags[i];
+        const int paddle_cond = (f & PPENV_TA_FLAG_PADDLE_COND) != 0, hit_table_calc = (f & PPENV_TA_FLAG_HIT_TABLE_CALC) != 0;
+        const int die_pen_calc = (f & PPENV_TA_FLAG_DIE_PENALTY_CALC) != 0, hum_die = (f & PPENV_TA_FLAG_HUMANOID_DIE_CALC) != 0;
+
+        /* ---- compute_pingpong_reward_nv TA:1440-1690 */
+        const float* paddle = &rb[39 * 13];
+        const float bx = ball[0], by = ball[1], bz = ball[2], vx = ball[7], pvx = pre_ball_vx[i];
+        int has_fallen;
+        float ref_reward = ta_imitation_reward(p, rb, irb, q, qd, &has_fallen);   /* TA:1492 */
+        float pelvis_h = rb[2];                                                   /* humanoid1_pelvis_rb_states[..., 2] */
+        if (has_fallen) f |= PPENV_TA_COUNT_FALL_DOWN;                            /* TA:1525-1529 */
+        int x_close = fabsf(bx - paddle[0]) < 0.2f;                               /* TA:1544 */
+        int first_close = x_close && !paddle_cond;                                /* TA:1545 */
+        float dy = by - paddle[1], dz = bz - paddle[2];
+        float yz = sqrtf(dy * dy + dz * dz);                                      /* TA:1548 */
+        int in_circle = yz < 0.15f;
+        float pos_reward = 0.f;
+        if (first_close && !hum_die) pos_reward = in_circle ? p->hit_paddle_reward : p->miss_paddle_penalty_coefficient * yz;   /* TA:1555-1563 */
+        if (first_close && in_circle) f |= PPENV_TA_COUNT_CLOSER;                 /* TA:1566-1570 */
+        int hit_paddle = pvx < 0.f && vx > 1.5f;                                  /* TA:1577 */
+        if (hit_paddle) f |= PPENV_TA_COUNT_HIT_PADDLE;                           /* TA:1579-1583 */
+        float vel_reward = (hit_paddle && !paddle_cond && !hum_die) ? p->alpha_velocity_reward * fabsf(vx) : 0.f;   /* TA:1586-1590 */
+        if (x_close) f |= PPENV_TA_FLAG_PADDLE_COND;                              /* TA:1595 */
+        float humanoid_x = root[0];
+        float time_penalty = (bx > humanoid_x && vx < 0.f) ? -0.01f * (float)prog : 0.f;   /* TA:1602-1607 */
+        /* compute_gradient_penalty TA:1245-1301 */
+        int z_in = bz >= 0.82f && bz <= 0.83f && vx > 0.f;
+        float ddx = bx - 2.5f, ddy = by - 0.0f;
+        float dist = sqrtf(ddx * ddx + ddy * ddy);
+        int in_range = bx >= 1.9f && bx <= 3.1f && by >= -0.6f && by <= 0.6f;
+        if (z_in && in_range) f |= PPENV_TA_COUNT_HIT_TABLE;
+        float hit_rp = 0.f;
+        if (z_in && !hit_table_calc && !hum_die) hit_rp = in_range ? p->hit_table_reward : p->not_hit_table_penalty * dist;
+        if (z_in) f |= PPENV_TA_FLAG_HIT_TABLE_CALC;
+        /* net TA:1619-1650 */
+        int over_net = bx > 1.72f && bx < 1.78f && vx > 0.f;
+        int suitable = bz > 0.96f && bz < 1.25f;
+        float over_h = 0.f;
+        if (!suitable) over_h = bz > 1.25f ? bz - 1.25f : 0.96f - bz;
+        float net_rp = 0.f;
+        if (over_net && !hum_die) net_rp = suitable ? p->cross_net_reward : -400.f * over_h;
+        if (net_rp > 0.f) f |= PPENV_TA_COUNT_CROSS_NET;                          /* TA:1652-1656 */
+        float power = 0.f;
+        for (int d = 0; d < TA_ND; d++) power += fabsf(dof_force[(size_t)i * TA_ND + d] * qd[d]);
+        float power_reward = -p->power_coefficient * power;                       /* TA:1664-1665 */
+        float die_penalty = (bz < 0.78f && !die_pen_calc && !hum_die) ? p->die_penalty : 0.f;   /* TA:1677-1679 */
+        if (bz < 0.78f) f |= PPENV_TA_FLAG_DIE_PENALTY_CALC;                      /* TA:1681 */
+        if (pelvis_h < 0.97f) f |= PPENV_TA_FLAG_HUMANOID_DIE_CALC;               /* TA:1683 */
+        float reward = 0.f + (((((((pos_reward + power_reward) + vel_reward) + hit_rp) + net_rp) + die_penalty) + time_penalty) + ref_reward);   /* TA:1686 */
+        int64_t rst = (prog >= (int64_t)p->max_episode_length - 1) ? 1 : 0;       /* TA:1688: time-out only */
+
+        /* ---- _reset_idx TA:965-1028 */
+        if (rst) {
+            any_reset = 1;
+            episode[i] += 1;
+            float ov[5];
+            if (reset_override) memcpy(ov, &reset_override[(size_t)i * 5], sizeof ov);
+            else {
+                uint32_t gid = (uint32_t)(p->env_id_offset + i), ep = episode[i];
+                float u[5];
+                for (int k = 0; k < 5; k++) {
+                    uint64_t s = mix64(p->seed + 0x9E3779B97F4A7C15ull * ((uint64_t)gid + 1));
+                    uint64_t x = mix64(s + 0x9E3779B97F4A7C15ull * ((uint64_t)ep * 8 + k + 1));
+                    u[k] = (float)(x >> 40) * (1.0f / 16777216.0f);
+                }
+                ov[0] = p->ball_y_lo + (p->ball_y_hi - p->ball_y_lo) * u[0];      /* draw order TA:976-979: y, z, speed, tilt, tilt_z */
+                ov[1] = p->ball_z_lo + (p->ball_z_hi - p->ball_z_lo) * u[1];
+                double speed = p->serve_speed_lo + (p->serve_speed_hi - p->serve_speed_lo) * u[2];
+                double a = (p->serve_tilt_lo_deg + (p->serve_tilt_hi_deg - p->serve_tilt_lo_deg) * u[3]) * (M_PI / 180.0);
+                double az = (p->serve_tilt_z_lo_deg + (p->serve_tilt_z_hi_deg - p->serve_tilt_z_lo_deg) * u[4]) * (M_PI / 180.0);
+                ov[2] = (float)(-speed * cos(a) * cos(az)); ov[3] = (float)(speed * sin(a) * cos(az)); ov[4] = (float)(speed * sin(az));   /* TA:370-375 */
+            }
+            for (int a = 0; a < 3; a++) {
+                memcpy(&root[a * 13], p->init_root[a], 7 * sizeof(float));
+                memset(&root[a * 13 + 7], 0, 6 * sizeof(float));
+            }
+            ball[1] = ov[0]; ball[2] = ov[1]; ball[7] = ov[2]; ball[8] = ov[3]; ball[9] = ov[4];
+            for (int d = 0; d < TA_ND; d++) { dofs[2 * d] = q[d] = p->init_dof_pos[d]; dofs[2 * d + 1] = qd[d] = p->init_dof_vel[d]; }
+            prog = 0;
+            f &= ~(PPENV_TA_FLAG_PADDLE_COND | PPENV_TA_FLAG_DIE_PENALTY_CALC | PPENV_TA_FLAG_HUMANOID_DIE_CALC | PPENV_TA_FLAG_HIT_TABLE_CALC);   /* TA:1021-1024 */
+        }
+        progress[i] = prog; flags[i] = f; rew[i] = reward; reset_out[i] = rst;
+
+        /* ---- compute_observations TA:867-904 (body states pre-reset, dof / ball post-reset) */
+        float* o = &obs[(size_t)i * PPENV_TA_NUM_OBS];
+        float hinv[4];
+        heading_quat_inv_f(&rb[3], hinv);
+        const float* rootp = &rb[0];
+        for (int j = 0; j < NB; j++) {
+            const float* b = &rb[ta_obs_ids[j] * 13];
+            float rel[3] = {b[0] - rootp[0], b[1] - rootp[1], b[2] - rootp[2]};
+            quat_rotate_f(hinv, rel, &o[3 * j]);
+            quat_rotate_f(hinv, &b[7], &o[30 + 3 * j]);
+        }
+        for (int d = 0; d < TA_ND; d++) { o[60 + d] = q[d]; o[60 + TA_ND + d] = qd[d] * 0.1f; }
+        float lb[3], lv[3];
+        float relb[3] = {ball[0] - rootp[0], ball[1] - rootp[1], ball[2] - rootp[2]};
+        quat_rotate_f(hinv, relb, lb);
+        quat_rotate_f(hinv, &ball[7], lv);
+        o[114] = lb[0]; o[115] = lb[1]; o[116] = lb[2]; o[117] = lv[0]; o[118] = lv[1]; o[119] = lv[2];
+        o[120] = lb[1] + (lv[1] / (-lv[0] + 1e-6f)) * lb[0];                       /* TA:1839 */
+        for (int j = 0; j < TA_NBAL; j++) {                                        /* TA:1891-1927 */
+            const float* b = &rb[ta_bal_ids[j] * 13];
+            const float* r = &irb[ta_bal_ids[j] * 13];
+            float dp[3] = {r[0] - b[0], r[1] - b[1], r[2] - b[2]}, dv[3] = {r[7] - b[7], r[8] - b[8], r[9] - b[9]}, t[3];
+            quat_rotate_f(hinv, dp, t);
+            o[121 + 3 * j] = t[0] * 10.f; o[122 + 3 * j] = t[1] * 10.f; o[123 + 3 * j] = t[2] * 10.f;
+            quat_rotate_f(hinv, dv, &o[121 + 3 * TA_NBAL + 3 * j]);
+        }
+        for (int d = 0; d < TA_ND; d++) { o[121 + 6 * TA_NBAL + d] = p->init_dof_pos[d]; o[121 + 6 * TA_NBAL + TA_ND + d] = p->init_dof_vel[d]; }
+    }
+    if (any_reset)                                                                  /* TA:1162-1166: fill_(0) on ALL envs */
+        for (int i = 0; i < n; i++) flags[i] &= ~PPENV_TA_COUNT_MASK;
+}

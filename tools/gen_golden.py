@@ -287,6 +287,169 @@ def generate(variant, seed):
     return out
 
 
+TA_BAL_IDS = [0, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 27]
+TA_PARAMS = dict(episode_length=14, alpha=3000.0, power_coefficient=0.002, hit_paddle_reward=200.0,
+                 miss_paddle_penalty_coefficient=-100.0, cross_net_reward=1000.0, hit_table_reward=3000.0,
+                 not_hit_table_penalty=-1000.0, die_penalty=-3000.0)   # HumanoidPingpongTiltNESSparse27DOFG1.yaml:15-30
+
+
+def pack_ta_flags(o):
+    f = np.zeros(o.num_envs, dtype=np.uint32)
+    for bit, name in ((1, "paddle_condition_calculated"), (2, "hit_table_calculated"), (4, "die_penalty_calculated"),
+                      (8, "humanoid_die_calculated"), (16, "closer_to_paddle_count"), (32, "hit_paddle_count"),
+                      (64, "cross_net_count"), (128, "hit_table_count"), (256, "fall_down_count")):
+        f |= getattr(o, name).numpy().astype(bool).astype(np.uint32) * bit
+    return f
+
+
+def generate_ta(seed):
+    """27-DoF variant: the reference's own post_physics_step (TA:1145-1192) on scripted [N,42,13] / [N,27,2] tensors."""
+    rng = np.random.default_rng(seed)
+    n, T = 32, 36      # [T,N,42,13] inputs: keep the fixture small
+    mod = ref_loader.load_task("humanoid_pingpong_3_actor_all_dof.py")
+    cls = find_task_class(mod)
+    sys.modules["isaacgym.gymapi"].Vec3 = Vec3
+    mod.gymapi.Vec3 = Vec3
+    o = object.__new__(cls)
+    P = TA_PARAMS
+    o.num_envs, o.device, o.headless, o.randomize = n, "cpu", True, False
+    o.gym, o.sim, o.viewer, o.num_steps = FakeGym(), None, None, 1
+    o.max_episode_length = P["episode_length"]
+    o.alpha, o.power_coefficient = P["alpha"], P["power_coefficient"]
+    o.hit_paddle_reward, o.miss_paddle_penalty_coefficient = P["hit_paddle_reward"], P["miss_paddle_penalty_coefficient"]
+    o.cross_net_reward_float, o.hit_table_reward = P["cross_net_reward"], P["hit_table_reward"]
+    o.not_hit_table_penalty, o.die_penalty_float = P["not_hit_table_penalty"], P["die_penalty"]
+    o.is_g1, o.is_train = True, True
+    o.initial_speed_range, o.tilt_angle_range, o.tilt_z_angle_range = (5.0, 5.4), (-8.0, 3.0), (14.0, 24.0)   # TA:129-131
+    o.initial_pos_y_range, o.initial_pos_z_range = (-0.5, 0.1), (0.96, 1.05)                                   # TA:133-134
+    o.actors_per_env, o.dofs_per_env = 3, 27
+    o.progress_buf = torch.zeros(n, dtype=torch.long)
+    o.randomize_buf = torch.zeros(n, dtype=torch.long)
+    o.reset_buf = torch.ones(n, dtype=torch.long)
+    o.reset_buf_force = torch.zeros(n, dtype=torch.long)
+    o.rew_buf, o.obs_buf, o.actions = torch.zeros(n), torch.zeros(n, 313), torch.zeros(n, 27)
+    init_root = np.zeros((3, 13), np.float32)
+    init_root[0, 0:3], init_root[0, 6] = (0.0, 0.0, 1.0), 1.0          # TA:578-579
+    init_root[1, 0:3], init_root[1, 6] = (1.75, 0.0, 0.0), 1.0
+    init_root[2, 0:3], init_root[2, 6] = (2.9, -0.2, 1.0), 1.0         # TA:678-680 (y, z are re-drawn at every reset)
+    o.root_states = torch.from_numpy(init_root).repeat(n, 1).clone()
+    o.vec_root_states = o.root_states.view(n, 3, 13)
+    o.initial_vec_root_states = o.vec_root_states.clone()
+    o.initial_pos, o.initial_rot = o.initial_vec_root_states[:, :, 0:3], o.initial_vec_root_states[:, :, 3:7]
+    o.humanoid1_root_states, o.ball2_root_states = o.vec_root_states[:, 0, :], o.vec_root_states[:, 2, :]
+    o.pre_ball2_root_states = o.ball2_root_states.clone()
+    o.rb_states = torch.zeros(n * 42, 13)
+    o.body_states = o.rb_states.view(n, 42, 13)
+    o.vec_rb_states = o.body_states
+    o.humanoid1_paddle_rb_states = o.vec_rb_states[:, 39, :]
+    o.humanoid1_pelvis_rb_states = o.vec_rb_states[:, 0, :]
+    o.body_states_id = torch.tensor(BODY_IDS, dtype=torch.long)              # bodyStatesIdPingpong, yaml:56
+    o.body_balance_states_id = torch.tensor(TA_BAL_IDS, dtype=torch.long)    # bodyStatesIdBalance, yaml:57
+    # a standing pose: the initial body states every later state is compared with (TA:200)
+    init_bodies = np.zeros((n, 42, 13), np.float32)
+    init_bodies[:, :, 0:3] = rng.uniform([-0.15, -0.25, 0.05], [0.15, 0.25, 1.35], (1, 42, 3))
+    init_bodies[:, 0, 0:3] = (0.0, 0.0, 1.0)
+    init_bodies[:, :, 6] = 1.0
+    o.initial_body_states = torch.from_numpy(init_bodies.copy())
+    o.dof_states = torch.zeros(n * 27, 2)
+    o.vec_dof_states = o.dof_states.view(n, 27, 2)
+    o.dof_pos, o.dof_vel = o.vec_dof_states[..., 0], o.vec_dof_states[..., 1]
+    o.initial_dof_states = o.vec_dof_states.clone()
+    o.initial_dof_pos, o.initial_dof_vel = o.initial_dof_states[..., 0], o.initial_dof_states[..., 1]
+    o.dof_force_tensor = torch.zeros(n, 27)
+    o.actor_indices = torch.arange(n * 3, dtype=torch.long)
+    o.dof_indices = torch.arange(n, dtype=torch.long)
+    for name in ("paddle_condition_calculated", "die_penalty_calculated", "humanoid_die_calculated", "hit_table_calculated",
+                 "closer_to_paddle_count", "hit_paddle_count", "cross_net_count", "hit_table_count", "fall_down_count"):
+        setattr(o, name, torch.zeros(n, dtype=torch.bool))
+
+    pelvis_q = random_unit_quats(rng, n)
+    pelvis_q[: n // 2] = yaw_quats(rng.uniform(-0.4, 0.4, n // 2))
+    ball = o.vec_root_states[:, 2, :].numpy().copy()
+    ball[:, 7:10] = rng.uniform([-6, -0.5, 1], [-4, 0.5, 2.5], (n, 3))
+    kin = np.arange(n) < n // 2
+    dt = 0.0083 * 4.0
+    dof = np.zeros((n, 27, 2), np.float32)
+    keys = ["in_bodies42", "in_root", "in_dof", "in_dof_force", "in_pre_vx", "reset_override", "out_rew", "out_reset", "out_obs",
+            "out_progress", "out_flags", "out_root", "out_dof"]
+    rec = {k: [] for k in keys}
+    random.seed(seed)
+    for t in range(T):
+        pre_vx = ball[:, 7].copy()
+        nb = ball.copy()
+        nb[kin, 9] -= 9.8 * dt
+        nb[kin, 0:3] += nb[kin, 7:10] * dt
+        on_table = kin & (nb[:, 2] < 0.78) & (nb[:, 9] < 0) & (nb[:, 0] > 0.38) & (nb[:, 0] < 3.12)
+        nb[on_table, 2] = 0.78 + (0.78 - nb[on_table, 2])
+        nb[on_table, 9] *= -0.9
+        at_paddle = kin & (nb[:, 0] < 0.45) & (nb[:, 7] < 0) & (rng.uniform(size=n) < 0.7)
+        nb[at_paddle, 7] = rng.uniform(0.5, 7.0, at_paddle.sum())
+        nb[at_paddle, 9] = rng.uniform(0.5, 3.5, at_paddle.sum())
+        iid = ~kin
+        nb[iid, 0:3] = rng.uniform([-0.4, -0.9, 0.5], [3.5, 0.9, 1.5], (iid.sum(), 3))
+        nb[iid, 7:10] = rng.uniform([-6, -2, -4], [6, 2, 4], (iid.sum(), 3))
+        pick = iid & (rng.uniform(size=n) < 0.25)      # net window 1.72 < x < 1.78
+        nb[pick, 0] = rng.uniform(1.70, 1.80, pick.sum())
+        nb[pick, 2] = rng.uniform(0.90, 1.32, pick.sum())
+        pick = iid & (rng.uniform(size=n) < 0.25)      # landing window 0.82 <= z <= 0.83 (TA:1263)
+        nb[pick, 2] = rng.uniform(0.815, 0.835, pick.sum())
+        pick = iid & (rng.uniform(size=n) < 0.15)      # ball dropped below 0.78 (TA:1479)
+        nb[pick, 2] = rng.uniform(0.5, 0.79, pick.sum())
+        nb[:, 10:13] = rng.uniform(-20, 20, (n, 3))
+        ball = nb.astype(np.float32)
+        dof[:, :, 1] = rng.normal(0, 1.0, (n, 27))
+        dof[:, :, 0] = np.clip(dof[:, :, 0] * 0.8 + rng.normal(0, 0.02, (n, 27)), -1.5, 1.5)
+        dof_force = rng.uniform(-25, 25, (n, 27)).astype(np.float32)
+        bodies = init_bodies.copy()
+        bodies[:, :, 0:3] += rng.normal(0, 0.03, (n, 42, 3))          # small sway around the standing pose
+        fallen = rng.uniform(size=n) < 0.08                             # some envs far from it (has_fallen, TA:1415)
+        bodies[fallen, :, 0:3] += rng.normal(0, 0.4, (fallen.sum(), 42, 3))
+        low = rng.uniform(size=n) < 0.1                                 # pelvis below 0.97 (TA:1683)
+        bodies[low, 0, 2] = rng.uniform(0.7, 0.969, low.sum())
+        bodies[:, :, 3:7] = random_unit_quats(rng, n * 42).reshape(n, 42, 4)
+        bodies[:, 0, 3:7] = pelvis_q
+        bodies[:, :, 7:13] = rng.normal(0, 0.5, (n, 42, 6))
+        bodies[:, 39, 0:3] = rng.uniform([0.1, -0.6, 0.8], [0.6, 0.2, 1.4], (n, 3))
+        near = rng.uniform(size=n) < 0.4
+        bodies[near, 39, 0:3] = ball[near, 0:3] + rng.normal(0, 0.08, (near.sum(), 3))
+        bodies = bodies.astype(np.float32)
+
+        o.body_states[:] = torch.from_numpy(bodies)
+        o.vec_root_states[:, 2, :] = torch.from_numpy(ball)
+        o.vec_dof_states[:] = torch.from_numpy(dof)
+        o.dof_force_tensor[:] = torch.from_numpy(dof_force)
+        o.pre_ball2_root_states = o.ball2_root_states.clone()
+        o.pre_ball2_root_states[:, 7] = torch.from_numpy(pre_vx)
+        rec["in_bodies42"].append(bodies.copy())
+        rec["in_root"].append(o.vec_root_states.numpy().copy())
+        rec["in_dof"].append(dof.copy())
+        rec["in_dof_force"].append(dof_force.copy())
+        rec["in_pre_vx"].append(pre_vx.astype(np.float32))
+        with contextlib.redirect_stdout(io.StringIO()):
+            o.post_physics_step()
+        out_root = o.vec_root_states.numpy().copy()
+        ov = np.full((n, 5), np.nan, np.float32)
+        ids = np.nonzero(o.reset_buf.numpy())[0]
+        ov[ids, 0:2] = out_root[ids, 2, 1:3]       # the y, z the reference drew (TA:976-979)
+        ov[ids, 2:5] = out_root[ids, 2, 7:10]      # and its serve velocity
+        rec["reset_override"].append(ov)
+        rec["out_rew"].append(o.rew_buf.numpy().copy())
+        rec["out_reset"].append(o.reset_buf.numpy().copy())
+        rec["out_obs"].append(o.obs_buf.numpy().copy())
+        rec["out_progress"].append(o.progress_buf.numpy().copy())
+        rec["out_flags"].append(pack_ta_flags(o))
+        rec["out_root"].append(out_root)
+        rec["out_dof"].append(o.vec_dof_states.numpy().copy())
+        ball = out_root[:, 2, :].copy()
+        dof = o.vec_dof_states.numpy().copy()
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out["initial_bodies42"] = init_bodies[0]          # identical for every env
+    out["init_root"] = init_root
+    out.update({k: np.array(v, np.float32 if isinstance(v, float) else np.int64) for k, v in P.items()})
+    out["seed"] = np.array(seed)
+    return out
+
+
 def branch_report(variant, g):
     rew, reset, fl = g["out_rew"], g["out_reset"], g["out_flags"]
     print(f"[{variant}] steps x envs = {rew.shape}, resets {int(reset.sum())}, "
@@ -303,6 +466,12 @@ def main():
         g = generate(variant, seed=20250 + i)
         branch_report(variant, g)
         np.savez_compressed(os.path.join(outdir, f"post_physics_{variant}.npz"), **g)
+    g = generate_ta(seed=20260)
+    rew, fl = g["out_rew"], g["out_flags"]
+    print(f"[TA] {rew.shape}, resets {int(g['out_reset'].sum())}, rew range [{rew.min():.1f}, {rew.max():.1f}], "
+          f"flag bits seen {sorted({b for w in set(fl.ravel().tolist()) for b in range(9) if w >> b & 1})}, "
+          f"rew>2500: {int((rew > 2500).sum())}, rew<-2500: {int((rew < -2500).sum())}, ref=-50 steps: {int((np.abs(rew + 50) < 30).sum())}")
+    np.savez_compressed(os.path.join(outdir, "post_physics_TA.npz"), **g)
     print("wrote", sorted(os.listdir(outdir)))
 
 
