@@ -320,6 +320,31 @@ int ppenv_ta_post_physics_step(const ppenv_ta_params* params, const float* rb_st
                                uint32_t* episode_dev, int64_t* progress_dev, float* obs_dev, float* rew_dev, int64_t* reset_dev,
                                uint32_t* scratch_any_reset_dev /* 1 word */, void* stream);
 
+/* ---- 4-actor variant (Humanoid12PingpongTiltG1), reward functions only ------------------------------
+ * tasks/humanoid_pingpong_4_actor_tilt.py ("T4") defines compute_humanoid1_pingpong_reward T4:1113-1278
+ * (token-identical to TT's compute_pingpong_reward_nv) and its mirror compute_humanoid2_pingpong_reward
+ * T4:1280-1439 for the second humanoid at x = 3.5, but its class never calls them (T4:743 names a
+ * function that does not exist) and leaves the two-agent wiring open (obs "TODO" T4:786).  This entry
+ * evaluates both functions in one launch on the class's tensors; flags use the PPENV_FLAG_* bits, one
+ * word per side.  Under @torch.jit.script the functions' `flag |= ...` statements compile to out-of-place
+ * ops, so the reference never writes the caller's flag tensors: flags*_in are read-only here and the
+ * function-local updated words come back in flags*_out for a caller that wants to carry them.
+ * `progress` is taken as given (the functions read progress_buf, they do not advance it). */
+#define PPENV_T4_NUM_DOF 14
+#define PPENV_T4_NUM_BODIES 82   /* humanoid1 0-39, humanoid2 40-79, table 80, ball 81 (T4:127,169-172) */
+#define PPENV_T4_NUM_ACTORS 4    /* humanoid1, humanoid2, table, ball (T4:181-185) */
+typedef struct ppenv_t4_params {
+    int32_t num_envs;
+    int32_t max_episode_length;
+    float alpha_velocity_reward, power_coefficient, penalty, hit_table_reward, not_hit_table_penalty;
+} ppenv_t4_params;
+int ppenv_t4_rewards(const ppenv_t4_params* params, const float* rb_states_dev /* [N,82,13] */,
+                     const float* root_states_dev /* [N,4,13] */, const float* dof_states_dev /* [N,14,2] */,
+                     const float* dof_force_dev /* [N,14] */, const float* pre_ball_vx_dev /* [N] */,
+                     const int64_t* progress_dev /* [N] */, const uint32_t* flags1_in_dev, const uint32_t* flags2_in_dev /* [N] */,
+                     uint32_t* flags1_out_dev, uint32_t* flags2_out_dev /* [N] */,
+                     float* rew1_dev, float* rew2_dev, int64_t* reset1_dev, int64_t* reset2_dev /* [N] out */, void* stream);
+
 /* ---- state I/O (parity tests, checkpoint) ----------------------------------- */
 
 /* Serve velocities to use at the next resets instead of the RNG

@@ -80,6 +80,7 @@ def lib():
         getattr(L, name).argtypes = [vp, vp, vp]
     L.ppenv_set_serve_override.argtypes = [vp, vp, C.c_int, vp]
     L.ppenv_ta_post_physics_step.argtypes = [C.POINTER(scene.TAParams)] + [vp] * 15
+    L.ppenv_t4_rewards.argtypes = [C.POINTER(scene.T4Params)] + [vp] * 15
     L.ppenv_state_bytes.restype = sz
     L.ppenv_state_bytes.argtypes = [vp]
     L.ppenv_get_state.argtypes = [vp, vp, sz]

@@ -722,11 +722,12 @@ struct RewardIn {
 
 // compute_pingpong_reward_nv TT:1105-1270 / compute_pingpong_reward T3:1080-1173 /
 // compute_pingpong_reward_only_paddle TN:1115-1322.  flags is read-modify-write.
-PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& flags, long long& reset) {
+template <bool CONST_AS>
+PP_HD float compute_reward_impl(const ppenv_config& c, const RewardIn& in, uint32_t& flags, long long& reset) {
     const float Bx = in.bp.x, By = in.bp.y, Bz = in.bp.z, vx = in.vx, pre_vx = in.pre_vx;
-    const float alpha = ldu(c.alpha_velocity_reward), penalty = ldu(c.penalty), threshold = 0.1f;
-    const float power_reward = -ldu(c.power_coefficient) * in.power;
-    const int variant = ldu(c.variant);
+    const float alpha = (CONST_AS ? ldu(c.alpha_velocity_reward) : c.alpha_velocity_reward), penalty = (CONST_AS ? ldu(c.penalty) : c.penalty), threshold = 0.1f;
+    const float power_reward = -(CONST_AS ? ldu(c.power_coefficient) : c.power_coefficient) * in.power;
+    const int variant = (CONST_AS ? ldu(c.variant) : c.variant);
     uint32_t f = flags;
     float reward;
     long long die = 0;
@@ -751,13 +752,13 @@ PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& 
         bool bounce = Bz < 0.83f && vx > 0.f && By < 0.6f && By > -0.6f;                        // TT:1184
         float hit = 0.f;
         bool early = Bx < 2.44f && bounce;
-        if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = ldu(c.not_hit_table_penalty);              // TT:1187-1191
+        if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = (CONST_AS ? ldu(c.not_hit_table_penalty) : c.not_hit_table_penalty);              // TT:1187-1191
         if (early) { f |= PPENV_FLAG_REWARD_CALC; f &= ~PPENV_FLAG_NO_BOUNCE; }                 // TT:1192,1196
         bool inx = Bx > 2.44f && Bx < 3.1f;                                                     // TT:1199
         bool good = inx && bounce && (f & PPENV_FLAG_NO_BOUNCE);
-        if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = ldu(c.hit_table_reward);                    // TT:1201-1205
+        if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = (CONST_AS ? ldu(c.hit_table_reward) : c.hit_table_reward);                    // TT:1201-1205
         if (good) f |= PPENV_FLAG_REWARD_CALC;                                                  // TT:1206
-        if (Bx >= 3.1f && vx > 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = ldu(c.not_hit_table_penalty);   // TT:1209-1213
+        if (Bx >= 3.1f && vx > 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = (CONST_AS ? ldu(c.not_hit_table_penalty) : c.not_hit_table_penalty);   // TT:1209-1213
         if (Bx >= 3.1f) f |= PPENV_FLAG_REWARD_CALC;                                            // TT:1214 (no vx guard)
         float net = (Bx > 1.7f && Bx < 1.8f && vx > 0.f && By < 0.4f && By > -0.4f && Bz > 0.98f && Bz < 1.14f) ? 400.f : 0.f;  // TT:1226-1244
         reward += (((pos_reward + power_reward) + vel_reward) + hit) + net;                     // TT:1251
@@ -777,8 +778,15 @@ PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& 
         if (Bz < threshold) reward = -800.f + reward;                                           // TN:1313-1315
     }
     flags = f;
-    reset = (in.progress >= (long long)ldu(c.max_episode_length) - 1) ? 1 : die;                     // TT:1265
+    reset = (in.progress >= (long long)(CONST_AS ? ldu(c.max_episode_length) : c.max_episode_length) - 1) ? 1 : die;                     // TT:1265
     return reward;
+}
+
+PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& flags, long long& reset) {
+    return compute_reward_impl<true>(c, in, flags, reset);    // c lives in device memory: scalar loads
+}
+PP_HD float compute_reward_generic(const ppenv_config& c, const RewardIn& in, uint32_t& flags, long long& reset) {
+    return compute_reward_impl<false>(c, in, flags, reset);   // c is a local object (T4 entry)
 }
 
 // ------------------------------------------------------------- the fused step

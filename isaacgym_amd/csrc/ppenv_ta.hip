@@ -199,9 +199,97 @@ __global__ void ta_clear_counts_kernel(int n, uint32_t* flags, uint32_t* any_res
     if (i < n && any) flags[i] &= ~PPENV_TA_COUNT_MASK;
 }
 
+// ---- 4-actor variant: compute_humanoid1_pingpong_reward (== TT's, T4:1113-1278) and its mirror
+// compute_humanoid2_pingpong_reward T4:1280-1439, both sides in one launch
+__device__ __forceinline__ float t4_reward_side2(const ppenv_t4_params& p, float humanoid_x, V3 paddle, float pre_vx, V3 bp, float vx,
+                                                 float power, long long progress, uint32_t& flags, long long& reset) {
+    const float Bx = bp.x, By = bp.y, Bz = bp.z;
+    uint32_t f = flags;
+    V3 dp = paddle - bp;
+    float dist = sqrtf(dp.x * dp.x + dp.y * dp.y + dp.z * dp.z);
+    float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                                     // T4:1305-1308
+    bool cond = pre_vx > 0.f && vx < 0.f;                                                      // T4:1328
+    float vel_reward = (cond && !(f & PPENV_FLAG_COND_CALC)) ? p.alpha_velocity_reward * fabsf(vx) : 0.f;
+    if (cond) f |= PPENV_FLAG_COND_CALC;
+    bool missed = Bx > humanoid_x + 0.05f;                                                     // T4:1344
+    float reward = missed ? 0.f + p.penalty : 0.f;
+    bool bounce = Bz < 0.83f && vx < 0.f && By < 0.6f && By > -0.6f;                           // T4:1359
+    float hit = 0.f;
+    bool early = Bx > 1.06f && bounce;                                                         // T4:1363
+    if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = p.not_hit_table_penalty;
+    if (early) { f |= PPENV_FLAG_REWARD_CALC; f &= ~PPENV_FLAG_NO_BOUNCE; }
+    bool inx = Bx < 1.06f && Bx > 0.4f;                                                        // T4:1374
+    bool good = inx && bounce && (f & PPENV_FLAG_NO_BOUNCE);
+    if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = p.hit_table_reward;
+    if (good) f |= PPENV_FLAG_REWARD_CALC;
+    if (Bx <= 0.4f && vx < 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = p.not_hit_table_penalty;   // T4:1384
+    if (Bx <= 0.4f) f |= PPENV_FLAG_REWARD_CALC;                                               // T4:1389
+    float net = (Bx > 1.7f && Bx < 1.8f && vx < 0.f && By < 0.4f && By > -0.4f && Bz > 0.98f && Bz < 1.14f) ? 400.f : 0.f;   // T4:1401-1409
+    float power_reward = -p.power_coefficient * power;
+    reward += (((pos_reward + power_reward) + vel_reward) + hit) + net;                        // T4:1426
+    flags = f;
+    reset = (progress >= (long long)p.max_episode_length - 1) ? 1 : (Bz < 0.1f ? 1 : 0);
+    return reward;
+}
+
+__global__ __launch_bounds__(kTaBlock) void t4_rewards_kernel(const ppenv_t4_params p, const float* __restrict__ rb_states,
+                                                               const float* __restrict__ root_states, const float* __restrict__ dof_states,
+                                                               const float* __restrict__ dof_force, const float* __restrict__ pre_ball_vx,
+                                                               const long long* __restrict__ progress, const uint32_t* __restrict__ flags1_in,
+                                                               const uint32_t* __restrict__ flags2_in, uint32_t* flags1, uint32_t* flags2,
+                                                               float* rew1, float* rew2, long long* reset1, long long* reset2) {
+    const int i = blockIdx.x * kTaBlock + threadIdx.x;
+    if (i >= p.num_envs) return;
+    const float* rb = rb_states + (size_t)i * PPENV_T4_NUM_BODIES * 13;
+    const float* root = root_states + (size_t)i * PPENV_T4_NUM_ACTORS * 13;
+    const float* ball = root + 3 * 13;
+    float power = 0.f;
+#pragma unroll
+    for (int d = 0; d < PPENV_T4_NUM_DOF; d++)   // the class hands the whole 14-dof tensors to the reward (T4:746-747)
+        power += fabsf(dof_force[(size_t)i * PPENV_T4_NUM_DOF + d] * dof_states[((size_t)i * PPENV_T4_NUM_DOF + d) * 2 + 1]);
+    const V3 bp = mk(ball[0], ball[1], ball[2]);
+    // side 1 = TT's function verbatim: run it through the shared compute_reward with a TT-shaped config
+    ppenv_config c;
+    c.variant = PPENV_VARIANT_TT;
+    c.max_episode_length = p.max_episode_length;
+    c.alpha_velocity_reward = p.alpha_velocity_reward; c.power_coefficient = p.power_coefficient; c.penalty = p.penalty;
+    c.hit_table_reward = p.hit_table_reward; c.not_hit_table_penalty = p.not_hit_table_penalty;
+    RewardIn in;
+    in.humanoid_x = root[0];
+    in.paddle = mk(rb[39 * 13], rb[39 * 13 + 1], rb[39 * 13 + 2]);
+    in.pre_vx = pre_ball_vx[i];
+    in.bp = bp;
+    in.vx = ball[7];
+    in.power = power;
+    in.progress = progress[i];
+    uint32_t f1 = flags1_in[i], f2 = flags2_in[i];
+    long long r1, r2;
+    rew1[i] = compute_reward_generic(c, in, f1, r1);
+    rew2[i] = t4_reward_side2(p, root[13], mk(rb[79 * 13], rb[79 * 13 + 1], rb[79 * 13 + 2]), in.pre_vx, bp, in.vx, power, in.progress, f2, r2);
+    flags1[i] = f1; flags2[i] = f2; reset1[i] = r1; reset2[i] = r2;
+}
+
 }  // namespace
 
 void ppenv_set_error(const char* msg);   // ppenv.hip
+
+extern "C" int ppenv_t4_rewards(const ppenv_t4_params* params, const float* rb_states_dev, const float* root_states_dev,
+                                const float* dof_states_dev, const float* dof_force_dev, const float* pre_ball_vx_dev,
+                                const int64_t* progress_dev, const uint32_t* flags1_in_dev, const uint32_t* flags2_in_dev,
+                                uint32_t* flags1_dev, uint32_t* flags2_dev, float* rew1_dev, float* rew2_dev, int64_t* reset1_dev,
+                                int64_t* reset2_dev, void* stream) {
+    if (!params || params->num_envs <= 0 || !rb_states_dev || !root_states_dev || !dof_states_dev || !dof_force_dev || !pre_ball_vx_dev ||
+        !progress_dev || !flags1_in_dev || !flags2_in_dev || !flags1_dev || !flags2_dev || !rew1_dev || !rew2_dev || !reset1_dev || !reset2_dev) {
+        ppenv_set_error("ppenv_t4_rewards: NULL argument or num_envs <= 0");
+        return PPENV_EINVAL;
+    }
+    const int n = params->num_envs;
+    hipLaunchKernelGGL(t4_rewards_kernel, dim3((n + kTaBlock - 1) / kTaBlock), dim3(kTaBlock), 0, (hipStream_t)stream, *params, rb_states_dev,
+                       root_states_dev, dof_states_dev, dof_force_dev, pre_ball_vx_dev, (const long long*)progress_dev, flags1_in_dev, flags2_in_dev, flags1_dev, flags2_dev,
+                       rew1_dev, rew2_dev, (long long*)reset1_dev, (long long*)reset2_dev);
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching t4_rewards_kernel failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
 
 extern "C" int ppenv_ta_post_physics_step(const ppenv_ta_params* params, const float* rb_states_dev, const float* initial_rb_states_dev,
                                           float* root_states_dev, float* dof_states_dev, const float* dof_force_dev,

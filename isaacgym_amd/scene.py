@@ -145,6 +145,22 @@ def build_ta_params(num_envs, env=None, seed=0, env_id_offset=0, is_train=True):
     return p
 
 
+class T4Params(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("max_episode_length", C.c_int32), ("alpha_velocity_reward", C.c_float),
+                ("power_coefficient", C.c_float), ("penalty", C.c_float), ("hit_table_reward", C.c_float),
+                ("not_hit_table_penalty", C.c_float)]
+
+
+def build_t4_params(num_envs, episode_length=140, alpha=50.0, power_coefficient=0.0005, penalty=-200.0, hit_table_reward=2000.0,
+                    not_hit_table_penalty=-1000.0):
+    """ppenv_t4_params; the 4-actor task has no yaml of its own, defaults are the Tilt yaml values."""
+    p = T4Params()
+    p.num_envs, p.max_episode_length = int(num_envs), int(episode_length)
+    p.alpha_velocity_reward, p.power_coefficient, p.penalty = alpha, power_coefficient, penalty
+    p.hit_table_reward, p.not_hit_table_penalty = hit_table_reward, not_hit_table_penalty
+    return p
+
+
 # ------------------------------------------------------------------ math helpers
 def rpy_to_rot(r, p, y):
     """URDF fixed-axis roll-pitch-yaw -> rotation matrix (parent <- child)."""

@@ -241,3 +241,19 @@ def ta_post_physics_step(params, rb, irb, root, dof, dof_force, pre_vx, reset_ov
                                flags.ctypes.data, episode.ctypes.data, progress.ctypes.data, obs.ctypes.data, rew.ctypes.data,
                                reset.ctypes.data)
     return obs, rew, reset
+
+
+# ---- 4-actor variant: the two reward functions -----------------------------------------------------
+def t4_rewards(params, rb, root, dof, dof_force, pre_vx, progress, flags1, flags2):
+    """Returns rew1, rew2, reset1, reset2, flags1_out, flags2_out (inputs are not modified)."""
+    L = lib()
+    n = params.num_envs
+    f1o, f2o = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    rew1, rew2 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    reset1, reset2 = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    L.ppo_t4_rewards.argtypes = [C.POINTER(scene.T4Params)] + [C.c_void_p] * 14
+    L.ppo_t4_rewards.restype = None
+    L.ppo_t4_rewards(C.byref(params), rb.ctypes.data, root.ctypes.data, dof.ctypes.data, dof_force.ctypes.data, pre_vx.ctypes.data,
+                     progress.ctypes.data, flags1.ctypes.data, flags2.ctypes.data, f1o.ctypes.data, f2o.ctypes.data, rew1.ctypes.data,
+                     rew2.ctypes.data, reset1.ctypes.data, reset2.ctypes.data)
+    return rew1, rew2, reset1, reset2, f1o, f2o

@@ -1070,3 +1070,65 @@ void ppo_ta_post_physics_step(const ppenv_ta_params* p, const float* rb_states, 
     if (any_reset)                                                                  /* TA:1162-1166: fill_(0) on ALL envs */
         for (int i = 0; i < n; i++) flags[i] &= ~PPENV_TA_COUNT_MASK;
 }
+
+/* ================================================================================================
+ * 4-actor variant: the two reward functions of tasks/humanoid_pingpong_4_actor_tilt.py (T4:1113-1439).
+ * ================================================================================================ */
+
+/* compute_humanoid2_pingpong_reward T4:1280-1439: TT's reward mirrored for the humanoid at the far end */
+static float t4_reward_side2(const ppenv_t4_params* p, float humanoid_x, const float* paddle, float pre_vx, const float* ball,
+                             float power, int64_t progress, uint32_t* flags, int64_t* reset_out) {
+    const float Bx = ball[0], By = ball[1], Bz = ball[2], vx = ball[7];
+    uint32_t f = *flags;
+    float dx = paddle[0] - Bx, dy = paddle[1] - By, dz = paddle[2] - Bz;
+    float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                                   /* T4:1305-1308 */
+    int cond = pre_vx > 0.0f && vx < 0.0f;                                                   /* T4:1328 */
+    float vel_reward = (cond && !(f & PPENV_FLAG_COND_CALC)) ? p->alpha_velocity_reward * fabsf(vx) : 0.0f;
+    if (cond) f |= PPENV_FLAG_COND_CALC;
+    int missed = Bx > humanoid_x + 0.05f;                                                    /* T4:1344 */
+    float reward = missed ? 0.0f + p->penalty : 0.0f;
+    int bounce = Bz < 0.83f && vx < 0.0f && By < 0.6f && By > -0.6f;                         /* T4:1359 */
+    float hit = 0.0f;
+    int early = Bx > 1.06f && bounce;                                                        /* T4:1363 */
+    if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = p->not_hit_table_penalty;
+    if (early) { f |= PPENV_FLAG_REWARD_CALC; f &= ~PPENV_FLAG_NO_BOUNCE; }
+    int inx = Bx < 1.06f && Bx > 0.4f;                                                       /* T4:1374 */
+    int good = inx && bounce && (f & PPENV_FLAG_NO_BOUNCE);
+    if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = p->hit_table_reward;
+    if (good) f |= PPENV_FLAG_REWARD_CALC;
+    if (Bx <= 0.4f && vx < 0.0f && !(f & PPENV_FLAG_REWARD_CALC)) hit = p->not_hit_table_penalty;   /* T4:1384 */
+    if (Bx <= 0.4f) f |= PPENV_FLAG_REWARD_CALC;                                             /* T4:1389 */
+    float net = (Bx > 1.7f && Bx < 1.8f && vx < 0.0f && By < 0.4f && By > -0.4f && Bz > 0.98f && Bz < 1.14f) ? 400.0f : 0.0f;   /* T4:1401-1409 */
+    float power_reward = -p->power_coefficient * power;
+    reward += (((pos_reward + power_reward) + vel_reward) + hit) + net;                      /* T4:1426 */
+    int64_t die = Bz < 0.1f ? 1 : 0;
+    *flags = f;
+    *reset_out = (progress >= (int64_t)p->max_episode_length - 1) ? 1 : die;
+    return reward;
+}
+
+void ppo_t4_rewards(const ppenv_t4_params* p, const float* rb_states, const float* root_states, const float* dof_states,
+                    const float* dof_force, const float* pre_ball_vx, const int64_t* progress, const uint32_t* flags1_in,
+                    const uint32_t* flags2_in, uint32_t* flags1, uint32_t* flags2, float* rew1, float* rew2, int64_t* reset1,
+                    int64_t* reset2) {
+    ppenv_config c;   /* side 1 is TT's function verbatim (T4:1113-1278 == TT:1105-1270): reuse its restatement */
+    memset(&c, 0, sizeof c);
+    c.variant = PPENV_VARIANT_TT;
+    c.max_episode_length = p->max_episode_length;
+    c.alpha_velocity_reward = p->alpha_velocity_reward; c.power_coefficient = p->power_coefficient; c.penalty = p->penalty;
+    c.hit_table_reward = p->hit_table_reward; c.not_hit_table_penalty = p->not_hit_table_penalty;
+    for (int i = 0; i < p->num_envs; i++) {
+        const float* rb = &rb_states[(size_t)i * PPENV_T4_NUM_BODIES * 13];
+        const float* root = &root_states[(size_t)i * PPENV_T4_NUM_ACTORS * 13];
+        const float* ball = &root[3 * 13];
+        float power = 0.f;
+        for (int d = 0; d < PPENV_T4_NUM_DOF; d++)       /* the class hands the whole 14-dof tensors to the reward (T4:746-747) */
+            power += fabsf(dof_force[(size_t)i * PPENV_T4_NUM_DOF + d] * dof_states[((size_t)i * PPENV_T4_NUM_DOF + d) * 2 + 1]);
+        /* side 1 through compute_reward(): its power term is -c * sum|tau qd| over 7 dofs, so feed the 14-dof sum in one slot */
+        float tau7[ND] = {power, 0, 0, 0, 0, 0, 0}, qd7[ND] = {1.0f, 0, 0, 0, 0, 0, 0};
+        flags1[i] = flags1_in[i]; flags2[i] = flags2_in[i];
+        rew1[i] = compute_reward(&c, root[0], &rb[39 * 13], pre_ball_vx[i], ball, tau7, qd7, progress[i], &flags1[i], &reset1[i]);
+        rew2[i] = t4_reward_side2(p, root[13], &rb[79 * 13], pre_ball_vx[i], ball, power, progress[i], &flags2[i], &reset2[i]);
+    }
+}

@@ -450,6 +450,95 @@ def generate_ta(seed):
     return out
 
 
+def generate_t4(seed):
+    """4-actor variant: direct calls of the two TorchScript reward functions (T4:1113-1439) over a scripted
+    sequence, sticky flags carried in place by the functions themselves (the class never calls them)."""
+    rng = np.random.default_rng(seed)
+    n, T, L = N_ENVS, T_STEPS, 12
+    mod = ref_loader.load_task("humanoid_pingpong_4_actor_tilt.py")
+    P = dict(alpha=50.0, power_coefficient=0.0005, penalty=-200.0, hit_table_reward=2000.0, not_hit_table_penalty=-1000.0)
+    # Under @torch.jit.script the functions' `flag |= ...` statements are out-of-place: the caller's flag tensors are
+    # never written, so the flags are pure inputs.  Feed every combination.
+    fl = {side: None for side in (1, 2)}
+    root = np.zeros((n, 4, 13), np.float32)
+    root[:, 0, 0:3], root[:, 1, 0:3], root[:, 2, 0:3] = (0, 0, 1), (3.5, 0, 1), (1.75, 0, 0)   # T4:525,555,~583
+    root[:, :, 6] = 1.0
+    root[:, 1, 3:7] = (0, 0, 1, 0)                                                             # T4:556
+    ball = np.zeros((n, 13), np.float32)
+    ball[:, 0:3], ball[:, 6] = (3.15, -0.28, 1.1), 1.0                                         # T4:625
+    ball[:, 7:10] = rng.uniform([-9, -0.8, -1], [-5, 0.8, 1], (n, 3))
+    kin = np.arange(n) < n // 2
+    dt = 0.0083 * 3.0
+    progress = np.zeros(n, np.int64)
+    keys = ["in_rb82", "in_root", "in_dof", "in_dof_force", "in_pre_vx", "in_progress", "in_flags1", "in_flags2", "out_rew1", "out_rew2",
+            "out_reset1", "out_reset2"]
+    rec = {k: [] for k in keys}
+
+    def pack(d):
+        return (d["calc"].numpy().astype(np.uint32) * scene.FLAG_REWARD_CALC | d["cond"].numpy().astype(np.uint32) * scene.FLAG_COND_CALC
+                | d["nob"].numpy().astype(np.uint32) * scene.FLAG_NO_BOUNCE)
+    for t in range(T):
+        pre_vx = ball[:, 7].copy()
+        nb = ball.copy()
+        nb[kin, 9] -= 9.8 * dt
+        nb[kin, 0:3] += nb[kin, 7:10] * dt
+        on_table = kin & (nb[:, 2] < 0.78) & (nb[:, 9] < 0) & (nb[:, 0] > 0.38) & (nb[:, 0] < 3.12) & (np.abs(nb[:, 1]) < 0.76)
+        nb[on_table, 2] = 0.78 + (0.78 - nb[on_table, 2])
+        nb[on_table, 9] *= -0.9
+        back1 = kin & (nb[:, 0] < 0.35) & (nb[:, 7] < 0)          # returned by humanoid 1 ...
+        nb[back1, 7] = rng.uniform(3.0, 8.0, back1.sum()); nb[back1, 9] = rng.uniform(0.5, 3.0, back1.sum())
+        back2 = kin & (nb[:, 0] > 3.15) & (nb[:, 7] > 0)          # ... and by humanoid 2
+        nb[back2, 7] = -rng.uniform(3.0, 8.0, back2.sum()); nb[back2, 9] = rng.uniform(0.5, 3.0, back2.sum())
+        iid = ~kin
+        nb[iid, 0:3] = rng.uniform([-0.4, -0.9, 0.0], [3.9, 0.9, 1.4], (iid.sum(), 3))
+        nb[iid, 7:10] = rng.uniform([-9, -2, -4], [9, 2, 4], (iid.sum(), 3))
+        pick = iid & (rng.uniform(size=n) < 0.3)
+        nb[pick, 0] = rng.uniform(1.68, 1.82, pick.sum()); nb[pick, 2] = rng.uniform(0.95, 1.17, pick.sum())
+        pick = iid & (rng.uniform(size=n) < 0.3)
+        nb[pick, 2] = rng.uniform(0.05, 0.9, pick.sum())
+        ball = nb.astype(np.float32)
+        progress = progress + 1
+        root[:, 3, :] = ball
+        rb = np.zeros((n, 82, 13), np.float32)
+        for row, side_x in ((39, 0.3), (79, 3.2)):
+            rb[:, row, 0:3] = rng.uniform([side_x - 0.3, -0.6, 0.8], [side_x + 0.3, 0.2, 1.4], (n, 3))
+            near = rng.uniform(size=n) < 0.3
+            rb[near, row, 0:3] = ball[near, 0:3] + rng.normal(0, 0.05, (near.sum(), 3))
+        dof = rng.uniform(-6, 6, (n, 14, 2)).astype(np.float32)
+        dof_force = rng.uniform(-25, 25, (n, 14)).astype(np.float32)
+        tr, tb, td, tf = (torch.from_numpy(x.copy()) for x in (root, rb, dof, dof_force))
+        pre = tr[:, 3, :].clone(); pre[:, 7] = torch.from_numpy(pre_vx)
+        tp = torch.from_numpy(progress.copy())
+        rec["in_rb82"].append(rb[:, [39, 79], :].copy())       # only the two paddle rows are read
+        rec["in_root"].append(root.copy()); rec["in_dof"].append(dof.copy()); rec["in_dof_force"].append(dof_force.copy())
+        rec["in_pre_vx"].append(pre_vx.astype(np.float32)); rec["in_progress"].append(progress.copy())
+        for side in (1, 2):
+            w = rng.integers(0, 8, n)
+            w[rng.uniform(size=n) < 0.5] = 4          # half the envs in the fresh-episode state
+            fl[side] = dict(calc=torch.from_numpy((w & 1) != 0), cond=torch.from_numpy((w & 2) != 0), nob=torch.from_numpy((w & 4) != 0))
+            rec[f"in_flags{side}"].append(pack(fl[side]))
+        outs = {}
+        for side, fn, hroot, paddle in ((1, mod.compute_humanoid1_pingpong_reward, tr[:, 0, :], tb[:, 39, :]),
+                                        (2, mod.compute_humanoid2_pingpong_reward, tr[:, 1, :], tb[:, 79, :])):
+            d = fl[side]
+            with contextlib.redirect_stdout(io.StringIO()):
+                rew, reset = fn(hroot, paddle, pre, tr[:, 3, :], tf, td[..., 1], torch.zeros(n, dtype=torch.long), tp, float(L), P["alpha"],
+                                P["power_coefficient"], P["penalty"], d["cond"], P["hit_table_reward"], P["not_hit_table_penalty"],
+                                d["calc"], d["nob"])
+            assert np.array_equal(pack(d), rec[f"in_flags{side}"][-1])   # the scripted function did not touch the caller's flags
+            outs[side] = (rew.numpy().copy(), reset.numpy().copy())
+        rec["out_rew1"].append(outs[1][0]); rec["out_rew2"].append(outs[2][0])
+        rec["out_reset1"].append(outs[1][1]); rec["out_reset2"].append(outs[2][1])
+        done = (outs[1][1] != 0) | (outs[2][1] != 0)            # the script's own episode boundary
+        progress[done] = 0
+        ball[done, 0:3] = (3.15, -0.28, 1.1)
+        ball[done, 7:10] = rng.uniform([-9, -0.8, -1], [-5, 0.8, 1], (done.sum(), 3))
+        rec.setdefault("episode_end", []).append(done.copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(episode_length=np.array(L), **{k: np.array(v, np.float32) for k, v in P.items()})
+    return out
+
+
 def branch_report(variant, g):
     rew, reset, fl = g["out_rew"], g["out_reset"], g["out_flags"]
     print(f"[{variant}] steps x envs = {rew.shape}, resets {int(reset.sum())}, "
@@ -466,6 +555,11 @@ def main():
         g = generate(variant, seed=20250 + i)
         branch_report(variant, g)
         np.savez_compressed(os.path.join(outdir, f"post_physics_{variant}.npz"), **g)
+    g = generate_t4(seed=20270)
+    print(f"[T4] {g['out_rew1'].shape}: side-1 rewards in [{g['out_rew1'].min():.0f}, {g['out_rew1'].max():.0f}], side-2 in "
+          f"[{g['out_rew2'].min():.0f}, {g['out_rew2'].max():.0f}], side-2 hit-table rewards {int((g['out_rew2'] > 1500).sum())}, "
+          f"input flag words {sorted(set(g['in_flags2'].ravel().tolist()))}")
+    np.savez_compressed(os.path.join(outdir, "rewards_T4.npz"), **g)
     g = generate_ta(seed=20260)
     rew, fl = g["out_rew"], g["out_flags"]
     print(f"[TA] {rew.shape}, resets {int(g['out_reset'].sum())}, rew range [{rew.min():.1f}, {rew.max():.1f}], "
