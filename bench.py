@@ -35,6 +35,19 @@ ALGO_BYTES_PER_ENV_STEP = 608
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def usable_cores():
+    """Host cores this process may really use: the cgroup CPU quota if there is one, else the affinity mask,
+    capped at 16 (a one-GPU box's CPU share); oversubscribing OpenMP threads only slows the baseline down."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, 16))
+
+
 def cpu_baseline(num_envs, target_seconds=12.0):
     """The CPU oracle (oracle/ppenv_oracle.c, kind 'port') timed on this box's host cores on a bounded
     sample of the same workload.  Reported, not targeted."""
@@ -42,7 +55,7 @@ def cpu_baseline(num_envs, target_seconds=12.0):
     from isaacgym_amd import scene
     from oracle import binding as ob
     ob.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     env = ob.OracleEnv(scene.build_config(VARIANT, num_envs=num_envs, seed=0), threads=cores)
     rng = np.random.default_rng(0)
     actions = [rng.uniform(-1, 1, (num_envs, 7)).astype(np.float32) for _ in range(4)]

@@ -31,7 +31,7 @@ using namespace pp;
 
 namespace {
 
-constexpr int kBlock = 64;
+constexpr int kBlock = 64;   // exactly one wave per workgroup: step_kernel relies on it (no barrier around its LDS tile)
 constexpr int kObsStride = PPENV_NUM_OBS + 1;   // +1 float: lanes write LDS rows bank-conflict-free
 
 struct DevBuffers {
@@ -106,24 +106,25 @@ __device__ __forceinline__ void flush_obs(const float* s_obs, float* obs, int ba
 // ------------------------------------------------------------------ the fused step
 // K1..K8 of SURVEY.md §2 in one launch: TT:1002-1052.
 template <class T>
-__global__ __launch_bounds__(kBlock) void step_kernel(const ppenv_config* __restrict__ cfgp, const float* __restrict__ hinv, DevBuffers b, const float* __restrict__ actions,
-                 int serve_on) {
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
     __shared__ float s_obs[kBlock * kObsStride];
     const int lane = threadIdx.x;
     PP_STAMP_AT(0);
-    const ppenv_config& cfg = *cfgp;
-    const int n = cfg.num_envs;
+    const int n = K.num_envs;
     const int base = blockIdx.x * kBlock;
     const int i = base + lane;
     const int nvalid = min(kBlock, n - base);
 
-    if (i < n) {
+    const bool active = i < n;
+    EnvState st;
+    float rew = 0.f;
+    long long reset = 0;
+    if (active) {
         // actions [N,7] row-major: the wave's 64 rows are one contiguous 1792-byte run, so the seven
         // strided dword loads of a lane hit the same 28 cache lines (L1 serves the re-touches)
         float act[ND];
 #pragma unroll
         for (int d = 0; d < ND; d++) act[d] = actions[(size_t)i * ND + d];
-        EnvState st;
         load_state(b, n, i, st);
 #if defined(PP_STAMP)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // attribute the load latency to phase 0->1
@@ -136,41 +137,39 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const ppenv_config* __rest
 #pragma unroll
         for (int j = 0; j < NB; j++) { bodies[j].pos = mk(act[0], act[1], (float)j); bodies[j].lin = mk(act[2], act[3], act[4]); }
 #else
-        simulate_env<T>(cfg, act, st, bodies, pre_vx);
+        simulate_env<T>(K, act, st, bodies, pre_vx);
 #endif
         V3 ov = mk(0, 0, 0);
         if (serve_on) ov = mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i]);
         LdsRowStore store{&s_obs[lane * kObsStride]};
-        float rew;
-        long long reset;
 #if PP_ABLATE >= 3   // skip reward / reset / observations as well: loads + stores only
         rew = pre_vx; reset = 0;
 #pragma unroll
         for (int k = 0; k < PPENV_NUM_OBS; k++) store(k, bodies[k % NB].pos.x);
 #else
-        post_physics_env(cfg, hinv, (uint32_t)(ldu(cfg.env_id_offset) + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, rew, reset, store);
+        post_physics_env(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, rew, reset, store);
 #endif
         PP_STAMP_AT(9);
-        store_state(b, n, i, st);
+    }
+    // One wave per workgroup: DS operations of a wave execute in order, so the tile written above is visible
+    // to the reads below without a barrier, and nothing forces the vector-memory queue to drain.  Every lane
+    // takes part in the flush (a ragged last workgroup has lanes without an env of their own).
+    __builtin_amdgcn_wave_barrier();
+    flush_obs(s_obs, b.obs, base, nvalid);
+    if (active) {
+        store_state(b, n, i, st);   // fire and forget: nothing in this launch reads the state again
         b.rew[i] = rew;
         b.reset[i] = reset;
     }
-    __syncthreads();
-    flush_obs(s_obs, b.obs, base, nvalid);
     PP_STAMP_AT(10);
 }
 
 // create (mode 0: creation is episode 0) / reset_all (mode 1: next episode): state as after
 // _create_envs (TT:512-643) plus the observations of that state
 template <class T>
-__global__ __launch_bounds__(kBlock) void init_kernel(const ppenv_config* __restrict__ cfgp, float* hinv_out, DevBuffers b, int mode, int serve_on) {
+__global__ __launch_bounds__(kBlock) void init_kernel(const StepConsts K, DevBuffers b, int mode, int serve_on) {
     __shared__ float s_obs[kBlock * kObsStride];
-    const ppenv_config& cfg = *cfgp;
-    float hinv[4];
-    heading_quat_inv(cfg.humanoid_root_quat, hinv);   // calc_heading_quat_inv of the fixed pelvis, once
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int k = 0; k < 4; k++) hinv_out[k] = hinv[k];
-    const int n = cfg.num_envs;
+    const int n = K.num_envs;
     const int base = blockIdx.x * kBlock;
     const int lane = threadIdx.x;
     const int i = base + lane;
@@ -179,19 +178,19 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const ppenv_config* __rest
         EnvState st;
         st.episode = mode == 0 ? 0u : b.episode[i] + 1u;
         V3 serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
-                            : serve_velocity(cfg, (uint32_t)(cfg.env_id_offset + i), st.episode);
-        reset_state(cfg, st, serve, true);
+                            : serve_velocity(K, (uint32_t)(K.env_id_offset + i), st.episode);
+        reset_state(K, st, serve, true);
 #pragma unroll
         for (int d = 0; d < ND; d++) st.dof_force[d] = 0.f;
         st.progress = 0;
         st.flags = PPENV_FLAG_NO_BOUNCE;
         BodyState bodies[NB];
-        bodies_of_state<T>(cfg, st.q, st.qd, bodies);
+        bodies_of_state<T>(K, st.q, st.qd, bodies);
         V3 bpos[NB], bvel[NB];
 #pragma unroll
         for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
         LdsRowStore store{&s_obs[lane * kObsStride]};
-        write_obs(bpos, bvel, hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
+        write_obs(bpos, bvel, K.hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
         store_state(b, n, i, st);
         b.rew[i] = 0.f;
         b.reset[i] = 1;   // upstream VecTask.allocate_buffers: ones; overwritten by the first step (TT:740)
@@ -201,12 +200,11 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const ppenv_config* __rest
 }
 
 // ---------------------------------------- Isaac-Gym tensor-API mode: TT:1022-1039 on caller tensors
-__global__ __launch_bounds__(kBlock) void post_physics_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, const float* __restrict__ rb,
+__global__ __launch_bounds__(kBlock) void post_physics_kernel(const StepConsts K, DevBuffers b, const float* __restrict__ rb,
                                                                float* root, float* dofs, const float* __restrict__ dof_force,
                                                                const float* __restrict__ pre_vx, int serve_on) {
     __shared__ float s_obs[kBlock * kObsStride];
-    const ppenv_config& cfg = *cfgp;
-    const int n = cfg.num_envs;
+    const int n = K.num_envs;
     const int base = blockIdx.x * kBlock;
     const int lane = threadIdx.x;
     const int i = base + lane;
@@ -249,13 +247,13 @@ __global__ __launch_bounds__(kBlock) void post_physics_kernel(const ppenv_config
         in.power = power;
         in.progress = st.progress;
         long long reset;
-        float rew = compute_reward(cfg, in, st.flags, reset);
+        float rew = compute_reward(K.rc, in, st.flags, reset);
         if (reset) {                                                        // TT:847-906
             st.episode += 1;
             V3 serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
-                                : serve_velocity(cfg, (uint32_t)(cfg.env_id_offset + i), st.episode);
-            const float* ipos[3] = {cfg.humanoid_root_pos, cfg.table_root_pos, cfg.ball_init_pos};
-            const float* iquat[3] = {cfg.humanoid_root_quat, cfg.table_root_quat, cfg.ball_init_quat};
+                                : serve_velocity(K, (uint32_t)(K.env_id_offset + i), st.episode);
+            const float* ipos[3] = {K.root_pos, K.table_pos, K.ball_init_pos};
+            const float* iquat[3] = {K.root_quat, K.table_quat, K.ball_init_quat};
 #pragma unroll
             for (int a = 0; a < 3; a++) {                                   // TT:853-855
 #pragma unroll
@@ -266,12 +264,12 @@ __global__ __launch_bounds__(kBlock) void post_physics_kernel(const ppenv_config
                 for (int k = 7; k < 13; k++) roote[a * 13 + k] = 0.f;
             }
             be[7] = serve.x; be[8] = serve.y; be[9] = serve.z;              // TT:857-862
-            st.ball.p = ld3(cfg.ball_init_pos);
+            st.ball.p = ld3(K.ball_init_pos);
             st.ball.v = serve;
-            if (cfg.variant != PPENV_VARIANT_TN) {                          // TN:888-901 keeps the dof state
+            if (K.rc.variant != PPENV_VARIANT_TN) {                          // TN:888-901 keeps the dof state
 #pragma unroll
                 for (int d = 0; d < ND; d++) {
-                    st.q[d] = cfg.init_dof_pos[d]; st.qd[d] = cfg.init_dof_vel[d];
+                    st.q[d] = K.init_dof_pos[d]; st.qd[d] = K.init_dof_vel[d];
                     dofe[2 * d] = st.q[d]; dofe[2 * d + 1] = st.qd[d];
                 }
             }
@@ -293,20 +291,18 @@ __global__ __launch_bounds__(kBlock) void post_physics_kernel(const ppenv_config
 }
 
 // ------------------------------------------------------------ gym.refresh_* equivalents
-__global__ void refresh_root_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, float* out) {
-    const ppenv_config& cfg = *cfgp;
-    const int n = cfg.num_envs;
+__global__ void refresh_root_kernel(const StepConsts K, DevBuffers b, float* out) {
+    const int n = K.num_envs;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float* r = out + (size_t)i * 39;
     for (int k = 0; k < 39; k++) r[k] = 0.f;
-    for (int k = 0; k < 3; k++) { r[k] = cfg.humanoid_root_pos[k]; r[13 + k] = cfg.table_root_pos[k]; }
-    for (int k = 0; k < 4; k++) { r[3 + k] = cfg.humanoid_root_quat[k]; r[16 + k] = cfg.table_root_quat[k]; }
+    for (int k = 0; k < 3; k++) { r[k] = K.root_pos[k]; r[13 + k] = K.table_pos[k]; }
+    for (int k = 0; k < 4; k++) { r[3 + k] = K.root_quat[k]; r[16 + k] = K.table_quat[k]; }
     for (int k = 0; k < 13; k++) r[26 + k] = b.ball[(size_t)k * n + i];
 }
-__global__ void refresh_dof_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, float* out) {
-    const ppenv_config& cfg = *cfgp;
-    const int n = cfg.num_envs;
+__global__ void refresh_dof_kernel(const StepConsts K, DevBuffers b, float* out) {
+    const int n = K.num_envs;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int d = 0; d < ND; d++) {
@@ -314,28 +310,26 @@ __global__ void refresh_dof_kernel(const ppenv_config* __restrict__ cfgp, DevBuf
         out[((size_t)i * ND + d) * 2 + 1] = b.dof_vel[(size_t)d * n + i];
     }
 }
-__global__ void refresh_dof_force_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, float* out) {
-    const ppenv_config& cfg = *cfgp;
-    const int n = cfg.num_envs;
+__global__ void refresh_dof_force_kernel(const StepConsts K, DevBuffers b, float* out) {
+    const int n = K.num_envs;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int d = 0; d < ND; d++) out[(size_t)i * ND + d] = b.dof_force[(size_t)d * n + i];
 }
 template <class T>
-__global__ __launch_bounds__(kBlock) void refresh_rb_kernel(const ppenv_config* __restrict__ cfgp, DevBuffers b, float* out) {
-    const ppenv_config& cfg = *cfgp;
-    const int n = cfg.num_envs;
+__global__ __launch_bounds__(kBlock) void refresh_rb_kernel(const StepConsts K, DevBuffers b, float* out) {
+    const int n = K.num_envs;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float q[ND], qd[ND];
     for (int d = 0; d < ND; d++) { q[d] = b.dof_pos[(size_t)d * n + i]; qd[d] = b.dof_vel[(size_t)d * n + i]; }
     BodyState bodies[NB];
-    bodies_of_state<T>(cfg, q, qd, bodies);
+    bodies_of_state<T>(K, q, qd, bodies);
     float* rb = out + (size_t)i * PPENV_NUM_BODIES * 13;
     for (int body = 0; body < PPENV_NUM_HUMANOID_BODIES; body++) {
         float* r = rb + body * 13;
-        for (int k = 0; k < 3; k++) r[k] = cfg.humanoid_root_pos[k];
-        for (int k = 0; k < 4; k++) r[3 + k] = cfg.humanoid_root_quat[k];
+        for (int k = 0; k < 3; k++) r[k] = K.root_pos[k];
+        for (int k = 0; k < 4; k++) r[3 + k] = K.root_quat[k];
         for (int k = 7; k < 13; k++) r[k] = 0.f;
     }
     const int body_ids[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};
@@ -351,8 +345,8 @@ __global__ __launch_bounds__(kBlock) void refresh_rb_kernel(const ppenv_config* 
     }
     float* t = rb + 40 * 13;
     for (int k = 0; k < 13; k++) t[k] = 0.f;
-    for (int k = 0; k < 3; k++) t[k] = cfg.table_root_pos[k];
-    for (int k = 0; k < 4; k++) t[3 + k] = cfg.table_root_quat[k];
+    for (int k = 0; k < 3; k++) t[k] = K.table_pos[k];
+    for (int k = 0; k < 4; k++) t[3 + k] = K.table_quat[k];
     float* bl = rb + 41 * 13;
     for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
 }
@@ -406,7 +400,7 @@ namespace {
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t obs, rew, reset, progress, dof_pos, dof_vel, dof_force, ball, flags, episode, serve, cfg, hinv, total;
+    size_t obs, rew, reset, progress, dof_pos, dof_vel, dof_force, ball, flags, episode, serve, total;
 };
 Layout layout_for(int n) {
     Layout l;
@@ -423,8 +417,6 @@ Layout layout_for(int n) {
     l.flags = take((size_t)n * 4);
     l.episode = take((size_t)n * 4);
     l.serve = take((size_t)n * 3 * 4);
-    l.cfg = take(sizeof(ppenv_config));
-    l.hinv = take(4 * sizeof(float));
     l.total = o;
     return l;
 }
@@ -452,8 +444,7 @@ int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 
 struct ppenv {
     ppenv_config cfg;
-    ppenv_config* cfg_dev;   // the same, in device memory (kernels read it with scalar loads)
-    float* hinv_dev;         // calc_heading_quat_inv(humanoid_root_quat), computed once by init_kernel
+    StepConsts K;            // run-time constants derived from cfg; passed to every kernel by value (kernarg)
     DevBuffers buf;
     Layout lay;
     void* arena;
@@ -511,13 +502,11 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
     e->buf = DevBuffers{(float*)(a + l.obs), (float*)(a + l.rew), (long long*)(a + l.reset), (long long*)(a + l.progress),
                         (float*)(a + l.dof_pos), (float*)(a + l.dof_vel), (float*)(a + l.dof_force), (float*)(a + l.ball),
                         (uint32_t*)(a + l.flags), (uint32_t*)(a + l.episode), (float*)(a + l.serve)};
-    e->cfg_dev = (ppenv_config*)(a + l.cfg);
-    e->hinv_dev = (float*)(a + l.hinv);
+    e->K = make_step_consts(e->cfg);
     hipStream_t s = (hipStream_t)stream;
     hipError_t err = hipMemsetAsync(e->arena, 0, l.total, s);
-    if (err == hipSuccess) err = hipMemcpyAsync(e->cfg_dev, &e->cfg, sizeof(ppenv_config), hipMemcpyHostToDevice, s);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->cfg_dev, e->hinv_dev, e->buf, 0, 0);
+        hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->K, e->buf, 0, 0);
         err = hipGetLastError();
     }
     if (err != hipSuccess) {
@@ -558,8 +547,8 @@ int ppenv_config_of(ppenv* e, ppenv_config* out) {
 int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->hinv_dev,
-                       e->buf, actions_dev, e->serve_on);
+    hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
+                       e->serve_on);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
@@ -567,8 +556,7 @@ int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
 int ppenv_reset_all(ppenv* e, void* stream) {
     if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->hinv_dev,
-                       e->buf, 1, e->serve_on);
+    hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, 1, e->serve_on);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
@@ -591,7 +579,7 @@ int ppenv_post_physics_step(ppenv* e, const float* rigid_body_states_dev, float*
         return PPENV_EINVAL;
     }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(post_physics_kernel, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf,
+    hipLaunchKernelGGL(post_physics_kernel, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf,
                        rigid_body_states_dev, root_states_dev, dof_states_dev, dof_force_dev, pre_ball_vx_dev, e->serve_on);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
@@ -600,28 +588,28 @@ int ppenv_post_physics_step(ppenv* e, const float* rigid_body_states_dev, float*
 int ppenv_refresh_root_states(ppenv* e, float* out, void* stream) {
     if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(refresh_root_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
+    hipLaunchKernelGGL(refresh_root_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->buf, out);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
 int ppenv_refresh_dof_states(ppenv* e, float* out, void* stream) {
     if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(refresh_dof_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
+    hipLaunchKernelGGL(refresh_dof_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->buf, out);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
 int ppenv_refresh_dof_force(ppenv* e, float* out, void* stream) {
     if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(refresh_dof_force_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
+    hipLaunchKernelGGL(refresh_dof_force_kernel, dim3((e->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->buf, out);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
 int ppenv_refresh_rigid_body_states(ppenv* e, float* out, void* stream) {
     if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(refresh_rb_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->cfg_dev, e->buf, out);
+    hipLaunchKernelGGL(refresh_rb_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, out);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }

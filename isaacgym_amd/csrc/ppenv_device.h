@@ -20,6 +20,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/ppenv.h"
 
@@ -62,47 +63,8 @@ PP_HD void sincos_joint(float q, float& s, float& c) {
 #endif
 }
 
-// Model constants live in a ppenv_config in device memory and are wave-uniform.  They are read
-// through the constant address space so the compiler emits scalar loads (s_load -> SGPRs) instead
-// of 64-lane vector loads:
-//   ldc(field): copy of a sub-struct (a joint, a shape ...) whose address goes through an empty asm
-//               first.  The asm stops loop-invariant code motion from hoisting the ~600 constants of
-//               the arm model out of the substep loop and holding them live (that spilled >1000
-//               SGPRs); each block of constants is fetched right where it is used instead.
-//   ldu(field): plain scalar read the optimiser may hoist and CSE (the few dozen hot scalars).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PP_CONST_AS __attribute__((address_space(4)))
-template <class S>
-PP_HD S ldc(const S& f) {
-    const S* p = &f;
-    asm volatile("" : "+s"(p));
-    S out;
-    __builtin_memcpy(&out, (const PP_CONST_AS S*)p, sizeof(S));
-    return out;
-}
-template <class S>
-PP_HD S ldu(const S& f) {
-    S out;
-    __builtin_memcpy(&out, (const PP_CONST_AS S*)&f, sizeof(S));
-    return out;
-}
 // 1-ulp hardware reciprocal / reciprocal square root for the physics (reward and observations keep
 // IEEE division and sqrt so that thresholds and roundings follow the reference's torch arithmetic)
-// fence(cfg): the same config behind an empty asm; scalars read through the result cannot be hoisted
-// above this point (keeps one phase's constants from staying live in SGPRs through the others)
-PP_HD const ppenv_config& fence(const ppenv_config& c) {
-    const ppenv_config* p = &c;
-    asm volatile("" : "+s"(p));
-    return *p;
-}
-PP_HD float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
-PP_HD float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
-#else
-template <class S>
-PP_HD S ldc(const S& f) { return f; }
-template <class S>
-PP_HD S ldu(const S& f) { return f; }
-PP_HD const ppenv_config& fence(const ppenv_config& c) { return c; }
 #if defined(__HIP_DEVICE_COMPILE__)
 PP_HD float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 PP_HD float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -110,7 +72,38 @@ PP_HD float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
 PP_HD float rcp_fast(float x) { return 1.0f / x; }
 PP_HD float rsq_fast(float x) { return 1.0f / sqrtf(x); }
 #endif
-#endif
+
+// Everything the step needs at run time that is not compiled into the model: ~170 dwords derived from
+// ppenv_config once, on the host, at create time (make_step_consts).  The kernels take it BY VALUE, so
+// it sits in the kernarg segment and the whole block is fetched with a handful of wide scalar loads at
+// wave start — one wait — instead of ~80 separate scalar loads scattered through the step, each of
+// which a lone wave per SIMD cannot hide (measured: ~16k of a wave's 52k cycles).
+struct RewardConsts {
+    int32_t variant, max_episode_length;
+    float alpha, power_coefficient, penalty, hit_table_reward, not_hit_table_penalty;
+};
+struct StepConsts {
+    int32_t num_envs, env_id_offset, substeps, ball_substeps;
+    uint64_t seed;
+    RewardConsts rc;
+    float h, clip_actions;                       // substep length dt / substeps
+    float base_pos[3], base_rot[9], base_grav[3]; // chain base; base_grav = base_rot^T (0, 0, -gravity_z)
+    // ball / contacts
+    float hb, inv_m, inv_h;                      // micro-step length, 1 / ball_substeps, 1 / h
+    float contact_offset, bounce_threshold, depen_cap, ball_r, inv_kr, stick_factor, gdv, damp;
+    float ground_z, ground_e, ground_mu;
+    ppenv_box table, net;
+    float bound_center[3], bound_r2;
+    float paddle_e, paddle_mu;
+    float shape_e[PPENV_MAX_SHAPES], shape_mu[PPENV_MAX_SHAPES];
+    float static_a[PPENV_MAX_SHAPES][3], static_b[PPENV_MAX_SHAPES][3];   // world end points of the static shapes
+    // task
+    float root_pos[3], root_rot[9], root_quat[4], hinv[4];   // pelvis (obs_body[0]); hinv = calc_heading_quat_inv(root_quat)
+    float table_pos[3], table_quat[4];
+    float serve_speed_lo, serve_speed_hi, serve_tilt_lo_deg, serve_tilt_hi_deg, serve_tilt_z_lo_deg, serve_tilt_z_hi_deg;
+    float ball_init_pos[3], ball_init_quat[4];
+    float init_dof_pos[PPENV_NUM_DOF], init_dof_vel[PPENV_NUM_DOF];
+};
 
 // ------------------------------------------------------------------ small math
 struct V3 { float x, y, z; };
@@ -235,24 +228,19 @@ PP_HD void sincos_small(float x, float& s, float& c) {
     c = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
 }
 // generate_random_speed_for_ball: TT:296-323 / T3:289-305 / TN:301-328
-PP_HD V3 serve_velocity(const ppenv_config& c, uint32_t gid, uint32_t episode) {
+PP_HD V3 serve_velocity(const StepConsts& K, uint32_t gid, uint32_t episode) {
     const float deg = 0.017453292519943295f;
-    const uint64_t seed = ldu(c.seed);
-    const int variant = ldu(c.variant);
-    float u0 = rng_uniform(seed, gid, episode, 0);
-    float u1 = rng_uniform(seed, gid, episode, 1);
-    float u2 = rng_uniform(seed, gid, episode, 2);
-    const float s_lo = ldu(c.serve_speed_lo), s_hi = ldu(c.serve_speed_hi);
-    const float t_lo = ldu(c.serve_tilt_lo_deg), t_hi = ldu(c.serve_tilt_hi_deg);
-    const float z_lo = ldu(c.serve_tilt_z_lo_deg), z_hi = ldu(c.serve_tilt_z_hi_deg);
-    float speed = s_lo + (s_hi - s_lo) * u0;
-    float a = (t_lo + (t_hi - t_lo) * u1) * deg;
-    float az = (z_lo + (z_hi - z_lo) * u2) * deg;
+    float u0 = rng_uniform(K.seed, gid, episode, 0);
+    float u1 = rng_uniform(K.seed, gid, episode, 1);
+    float u2 = rng_uniform(K.seed, gid, episode, 2);
+    float speed = K.serve_speed_lo + (K.serve_speed_hi - K.serve_speed_lo) * u0;
+    float a = (K.serve_tilt_lo_deg + (K.serve_tilt_hi_deg - K.serve_tilt_lo_deg) * u1) * deg;
+    float az = (K.serve_tilt_z_lo_deg + (K.serve_tilt_z_hi_deg - K.serve_tilt_z_lo_deg) * u2) * deg;
     float sa, ca, sz, cz;
     sincos_small(a, sa, ca);
     sincos_small(az, sz, cz);
-    if (variant == PPENV_VARIANT_T3) return mk(-speed * ca, -speed * sa, 0.f);                 // T3:296-300
-    if (variant == PPENV_VARIANT_TT) return mk(-speed * ca * cz, -speed * sa * sz, -speed * sa); // TT:307-318 (sic)
+    if (K.rc.variant == PPENV_VARIANT_T3) return mk(-speed * ca, -speed * sa, 0.f);                 // T3:296-300
+    if (K.rc.variant == PPENV_VARIANT_TT) return mk(-speed * ca * cz, -speed * sa * sz, -speed * sa); // TT:307-318 (sic)
     return mk(-speed * ca * cz, speed * sa * cz, speed * sz);                                     // TN:312-323
 }
 
@@ -291,9 +279,9 @@ struct BodyState { V3 pos; M3 rot; V3 lin, ang; };
 // Forward kinematics sweep base -> tip.  Fills JointSave::{c,s,w,v}; hands every
 // link's world transform to `vis(i, Rw, pw, w_link, v_link)`.
 template <class T, class Visitor>
-PP_HD void fk_sweep(const ppenv_config& cfg, const float* q, const float* qd, JointSave* js, Visitor& vis) {
-    M3 Rp = ldu(*reinterpret_cast<const M3*>(cfg.base_rot));
-    V3 pp = ldu(*reinterpret_cast<const V3*>(cfg.base_pos));
+PP_HD void fk_sweep(const StepConsts& K, const float* q, const float* qd, JointSave* js, Visitor& vis) {
+    M3 Rp = ldm(K.base_rot);
+    V3 pp = ld3(K.base_pos);
     V3 wp = mk(0, 0, 0), vp = mk(0, 0, 0);
 #pragma unroll
     for (int i = 0; i < ND; i++) {
@@ -316,9 +304,8 @@ PP_HD void fk_sweep(const ppenv_config& cfg, const float* q, const float* qd, Jo
 // collects the moving collision geometry during an FK sweep
 template <class T>
 struct GeomVisitor {
-    const ppenv_config& cfg;
     ArmGeom<T::kShapes>& g;
-    PP_HD GeomVisitor(const ppenv_config& c, ArmGeom<T::kShapes>& gg) : cfg(c), g(gg) {}
+    PP_HD explicit GeomVisitor(ArmGeom<T::kShapes>& gg) : g(gg) {}
     PP_HD void operator()(int i, const M3& Rw, V3 pw, V3, V3) {
         if (i == ND - 1) {   // paddle_link is validated to be the last link at create time
             const ModelPaddle P = T::paddle();
@@ -335,10 +322,10 @@ struct GeomVisitor {
     }
 };
 template <class T>
-PP_HD void static_geometry(const ppenv_config& cfg, ArmGeom<T::kShapes>& g) {
+PP_HD void static_geometry(const StepConsts& K, ArmGeom<T::kShapes>& g) {
 #pragma unroll
     for (int s = 0; s < T::kShapes; s++)
-        if (T::shape_link(s) < 0) { const ppenv_shape sh = ldc(cfg.shape[s]); g.a[s] = ld3(sh.a); g.b[s] = ld3(sh.b); }
+        if (T::shape_link(s) < 0) { g.a[s] = ld3(K.static_a[s]); g.b[s] = ld3(K.static_b[s]); }
 }
 
 // geometry + the observed bodies (obs_body[1..7] are the chain links, [8],[9] ride on the last link).
@@ -347,12 +334,11 @@ PP_HD void static_geometry(const ppenv_config& cfg, ArmGeom<T::kShapes>& g) {
 // angular velocity for ppenv_refresh_rigid_body_states.
 template <class T, bool FULL>
 struct BodyVisitor {
-    const ppenv_config& cfg;
     ArmGeom<T::kShapes>& g;
     BodyState* bodies;   // [NB]
-    PP_HD BodyVisitor(const ppenv_config& c, ArmGeom<T::kShapes>& gg, BodyState* b) : cfg(c), g(gg), bodies(b) {}
+    PP_HD BodyVisitor(ArmGeom<T::kShapes>& gg, BodyState* b) : g(gg), bodies(b) {}
     PP_HD void operator()(int i, const M3& Rw, V3 pw, V3 w, V3 v) {
-        GeomVisitor<T> gv(cfg, g);
+        GeomVisitor<T> gv(g);
         gv(i, Rw, pw, w, v);
         V3 ww = mul(Rw, w), vw = mul(Rw, v);
         bodies[1 + i].pos = pw; bodies[1 + i].lin = vw;
@@ -370,17 +356,16 @@ struct BodyVisitor {
     }
 };
 template <bool FULL>
-PP_HD void static_body(const ppenv_config& cfg, BodyState& b) {   // obs_body[0]: the pelvis, fixed at the root pose
-    const ppenv_frame f = ldc(cfg.obs_body[0]);
-    b.pos = ld3(f.xyz); b.lin = mk(0, 0, 0);
-    if (FULL) { b.rot = ldm(f.rot); b.ang = mk(0, 0, 0); }
+PP_HD void static_body(const StepConsts& K, BodyState& b) {   // obs_body[0]: the pelvis, fixed at the root pose
+    b.pos = ld3(K.root_pos); b.lin = mk(0, 0, 0);
+    if (FULL) { b.rot = ldm(K.root_rot); b.ang = mk(0, 0, 0); }
 }
 
 // --------------------------------------------------- ABA passes 2 and 3 (RBDA 7.1)
 // tau / arm_eff: drive torque and joint-space inertia added on the diagonal
 // (armature + the implicit PD terms).  Returns qdd.
 template <class T>
-PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, const float* tau, const float* arm_eff, float* qdd) {
+PP_HD void aba_solve(const StepConsts& K, JointSave* js, const float* qd, const float* tau, const float* arm_eff, float* qdd) {
     // articulated inertia / bias force handed down by the child, in this link's coordinates
     S3 cA = {0, 0, 0, 0, 0, 0}, cD = {0, 0, 0, 0, 0, 0};
     M3 cB = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
@@ -449,7 +434,7 @@ PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, co
     }
     // pass 3: accelerations base -> tip; the base "accelerates" upward by |g|
     V3 aw = mk(0, 0, 0);
-    V3 av = tmul(ldc(*reinterpret_cast<const M3*>(cfg.base_rot)), mk(0, 0, -ldu(cfg.gravity_z)));
+    V3 av = ld3(K.base_grav);
 #pragma unroll
     for (int i = 0; i < ND; i++) {
         const JointKin J = T::kin(i);
@@ -471,7 +456,7 @@ PP_HD void aba_solve(const ppenv_config& cfg, JointSave* js, const float* qd, co
 // the joint-space inertia diagonal); a joint whose explicit PD torque exceeds the
 // effort limit gets the constant limit torque instead.
 template <class T>
-PP_HD void arm_substep(const ppenv_config& cfg, JointSave* js, float* q, float* qd, const float* target, float h, float* tau_drive) {
+PP_HD void arm_substep(const StepConsts& K, JointSave* js, float* q, float* qd, const float* target, float h, float* tau_drive) {
     float tau[ND], arm[ND], qdd[ND];
     bool sat[ND];
 #pragma unroll
@@ -484,7 +469,7 @@ PP_HD void arm_substep(const ppenv_config& cfg, JointSave* js, float* q, float* 
         tau[d] = sat[d] ? copysignf(J.effort, t_exp) : t_imp;
         arm[d] = sat[d] ? J.armature : J.armature + h * J.kd + h * h * J.kp;
     }
-    aba_solve<T>(cfg, js, qd, tau, arm, qdd);
+    aba_solve<T>(K, js, qd, tau, arm, qdd);
 #pragma unroll
     for (int d = 0; d < ND; d++) {
         const JointDrive J = T::drive(d);
@@ -601,29 +586,24 @@ PP_HD V3 lerp(V3 a, V3 b, float f) { return madd(a, b - a, f); }
 // one physics substep of the ball: ball_substeps micro-steps against the static scene
 // and the arm geometry interpolated between the substep's two ends (g0 -> g1)
 template <class T>
-PP_HD void ball_substep(const ppenv_config& cfg_in, Ball& b, const ArmGeom<T::kShapes>& g0, const ArmGeom<T::kShapes>& g1, float h) {
-    const ppenv_config& cfg = fence(cfg_in);
-    const int M = ldu(cfg.ball_substeps);
-    const float inv_m = rcp_fast((float)M);
-    const float hb = h * inv_m;
-    const float inv_h = rcp_fast(h);
+PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes>& g0, const ArmGeom<T::kShapes>& g1) {
+    const int M = K.ball_substeps;
+    const float inv_m = K.inv_m, hb = K.hb, inv_h = K.inv_h, h = K.h;
     BallConsts k;
-    k.contact_offset = ldu(cfg.contact_offset);
-    k.bounce_threshold = ldu(cfg.bounce_threshold);
-    k.depen_cap = ldu(cfg.max_depenetration_velocity) * hb;
-    k.r = ldu(cfg.ball_radius);
-    const float kappa = ldu(cfg.ball_inertia_factor);
-    k.inv_kr = rcp_fast(kappa * k.r);
-    k.stick_factor = kappa * rcp_fast(kappa + 1.f);
-    const float gdv = ldu(cfg.gravity_z) * hb;
-    const float damp = fmaxf(1.0f - ldu(cfg.ball_angular_damping) * hb, 0.f);
-    const float ground_z = ldu(cfg.ground_z), ground_e = ldu(cfg.ground_restitution), ground_mu = ldu(cfg.ground_friction);
-    const V3 bc = ldu(*reinterpret_cast<const V3*>(cfg.humanoid_bound_center));
-    const float br = ldu(cfg.humanoid_bound_radius);
-    const ppenv_box table = ldu(cfg.table), net = ldu(cfg.net);
+    k.contact_offset = K.contact_offset;
+    k.bounce_threshold = K.bounce_threshold;
+    k.depen_cap = K.depen_cap;
+    k.r = K.ball_r;
+    k.inv_kr = K.inv_kr;
+    k.stick_factor = K.stick_factor;
+    const float gdv = K.gdv, damp = K.damp;
+    const float ground_z = K.ground_z, ground_e = K.ground_e, ground_mu = K.ground_mu;
+    const V3 bc = ld3(K.bound_center);
+    const ppenv_box& table = K.table;
+    const ppenv_box& net = K.net;
     // broad-phase spheres of the humanoid shapes for this substep
     const ModelPaddle P = T::paddle();
-    const float pad_e = ldu(cfg.paddle_restitution), pad_mu = ldu(cfg.paddle_friction);
+    const float pad_e = K.paddle_e, pad_mu = K.paddle_mu;
     const V3 pdc = g1.pc - g0.pc;
     const float reach = k.r + k.contact_offset + 1e-4f;
     const float pad_rr = sqrtf(P.radius * P.radius + P.half_thickness * P.half_thickness) + reach;
@@ -650,7 +630,7 @@ PP_HD void ball_substep(const ppenv_config& cfg_in, Ball& b, const ArmGeom<T::kS
 #if defined(PP_ABLATE) && PP_ABLATE == 1   // profiling build: no humanoid shapes
         if (false) {
 #else
-        if (dot(db, db) < br * br) {
+        if (dot(db, db) < K.bound_r2) {
 #endif
             // Broad phase: one bounding sphere per shape (centre moves linearly over the substep).  The
             // narrow phase behind it is unchanged, and a ball outside the sphere cannot touch the shape,
@@ -667,7 +647,7 @@ PP_HD void ball_substep(const ppenv_config& cfg_in, Ball& b, const ArmGeom<T::kS
             for (int s = 0; s < T::kShapes; s++) {
                 V3 dsc = b.p - madd(sc0[s], sdc[s], f);
                 if (dot(dsc, dsc) < sr2[s]) {
-                    const float radius = T::shape(s).radius, e = ldu(cfg.shape[s].restitution), mu = ldu(cfg.shape[s].friction);
+                    const float radius = T::shape(s).radius, e = K.shape_e[s], mu = K.shape_mu[s];
                     if (T::shape_link(s) < 0)
                         contact_capsule(k, b, g0.a[s], g0.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
                     else
@@ -722,12 +702,11 @@ struct RewardIn {
 
 // compute_pingpong_reward_nv TT:1105-1270 / compute_pingpong_reward T3:1080-1173 /
 // compute_pingpong_reward_only_paddle TN:1115-1322.  flags is read-modify-write.
-template <bool CONST_AS>
-PP_HD float compute_reward_impl(const ppenv_config& c, const RewardIn& in, uint32_t& flags, long long& reset) {
+PP_HD float compute_reward(const RewardConsts& c, const RewardIn& in, uint32_t& flags, long long& reset) {
     const float Bx = in.bp.x, By = in.bp.y, Bz = in.bp.z, vx = in.vx, pre_vx = in.pre_vx;
-    const float alpha = (CONST_AS ? ldu(c.alpha_velocity_reward) : c.alpha_velocity_reward), penalty = (CONST_AS ? ldu(c.penalty) : c.penalty), threshold = 0.1f;
-    const float power_reward = -(CONST_AS ? ldu(c.power_coefficient) : c.power_coefficient) * in.power;
-    const int variant = (CONST_AS ? ldu(c.variant) : c.variant);
+    const float alpha = c.alpha, penalty = c.penalty, threshold = 0.1f;
+    const float power_reward = -c.power_coefficient * in.power;
+    const int variant = c.variant;
     uint32_t f = flags;
     float reward;
     long long die = 0;
@@ -752,13 +731,13 @@ PP_HD float compute_reward_impl(const ppenv_config& c, const RewardIn& in, uint3
         bool bounce = Bz < 0.83f && vx > 0.f && By < 0.6f && By > -0.6f;                        // TT:1184
         float hit = 0.f;
         bool early = Bx < 2.44f && bounce;
-        if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = (CONST_AS ? ldu(c.not_hit_table_penalty) : c.not_hit_table_penalty);              // TT:1187-1191
+        if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.not_hit_table_penalty;              // TT:1187-1191
         if (early) { f |= PPENV_FLAG_REWARD_CALC; f &= ~PPENV_FLAG_NO_BOUNCE; }                 // TT:1192,1196
         bool inx = Bx > 2.44f && Bx < 3.1f;                                                     // TT:1199
         bool good = inx && bounce && (f & PPENV_FLAG_NO_BOUNCE);
-        if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = (CONST_AS ? ldu(c.hit_table_reward) : c.hit_table_reward);                    // TT:1201-1205
+        if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.hit_table_reward;                    // TT:1201-1205
         if (good) f |= PPENV_FLAG_REWARD_CALC;                                                  // TT:1206
-        if (Bx >= 3.1f && vx > 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = (CONST_AS ? ldu(c.not_hit_table_penalty) : c.not_hit_table_penalty);   // TT:1209-1213
+        if (Bx >= 3.1f && vx > 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.not_hit_table_penalty;   // TT:1209-1213
         if (Bx >= 3.1f) f |= PPENV_FLAG_REWARD_CALC;                                            // TT:1214 (no vx guard)
         float net = (Bx > 1.7f && Bx < 1.8f && vx > 0.f && By < 0.4f && By > -0.4f && Bz > 0.98f && Bz < 1.14f) ? 400.f : 0.f;  // TT:1226-1244
         reward += (((pos_reward + power_reward) + vel_reward) + hit) + net;                     // TT:1251
@@ -778,15 +757,8 @@ PP_HD float compute_reward_impl(const ppenv_config& c, const RewardIn& in, uint3
         if (Bz < threshold) reward = -800.f + reward;                                           // TN:1313-1315
     }
     flags = f;
-    reset = (in.progress >= (long long)(CONST_AS ? ldu(c.max_episode_length) : c.max_episode_length) - 1) ? 1 : die;                     // TT:1265
+    reset = (in.progress >= (long long)c.max_episode_length - 1) ? 1 : die;                     // TT:1265
     return reward;
-}
-
-PP_HD float compute_reward(const ppenv_config& c, const RewardIn& in, uint32_t& flags, long long& reset) {
-    return compute_reward_impl<true>(c, in, flags, reset);    // c lives in device memory: scalar loads
-}
-PP_HD float compute_reward_generic(const ppenv_config& c, const RewardIn& in, uint32_t& flags, long long& reset) {
-    return compute_reward_impl<false>(c, in, flags, reset);   // c is a local object (T4 entry)
 }
 
 // ------------------------------------------------------------- the fused step
@@ -800,65 +772,65 @@ struct EnvState {
 // Physics part of one VecTask.step for one env (pre_physics_step + gym.simulate):
 // updates st in place, returns the pre-reset observed-body states and pre_vx.
 template <class T>
-PP_HD void simulate_env(const ppenv_config& cfg, const float* actions, EnvState& st, BodyState* bodies, float& pre_vx) {
+PP_HD void simulate_env(const StepConsts& K, const float* actions, EnvState& st, BodyState* bodies, float& pre_vx) {
     float target[ND];
 #pragma unroll
     for (int d = 0; d < ND; d++) {   // VecTask.step clamp + TT:1008 (offset/scale TT:664-665)
-        const float clip = ldu(cfg.clip_actions);
+        const float clip = K.clip_actions;
         float a = fminf(fmaxf(actions[d], -clip), clip);
         const float lo = T::drive(d).lower, hi = T::drive(d).upper;
         target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;
     }
     pre_vx = st.ball.v.x;   // TT:1020
-    const int substeps = ldu(cfg.substeps);
-    const float h = ldu(cfg.dt) / (float)substeps;
+    const int substeps = K.substeps;
+    const float h = K.h;
     JointSave js[ND];
     ArmGeom<T::kShapes> g0, g1;
-    static_geometry<T>(cfg, g0);
-    static_geometry<T>(cfg, g1);
+    static_geometry<T>(K, g0);
+    static_geometry<T>(K, g1);
     {
-        GeomVisitor<T> gv(cfg, g0);
-        fk_sweep<T>(cfg, st.q, st.qd, js, gv);
+        GeomVisitor<T> gv(g0);
+        fk_sweep<T>(K, st.q, st.qd, js, gv);
     }
     PP_STAMP_AT(2);
     for (int s = 0; s < substeps; s++) {
-        arm_substep<T>(cfg, js, st.q, st.qd, target, h, st.dof_force);
+        arm_substep<T>(K, js, st.q, st.qd, target, h, st.dof_force);
         PP_STAMP_AT(3 + 3 * s);
         if (s + 1 < substeps) {
-            GeomVisitor<T> gv(cfg, g1);
-            fk_sweep<T>(cfg, st.q, st.qd, js, gv);
+            GeomVisitor<T> gv(g1);
+            fk_sweep<T>(K, st.q, st.qd, js, gv);
         } else {
-            BodyVisitor<T, false> bv(cfg, g1, bodies);
-            fk_sweep<T>(cfg, st.q, st.qd, js, bv);
+            BodyVisitor<T, false> bv(g1, bodies);
+            fk_sweep<T>(K, st.q, st.qd, js, bv);
         }
         PP_STAMP_AT(4 + 3 * s);
-        ball_substep<T>(cfg, st.ball, g0, g1, h);
+        ball_substep<T>(K, st.ball, g0, g1);
         PP_STAMP_AT(5 + 3 * s);
         g0 = g1;
     }
-    static_body<false>(cfg, bodies[0]);
+    static_body<false>(K, bodies[0]);
 }
 
 // FK only (create / reset_all / refresh): observed-body states of the current dof state
 template <class T>
-PP_HD void bodies_of_state(const ppenv_config& cfg, const float* q, const float* qd, BodyState* bodies) {
+PP_HD void bodies_of_state(const StepConsts& K, const float* q, const float* qd, BodyState* bodies) {
     JointSave js[ND];
     ArmGeom<T::kShapes> g;
-    BodyVisitor<T, true> bv(cfg, g, bodies);
-    fk_sweep<T>(cfg, q, qd, js, bv);
-    static_body<true>(cfg, bodies[0]);
+    BodyVisitor<T, true> bv(g, bodies);
+    fk_sweep<T>(K, q, qd, js, bv);
+    static_body<true>(K, bodies[0]);
 }
 
 // initial simulation state of an env with the serve of `episode` (TT:853-867)
-PP_HD void reset_state(const ppenv_config& cfg, EnvState& st, V3 serve, bool reset_dofs) {
-    st.ball.p = ldu(*reinterpret_cast<const V3*>(cfg.ball_init_pos));
+PP_HD void reset_state(const StepConsts& K, EnvState& st, V3 serve, bool reset_dofs) {
+    st.ball.p = ld3(K.ball_init_pos);
 #pragma unroll
-    for (int k = 0; k < 4; k++) st.ball.quat[k] = ldu(cfg.ball_init_quat[k]);
+    for (int k = 0; k < 4; k++) st.ball.quat[k] = K.ball_init_quat[k];
     st.ball.v = serve;
     st.ball.w = mk(0, 0, 0);
     if (reset_dofs) {
 #pragma unroll
-        for (int d = 0; d < ND; d++) { st.q[d] = ldu(cfg.init_dof_pos[d]); st.qd[d] = ldu(cfg.init_dof_vel[d]); }
+        for (int d = 0; d < ND; d++) { st.q[d] = K.init_dof_pos[d]; st.qd[d] = K.init_dof_vel[d]; }
     }
 }
 
@@ -891,11 +863,11 @@ PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float hinv[4]
 // post_physics_step for one env of the fused path (TT:1022-1039): progress, reward,
 // masked reset, observations.  serve_override: used instead of the RNG when non-null.
 template <class Store>
-PP_HD void post_physics_env(const ppenv_config& cfg, const float* hinv_dev, uint32_t gid, EnvState& st, const BodyState* bodies,
-                            float pre_vx, const V3* serve_override, float& rew, long long& reset, Store& store) {
+PP_HD void post_physics_env(const StepConsts& K, uint32_t gid, EnvState& st, const BodyState* bodies, float pre_vx,
+                            const V3* serve_override, float& rew, long long& reset, Store& store) {
     st.progress += 1;                                                            // TT:1023
     RewardIn in;
-    in.humanoid_x = ldu(cfg.humanoid_root_pos[0]);
+    in.humanoid_x = K.root_pos[0];
     in.paddle = bodies[NB - 1].pos;
     in.pre_vx = pre_vx;
     in.bp = st.ball.p;
@@ -905,11 +877,11 @@ PP_HD void post_physics_env(const ppenv_config& cfg, const float* hinv_dev, uint
     for (int d = 0; d < ND; d++) power += fabsf(st.dof_force[d] * st.qd[d]);     // TT:1246
     in.power = power;
     in.progress = st.progress;
-    rew = compute_reward(cfg, in, st.flags, reset);
+    rew = compute_reward(K.rc, in, st.flags, reset);
     if (reset) {                                                                 // TT:1034-1036 -> 847-906
         st.episode += 1;
-        V3 serve = serve_override ? *serve_override : serve_velocity(cfg, gid, st.episode);
-        reset_state(cfg, st, serve, ldu(cfg.variant) != PPENV_VARIANT_TN);            // TN:888-901 keeps the dof state
+        V3 serve = serve_override ? *serve_override : serve_velocity(K, gid, st.episode);
+        reset_state(K, st, serve, K.rc.variant != PPENV_VARIANT_TN);            // TN:888-901 keeps the dof state
         st.progress = 0;                                                         // TT:902
         st.flags = PPENV_FLAG_NO_BOUNCE;                                         // TT:903-905
     }
@@ -917,12 +889,60 @@ PP_HD void post_physics_env(const ppenv_config& cfg, const float* hinv_dev, uint
     V3 bpos[NB], bvel[NB];
 #pragma unroll
     for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
-    float hinv[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) hinv[k] = ldu(hinv_dev[k]);
-    write_obs(bpos, bvel, hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
+    write_obs(bpos, bvel, K.hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
 }
 
+}  // namespace pp
+
+// ----------------------------------------------------------------- StepConsts from the config (host)
+namespace pp {
+inline RewardConsts make_reward_consts(const ppenv_config& c) {
+    RewardConsts r;
+    r.variant = c.variant; r.max_episode_length = c.max_episode_length;
+    r.alpha = c.alpha_velocity_reward; r.power_coefficient = c.power_coefficient; r.penalty = c.penalty;
+    r.hit_table_reward = c.hit_table_reward; r.not_hit_table_penalty = c.not_hit_table_penalty;
+    return r;
+}
+inline StepConsts make_step_consts(const ppenv_config& c) {
+    StepConsts K;
+    memset(&K, 0, sizeof K);
+    K.num_envs = c.num_envs; K.env_id_offset = c.env_id_offset; K.substeps = c.substeps; K.ball_substeps = c.ball_substeps;
+    K.seed = c.seed;
+    K.rc = make_reward_consts(c);
+    K.h = c.dt / (float)c.substeps;
+    K.clip_actions = c.clip_actions;
+    for (int k = 0; k < 3; k++) K.base_pos[k] = c.base_pos[k];
+    for (int k = 0; k < 9; k++) K.base_rot[k] = c.base_rot[k];
+    for (int k = 0; k < 3; k++) K.base_grav[k] = c.base_rot[6 + k] * (-c.gravity_z);   // base_rot^T (0, 0, -g): third row of base_rot
+    K.inv_m = 1.0f / (float)c.ball_substeps;
+    K.hb = K.h * K.inv_m;
+    K.inv_h = 1.0f / K.h;
+    K.contact_offset = c.contact_offset; K.bounce_threshold = c.bounce_threshold;
+    K.depen_cap = c.max_depenetration_velocity * K.hb;
+    K.ball_r = c.ball_radius;
+    K.inv_kr = 1.0f / (c.ball_inertia_factor * c.ball_radius);
+    K.stick_factor = c.ball_inertia_factor / (c.ball_inertia_factor + 1.0f);
+    K.gdv = c.gravity_z * K.hb;
+    K.damp = fmaxf(1.0f - c.ball_angular_damping * K.hb, 0.0f);
+    K.ground_z = c.ground_z; K.ground_e = c.ground_restitution; K.ground_mu = c.ground_friction;
+    K.table = c.table; K.net = c.net;
+    for (int k = 0; k < 3; k++) K.bound_center[k] = c.humanoid_bound_center[k];
+    K.bound_r2 = c.humanoid_bound_radius * c.humanoid_bound_radius;
+    K.paddle_e = c.paddle_restitution; K.paddle_mu = c.paddle_friction;
+    for (int s = 0; s < PPENV_MAX_SHAPES; s++) {
+        K.shape_e[s] = c.shape[s].restitution; K.shape_mu[s] = c.shape[s].friction;
+        for (int k = 0; k < 3; k++) { K.static_a[s][k] = c.shape[s].a[k]; K.static_b[s][k] = c.shape[s].b[k]; }
+    }
+    for (int k = 0; k < 3; k++) { K.root_pos[k] = c.obs_body[0].xyz[k]; K.table_pos[k] = c.table_root_pos[k]; K.ball_init_pos[k] = c.ball_init_pos[k]; }
+    for (int k = 0; k < 9; k++) K.root_rot[k] = c.obs_body[0].rot[k];
+    for (int k = 0; k < 4; k++) { K.root_quat[k] = c.humanoid_root_quat[k]; K.table_quat[k] = c.table_root_quat[k]; K.ball_init_quat[k] = c.ball_init_quat[k]; }
+    heading_quat_inv(c.humanoid_root_quat, K.hinv);   // calc_heading_quat_inv of the fixed pelvis, once (TT:1684)
+    K.serve_speed_lo = c.serve_speed_lo; K.serve_speed_hi = c.serve_speed_hi;
+    K.serve_tilt_lo_deg = c.serve_tilt_lo_deg; K.serve_tilt_hi_deg = c.serve_tilt_hi_deg;
+    K.serve_tilt_z_lo_deg = c.serve_tilt_z_lo_deg; K.serve_tilt_z_hi_deg = c.serve_tilt_z_hi_deg;
+    for (int d = 0; d < PPENV_NUM_DOF; d++) { K.init_dof_pos[d] = c.init_dof_pos[d]; K.init_dof_vel[d] = c.init_dof_vel[d]; }
+    return K;
+}
 }  // namespace pp
 
 // ------------------------------------------------------- the compiled model and its runtime check

@@ -248,11 +248,11 @@ __global__ __launch_bounds__(kTaBlock) void t4_rewards_kernel(const ppenv_t4_par
     for (int d = 0; d < PPENV_T4_NUM_DOF; d++)   // the class hands the whole 14-dof tensors to the reward (T4:746-747)
         power += fabsf(dof_force[(size_t)i * PPENV_T4_NUM_DOF + d] * dof_states[((size_t)i * PPENV_T4_NUM_DOF + d) * 2 + 1]);
     const V3 bp = mk(ball[0], ball[1], ball[2]);
-    // side 1 = TT's function verbatim: run it through the shared compute_reward with a TT-shaped config
-    ppenv_config c;
+    // side 1 = TT's function verbatim (T4:1113-1278 == TT:1105-1270): the shared compute_reward with TT semantics
+    RewardConsts c;
     c.variant = PPENV_VARIANT_TT;
     c.max_episode_length = p.max_episode_length;
-    c.alpha_velocity_reward = p.alpha_velocity_reward; c.power_coefficient = p.power_coefficient; c.penalty = p.penalty;
+    c.alpha = p.alpha_velocity_reward; c.power_coefficient = p.power_coefficient; c.penalty = p.penalty;
     c.hit_table_reward = p.hit_table_reward; c.not_hit_table_penalty = p.not_hit_table_penalty;
     RewardIn in;
     in.humanoid_x = root[0];
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kTaBlock) void t4_rewards_kernel(const ppenv_t4_par
     in.progress = progress[i];
     uint32_t f1 = flags1_in[i], f2 = flags2_in[i];
     long long r1, r2;
-    rew1[i] = compute_reward_generic(c, in, f1, r1);
+    rew1[i] = compute_reward(c, in, f1, r1);
     rew2[i] = t4_reward_side2(p, root[13], mk(rb[79 * 13], rb[79 * 13 + 1], rb[79 * 13 + 2]), in.pre_vx, bp, in.vx, power, in.progress, f2, r2);
     flags1[i] = f1; flags2[i] = f2; reset1[i] = r1; reset2[i] = r2;
 }

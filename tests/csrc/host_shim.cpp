@@ -42,12 +42,13 @@ void shim_step(const ppenv_config* cfg, const float* actions /*[N,7]*/, float* d
                float* ball, long long* progress, uint32_t* flags, uint32_t* episode, const float* serve_override /*[3][N] or NULL*/,
                float* obs /*[N,80]*/, float* rew, long long* reset, float* bodies_out /*[N,10,13] or NULL*/) {
     const int n = cfg->num_envs;
+    const StepConsts K = make_step_consts(*cfg);
     for (int i = 0; i < n; i++) {
         EnvState st;
         load_state(n, i, dof_pos, dof_vel, dof_force, ball, progress, flags, episode, st);
         BodyState bodies[NB];
         float pre_vx;
-        simulate_env<T>(*cfg, &actions[(size_t)i * ND], st, bodies, pre_vx);
+        simulate_env<T>(K, &actions[(size_t)i * ND], st, bodies, pre_vx);
         if (bodies_out)
             for (int j = 0; j < NB; j++) {
                 float* o = &bodies_out[((size_t)i * NB + j) * 13];
@@ -62,9 +63,7 @@ void shim_step(const ppenv_config* cfg, const float* actions /*[N,7]*/, float* d
         RowStore rs{&obs[(size_t)i * PPENV_NUM_OBS]};
         float r;
         long long rst;
-        float hinv[4];
-        heading_quat_inv(cfg->humanoid_root_quat, hinv);
-        post_physics_env(*cfg, hinv, (uint32_t)(cfg->env_id_offset + i), st, bodies, pre_vx, ovp, r, rst, rs);
+        post_physics_env(K, (uint32_t)(cfg->env_id_offset + i), st, bodies, pre_vx, ovp, r, rst, rs);
         rew[i] = r; reset[i] = rst;
         store_state(n, i, dof_pos, dof_vel, dof_force, ball, progress, flags, episode, st);
     }
@@ -72,15 +71,16 @@ void shim_step(const ppenv_config* cfg, const float* actions /*[N,7]*/, float* d
 
 // joint accelerations of the kernel's ABA for one env (KAT against the oracle's RNEA + solve)
 void shim_arm_qdd(const ppenv_config* cfg, const float* q, const float* qd, const float* tau, const float* arm_eff, float* qdd) {
+    const StepConsts K = make_step_consts(*cfg);
     JointSave js[ND];
     ArmGeom<T::kShapes> g;
-    GeomVisitor<T> gv(*cfg, g);
-    fk_sweep<T>(*cfg, q, qd, js, gv);
-    aba_solve<T>(*cfg, js, qd, tau, arm_eff, qdd);
+    GeomVisitor<T> gv(g);
+    fk_sweep<T>(K, q, qd, js, gv);
+    aba_solve<T>(K, js, qd, tau, arm_eff, qdd);
 }
 
 void shim_serve_velocity(const ppenv_config* cfg, uint32_t gid, uint32_t episode, float* out) {
-    V3 v = serve_velocity(*cfg, gid, episode);
+    V3 v = serve_velocity(make_step_consts(*cfg), gid, episode);
     out[0] = v.x; out[1] = v.y; out[2] = v.z;
 }
 }
