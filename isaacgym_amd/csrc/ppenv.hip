@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -93,10 +94,10 @@ struct GlobalRowStore {
 };
 
 // obs rows of one workgroup: LDS [kBlock][kObsStride] -> obs_buf[base*80 ...], 16 B per lane, contiguous
-__device__ __forceinline__ void flush_obs(const float* s_obs, float* obs, int base, int nvalid) {
+__device__ __forceinline__ void flush_obs(const float* s_obs, float* obs, int base, int nvalid, int lane) {
     const int total = nvalid * PPENV_NUM_OBS;   // multiple of 4; a float4 never straddles rows (80 % 4 == 0)
     float4* dst = reinterpret_cast<float4*>(obs + (size_t)base * PPENV_NUM_OBS);
-    for (int k = threadIdx.x * 4; k < total; k += kBlock * 4) {
+    for (int k = lane * 4; k < total; k += kBlock * 4) {
         int r = k / PPENV_NUM_OBS, c = k - r * PPENV_NUM_OBS;
         const float* src = &s_obs[r * kObsStride + c];
         dst[k >> 2] = make_float4(src[0], src[1], src[2], src[3]);
@@ -155,13 +156,162 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
     // to the reads below without a barrier, and nothing forces the vector-memory queue to drain.  Every lane
     // takes part in the flush (a ragged last workgroup has lanes without an env of their own).
     __builtin_amdgcn_wave_barrier();
-    flush_obs(s_obs, b.obs, base, nvalid);
+    flush_obs(s_obs, b.obs, base, nvalid, lane);
     if (active) {
         store_state(b, n, i, st);   // fire and forget: nothing in this launch reads the state again
         b.rew[i] = rew;
         b.reset[i] = reset;
     }
     PP_STAMP_AT(10);
+}
+
+// ------------------------------------------------- the fused step, two waves per 64 envs
+// Same arithmetic as step_kernel, different schedule.  At N = 16384 step_kernel puts one wave on each CU
+// and leaves three of its four SIMDs idle, and a lone wave is bound by its own serial instruction
+// stream.  Here a workgroup is two waves that own the same 64 envs:
+//   wave 0 ("arm")  : actions -> PD targets, then per substep ABA + integration + FK, publishing the
+//                     collision geometry of every substep boundary (and finally the observed bodies and
+//                     the dof state) in LDS;
+//   wave 1 ("ball") : per substep the ball's micro-stepped contacts against that geometry — which run
+//                     while wave 0 is already in the next substep's ABA — then reward, masked reset,
+//                     observations and every store.
+// One s_barrier per substep is the only synchronisation; geometry sets rotate through three LDS slots
+// so the arm wave can run one substep ahead.
+constexpr int kGeomFloats = 24;   // paddle centre 3 + normal 3 + 3 moving shapes x 2 end points x 3
+static_assert(ModelG1::kShapes == 6, "LDS geometry record is laid out for the G1 shape list");
+
+template <class T>
+__device__ __forceinline__ void geom_to_lds(float (*slot)[kBlock], int lane, const ArmGeom<T::kShapes>& g) {
+    int k = 0;
+    auto put = [&](V3 v) { slot[k][lane] = v.x; slot[k + 1][lane] = v.y; slot[k + 2][lane] = v.z; k += 3; };
+    put(g.pc); put(g.pn);
+#pragma unroll
+    for (int s = 0; s < T::kShapes; s++)
+        if (T::shape_link(s) >= 0) { put(g.a[s]); put(g.b[s]); }
+}
+template <class T>
+__device__ __forceinline__ void geom_from_lds(float (*slot)[kBlock], int lane, ArmGeom<T::kShapes>& g) {
+    int k = 0;
+    auto get = [&]() { V3 v = mk(slot[k][lane], slot[k + 1][lane], slot[k + 2][lane]); k += 3; return v; };
+    g.pc = get(); g.pn = get();
+#pragma unroll
+    for (int s = 0; s < T::kShapes; s++)
+        if (T::shape_link(s) >= 0) { g.a[s] = get(); g.b[s] = get(); }
+}
+
+template <class T>
+__global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
+    __shared__ float s_obs[kBlock * kObsStride];
+    __shared__ float s_geom[3][kGeomFloats][kBlock];
+    __shared__ float s_paddle[3][kBlock];            // paddle position after the last substep (the reward reads it)
+    __shared__ float s_dof[3 * ND][kBlock];          // q, qd, dof_force after the last substep
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int n = K.num_envs;
+    const int base = blockIdx.x * kBlock;
+    const int i = base + lane;
+    const int nvalid = min(kBlock, n - base);
+    const bool active = i < n;
+    const int substeps = K.substeps;
+
+    if (wave == 0) {
+        // ------------------------------------------------------------------ arm wave
+        float q[ND], qd[ND], target[ND], tau[ND];
+        JointSave js[ND];
+        ArmGeom<T::kShapes> g;
+        BodyState bodies[NB];
+        if (active) {
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                q[d] = b.dof_pos[(size_t)d * n + i];
+                qd[d] = b.dof_vel[(size_t)d * n + i];
+                tau[d] = 0.f;
+                float a = fminf(fmaxf(actions[(size_t)i * ND + d], -K.clip_actions), K.clip_actions);   // VecTask.step clamp
+                const float lo = T::drive(d).lower, hi = T::drive(d).upper;
+                target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;                                     // TT:1008, 664-665
+            }
+            GeomVisitor<T> gv(g);
+            fk_sweep<T>(K, q, qd, js, gv);
+            geom_to_lds<T>(s_geom[0], lane, g);
+        }
+        for (int s = 0; s < substeps; s++) {
+            if (active) {
+                arm_substep<T>(K, js, q, qd, target, K.h, tau);
+                if (s + 1 < substeps) {
+                    GeomVisitor<T> gv(g);
+                    fk_sweep<T>(K, q, qd, js, gv);
+                } else {
+                    BodyVisitor<T, false> bv(g, bodies);
+                    fk_sweep<T>(K, q, qd, js, bv);
+                    static_body<false>(K, bodies[0]);
+                    s_paddle[0][lane] = bodies[NB - 1].pos.x; s_paddle[1][lane] = bodies[NB - 1].pos.y; s_paddle[2][lane] = bodies[NB - 1].pos.z;
+#pragma unroll
+                    for (int d = 0; d < ND; d++) { s_dof[d][lane] = q[d]; s_dof[ND + d][lane] = qd[d]; s_dof[2 * ND + d][lane] = tau[d]; }
+                }
+                geom_to_lds<T>(s_geom[(s + 1) % 3], lane, g);
+            }
+            __syncthreads();   // geometry of boundary s+1 (and, last time, paddle position + dof state) is published
+        }
+        // While the ball wave runs its last substep: the body block of the observation row, obs[0:60]
+        // (TT:1696-1697) — it depends on the pre-reset body states only (TT:1039).
+        if (active) {
+            V3 bpos[NB], bvel[NB];
+#pragma unroll
+            for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
+            LdsRowStore store{&s_obs[lane * kObsStride]};
+            write_obs_bodies(bpos, bvel, K.hinv, store);
+        }
+        __syncthreads();   // obs[0:60] of every row is in the tile
+        return;
+    }
+
+    // ---------------------------------------------------------------------- ball wave
+    EnvState st;
+    float rew = 0.f, pre_vx = 0.f;
+    long long reset = 0;
+    ArmGeom<T::kShapes> g0, g1;
+    if (active) {
+        float bl[13];
+#pragma unroll
+        for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
+        st.ball.p = mk(bl[0], bl[1], bl[2]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) st.ball.quat[k] = bl[3 + k];
+        st.ball.v = mk(bl[7], bl[8], bl[9]);
+        st.ball.w = mk(bl[10], bl[11], bl[12]);
+        st.progress = b.progress[i];
+        st.flags = b.flags[i];
+        st.episode = b.episode[i];
+        pre_vx = st.ball.v.x;   // TT:1020
+        static_geometry<T>(K, g0);
+        static_geometry<T>(K, g1);
+    }
+    for (int s = 0; s < substeps; s++) {
+        __syncthreads();
+        if (active) {
+            geom_from_lds<T>(s_geom[s % 3], lane, g0);
+            geom_from_lds<T>(s_geom[(s + 1) % 3], lane, g1);
+            ball_substep<T>(K, st.ball, g0, g1);
+        }
+    }
+    if (active) {
+        BodyState bodies[NB];   // the task part reads the pelvis (row 0) and the paddle (row 9) only
+        static_body<false>(K, bodies[0]);
+        bodies[NB - 1].pos = mk(s_paddle[0][lane], s_paddle[1][lane], s_paddle[2][lane]);
+#pragma unroll
+        for (int d = 0; d < ND; d++) { st.q[d] = s_dof[d][lane]; st.qd[d] = s_dof[ND + d][lane]; st.dof_force[d] = s_dof[2 * ND + d][lane]; }
+        V3 ov = mk(0, 0, 0);
+        if (serve_on) ov = mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i]);
+        LdsRowStore store{&s_obs[lane * kObsStride]};
+        post_physics_env<false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, rew, reset, store);
+    }
+    __syncthreads();   // the arm wave's obs[0:60] and this wave's obs[60:80] are both in the tile
+    flush_obs(s_obs, b.obs, base, nvalid, lane);
+    if (active) {
+        store_state(b, n, i, st);
+        b.rew[i] = rew;
+        b.reset[i] = reset;
+    }
 }
 
 // create (mode 0: creation is episode 0) / reset_all (mode 1: next episode): state as after
@@ -196,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const StepConsts K, DevBuf
         b.reset[i] = 1;   // upstream VecTask.allocate_buffers: ones; overwritten by the first step (TT:740)
     }
     __syncthreads();
-    flush_obs(s_obs, b.obs, base, nvalid);
+    flush_obs(s_obs, b.obs, base, nvalid, lane);
 }
 
 // ---------------------------------------- Isaac-Gym tensor-API mode: TT:1022-1039 on caller tensors
@@ -287,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void post_physics_kernel(const StepConsts K
         b.reset[i] = reset;
     }
     __syncthreads();
-    flush_obs(s_obs, b.obs, base, nvalid);
+    flush_obs(s_obs, b.obs, base, nvalid, lane);
 }
 
 // ------------------------------------------------------------ gym.refresh_* equivalents
@@ -450,6 +600,7 @@ struct ppenv {
     void* arena;
     bool owns_arena;
     int serve_on;
+    int split;               // 1: step_kernel_split (two waves per 64 envs), 0: step_kernel
 };
 
 namespace {
@@ -483,6 +634,12 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
     e->cfg = *cfg;
     e->lay = layout_for(cfg->num_envs);
     e->serve_on = 0;
+    {   // PPENV_STEP_KERNEL=fused|split forces a schedule (same arithmetic either way)
+        // Two waves per 64 envs pay off while the one-wave grid leaves SIMDs idle (N <= 32768: at most 512 of
+        // 1024 SIMDs); beyond that the extra waves only compete (measured: N = 65536 22.7 vs 33.4 us).
+        const char* k = getenv("PPENV_STEP_KERNEL");
+        e->split = k ? (strcmp(k, "split") == 0) : (cfg->num_envs <= 32768);
+    }
     e->arena = nullptr;
     e->owns_arena = false;
     if (hipSetDevice(cfg->device_id) != hipSuccess) { delete e; set_err("hipSetDevice failed"); return PPENV_EHIP; }
@@ -547,8 +704,12 @@ int ppenv_config_of(ppenv* e, ppenv_config* out) {
 int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
-                       e->serve_on);
+    if (e->split)
+        hipLaunchKernelGGL(step_kernel_split<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+                           actions_dev, e->serve_on);
+    else
+        hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
+                           e->serve_on);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }

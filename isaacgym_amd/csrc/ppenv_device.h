@@ -838,9 +838,9 @@ PP_HD void reset_state(const StepConsts& K, EnvState& st, V3 serve, bool reset_d
 // compute_pingpong_observations TT:1640-1666.  `obs` is indexed obs[k * stride].
 // `hinv` = calc_heading_quat_inv(root_rot) (TT:1684).  The fused path passes the value computed once
 // at create time (the pelvis is fixed); tensor-API mode computes it per env from the caller's tensor.
+// compute_humanoid_observations, body part (TT:1696-1697): obs[0:30] local positions, obs[30:60] local velocities
 template <class Store>
-PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float hinv[4], const float* q, const float* qd,
-                     V3 ball_p, V3 ball_v, Store& store) {
+PP_HD void write_obs_bodies(const V3* body_pos, const V3* body_vel, const float hinv[4], Store& store) {
     V3 root = body_pos[0];
 #pragma unroll
     for (int j = 0; j < NB; j++) {
@@ -849,6 +849,10 @@ PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float hinv[4]
         store(3 * j, lp.x); store(3 * j + 1, lp.y); store(3 * j + 2, lp.z);
         store(3 * NB + 3 * j, lv.x); store(3 * NB + 3 * j + 1, lv.y); store(3 * NB + 3 * j + 2, lv.z);
     }
+}
+// dof part (TT:1702-1703) and compute_pingpong_observations (TT:1640-1666): obs[60:80]
+template <class Store>
+PP_HD void write_obs_tail(V3 root, const float hinv[4], const float* q, const float* qd, V3 ball_p, V3 ball_v, Store& store) {
 #pragma unroll
     for (int d = 0; d < ND; d++) {                       // TT:1702-1703
         store(6 * NB + d, q[d]);
@@ -859,10 +863,18 @@ PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float hinv[4]
     store(6 * NB + 2 * ND, lb.x); store(6 * NB + 2 * ND + 1, lb.y); store(6 * NB + 2 * ND + 2, lb.z);
     store(6 * NB + 2 * ND + 3, lbv.x); store(6 * NB + 2 * ND + 4, lbv.y); store(6 * NB + 2 * ND + 5, lbv.z);
 }
+// Observation row: TT:770-799 -> compute_humanoid_observations TT:1669-1708 + compute_pingpong_observations TT:1640-1666
+template <class Store>
+PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float hinv[4], const float* q, const float* qd,
+                     V3 ball_p, V3 ball_v, Store& store) {
+    write_obs_bodies(body_pos, body_vel, hinv, store);
+    write_obs_tail(body_pos[0], hinv, q, qd, ball_p, ball_v, store);
+}
 
 // post_physics_step for one env of the fused path (TT:1022-1039): progress, reward,
 // masked reset, observations.  serve_override: used instead of the RNG when non-null.
-template <class Store>
+// BODY_OBS = false: the body block obs[0:60] has already been written (by the arm wave of step_kernel_split).
+template <bool BODY_OBS = true, class Store>
 PP_HD void post_physics_env(const StepConsts& K, uint32_t gid, EnvState& st, const BodyState* bodies, float pre_vx,
                             const V3* serve_override, float& rew, long long& reset, Store& store) {
     st.progress += 1;                                                            // TT:1023
@@ -886,10 +898,13 @@ PP_HD void post_physics_env(const StepConsts& K, uint32_t gid, EnvState& st, con
         st.flags = PPENV_FLAG_NO_BOUNCE;                                         // TT:903-905
     }
     // TT:1039: dof / ball already show the reset state, body states are the pre-reset ones
-    V3 bpos[NB], bvel[NB];
+    if (BODY_OBS) {
+        V3 bpos[NB], bvel[NB];
 #pragma unroll
-    for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
-    write_obs(bpos, bvel, K.hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
+        for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
+        write_obs_bodies(bpos, bvel, K.hinv, store);
+    }
+    write_obs_tail(bodies[0].pos, K.hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
 }
 
 }  // namespace pp
