@@ -85,6 +85,13 @@ def pmc_traffic(num_envs):
     return best
 
 
+def kernel_name(num_envs):
+    """The schedule ppenv_create picks (isaacgym_amd/csrc/ppenv.hip): two waves per 64 envs up to 32768 envs."""
+    forced = os.environ.get("PPENV_STEP_KERNEL")
+    split = (forced == "split") if forced else (num_envs <= 32768)
+    return "step_kernel_split<ModelG1>" if split else "step_kernel<ModelG1>"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,7 +194,7 @@ def main():
                        "num_envs_per_gpu": n, "global_envs": n * world, "horizon_stats_every": HORIZON,
                        "parallelism": f"env-shard x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(n), "kernel": "step_kernel<ModelG1>", "avg_kernel_us": kernel_us,
+                         "traffic": pmc_traffic(n), "kernel": kernel_name(n), "avg_kernel_us": kernel_us,
                          "timed_region_us_per_step": dev_ms * 1e3 / args.steps,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n},
             "episode_stats": {"mean_reward_last_step": final_stats[0], "mean_progress": final_stats[1],
