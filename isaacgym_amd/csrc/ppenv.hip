@@ -88,10 +88,6 @@ struct LdsRowStore {
     float* row;
     __device__ __forceinline__ void operator()(int k, float v) { row[k] = v; }
 };
-struct GlobalRowStore {
-    float* row;
-    __device__ __forceinline__ void operator()(int k, float v) { row[k] = v; }
-};
 
 // obs rows of one workgroup: LDS [kBlock][kObsStride] -> obs_buf[base*80 ...], 16 B per lane, contiguous
 __device__ __forceinline__ void flush_obs(const float* s_obs, float* obs, int base, int nvalid, int lane) {

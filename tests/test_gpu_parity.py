@@ -89,6 +89,54 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant)
     env.close()
 
 
+@pytest.mark.parametrize("schedule,n", [("split", 1000), ("fused", 1000), ("fused", 130), ("split", 63)])
+def test_both_schedules_on_ragged_sizes(torch_cuda, oracle_lib, monkeypatch, schedule, n):
+    """The two-wave and the one-wave step kernels run the same arithmetic; sizes that are not a multiple of 64."""
+    torch = torch_cuda
+    monkeypatch.setenv("PPENV_STEP_KERNEL", schedule)
+    cfg = scene.build_config("TT", num_envs=n, seed=21)
+    o = oracle_lib.OracleEnv(cfg)
+    env = make_env(scene.build_config("TT", num_envs=n, seed=21))
+    rng = np.random.default_rng(4)
+    oa, ra = obs_atol(), reward_atol(cfg)
+    for t in range(60):
+        actions = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        env.set_state(o.get_state())
+        o.step(actions)
+        env.step(torch.from_numpy(actions).cuda())
+        v = DevView(env)
+        np.testing.assert_array_equal(v.reset_buf, o.reset_buf, err_msg=f"reset step {t}")
+        np.testing.assert_array_equal(v.flags, o.flags, err_msg=f"flags step {t}")
+        assert_state_close(v, o, f"{schedule} step {t}")
+        assert_close(v.obs_buf, o.obs_buf, f"{schedule} obs step {t}", atol=oa)
+        assert_close(v.rew_buf, o.rew_buf, f"{schedule} rew step {t}", atol=ra)
+    env.close()
+
+
+def test_schedules_agree_step_by_step(torch_cuda, monkeypatch):
+    """Two compilations of the same per-env arithmetic (FMA contraction may differ in the last bits): restarted from a
+    common state every step they must agree to a few ulp, and take identical discrete decisions."""
+    torch = torch_cuda
+    n = 4096
+    envs = {}
+    for schedule in ("split", "fused"):
+        monkeypatch.setenv("PPENV_STEP_KERNEL", schedule)
+        envs[schedule] = make_env(scene.build_config("TN", num_envs=n, seed=2))
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for t in range(100):
+        a = torch.rand(n, 7, device="cuda", generator=gen) * 2 - 1
+        envs["fused"].set_state(envs["split"].get_state())
+        for e in envs.values():
+            e.step(a)
+        for name in ("reset_buf", "progress_buf", "flags", "episode"):
+            assert torch.equal(getattr(envs["split"], name), getattr(envs["fused"], name)), (name, t)
+        for name, atol in (("obs_buf", 2e-4), ("rew_buf", 2e-2), ("dof_pos", 1e-5), ("dof_vel", 1e-3), ("ball", 5e-3)):
+            x, y = getattr(envs["split"], name), getattr(envs["fused"], name)
+            assert torch.allclose(x, y, rtol=1e-5, atol=atol), (name, t, float((x - y).abs().max()))
+    for e in envs.values():
+        e.close()
+
+
 def test_initial_state_and_reset_all_match_oracle(torch_cuda, oracle_lib):
     n = 777   # ragged: not a multiple of the 64-lane workgroup
     for variant in ("TT", "T3", "TN"):
