@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL (default); gloo only to rehearse the rank logic on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -118,21 +119,26 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.dist_backend == "nccl":
+        sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible; one process per GPU is required")
+    device = torch.device("cuda", local_rank % max(ndev, 1))   # the modulo only matters for the gloo rehearsal
     torch.cuda.set_device(device)
+    if world > 1:
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
 
     n = args.num_envs
     off, cnt = D.shard_range(n * world, rank, world)   # contiguous global env ids; trajectories do not depend on the split
-    env = PPEnv(scene.build_config(VARIANT, num_envs=cnt, seed=0, device_id=local_rank, env_id_offset=off), device=device)
+    env = PPEnv(scene.build_config(VARIANT, num_envs=cnt, seed=0, device_id=device.index, env_id_offset=off), device=device)
     gen = torch.Generator(device=device).manual_seed(rank)
     pool = [(torch.rand(n, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
-    stats = [torch.zeros(3, device=device, dtype=torch.float64)]
+    stats = D.AsyncHorizonStats(env)   # what the reference prints every 40 steps (TT:763-766) + finished episodes
 
     def horizon_stats():
-        # what the reference prints every 40 steps (TT:763-766) + finished episodes: one small all-reduce over RCCL
-        stats[0] = D.env_horizon_stats(env)
+        stats.push()                   # one reduction launch + one asynchronous 4-double all-reduce over RCCL
 
     def run(k):
         for s in range(k):
@@ -171,7 +177,7 @@ def main():
     torch.cuda.synchronize(device)
     kernel_us = ev0.elapsed_time(ev1) * 1e3 / kreg
     horizon_stats()
-    final_stats = stats[0].cpu().tolist()
+    final_stats = stats.latest().cpu().tolist()
 
     if rank == 0:
         total_env_steps = n * world * args.steps

@@ -43,6 +43,39 @@ def env_horizon_stats(env, group=None):
     return torch.stack([s[0] / s[3], s[1] / s[3], s[2]])
 
 
+class AsyncHorizonStats:
+    """The same statistics without ever making the step stream wait for the collective: the all-reduce of
+    horizon k is issued asynchronously into one of `depth` rotating buffers and only joined when its buffer
+    comes round again (or in `latest()`).  A synchronous all-reduce would serialise ~30 us of RCCL latency into
+    every 32-step horizon of a ~16 us step."""
+
+    def __init__(self, env, depth=4, group=None):
+        self.env, self.group, self.depth = env, group, depth
+        self.bufs = [torch.zeros(4, dtype=torch.float64, device=env.device) for _ in range(depth)]
+        self.works = [None] * depth
+        self.k = -1
+        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def push(self):
+        self.k += 1
+        slot = self.k % self.depth
+        if self.works[slot] is not None:
+            self.works[slot].wait()
+            self.works[slot] = None
+        self.env.reduce_stats(out=self.bufs[slot])
+        if self.multi:
+            self.works[slot] = dist.all_reduce(self.bufs[slot], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def latest(self):
+        """[mean reward, mean progress, finished episodes] of the most recent horizon (joins outstanding work)."""
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        self.works = [None] * self.depth
+        s = self.bufs[self.k % self.depth] if self.k >= 0 else self.bufs[0]
+        return torch.stack([s[0] / s[3].clamp(min=1), s[1] / s[3].clamp(min=1), s[2]])
+
+
 def horizon_stats(rew_buf, progress_buf, episode, group=None):
     """[mean reward, mean progress, finished episodes] over ALL ranks' envs (tensor of 3 float64)."""
     n = torch.tensor(float(rew_buf.numel()), dtype=torch.float64, device=rew_buf.device)

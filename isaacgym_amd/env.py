@@ -77,12 +77,15 @@ class PPEnv:
     def reset_all(self):
         _lib.check(self.L.ppenv_reset_all(self.h, self._stream()))
 
-    def reduce_stats(self):
+    def reduce_stats(self, out=None):
         """float64[4] on the device: sum rew_buf, sum progress_buf, sum episode, num_envs (one reduction launch)."""
-        if not hasattr(self, "_stats"):
-            self._stats = torch.zeros(4, dtype=torch.float64, device=self.device)
-        _lib.check(self.L.ppenv_reduce_stats(self.h, self._stats.data_ptr(), self._stream()))
-        return self._stats
+        if out is None:
+            if not hasattr(self, "_stats"):
+                self._stats = torch.zeros(4, dtype=torch.float64, device=self.device)
+            out = self._stats
+        assert out.dtype == torch.float64 and out.numel() == 4 and out.device == self.device and out.is_contiguous()
+        _lib.check(self.L.ppenv_reduce_stats(self.h, out.data_ptr(), self._stream()))
+        return out
 
     # ---- Isaac-Gym tensor-API mode
     def post_physics_step(self, rigid_body_states, root_states, dof_states, dof_force, pre_ball_vx):

@@ -73,6 +73,50 @@ def test_two_rank_sharding_reproduces_the_single_process_run(oracle_lib, tmp_pat
     assert got["obs"].shape == (N_GLOBAL, 80)
 
 
+class _FakeEnv:
+    """Stands in for PPEnv in the CPU test of AsyncHorizonStats: reduce_stats over oracle arrays."""
+
+    def __init__(self, oracle_env):
+        self.o, self.device = oracle_env, torch.device("cpu")
+
+    def reduce_stats(self, out=None):
+        out[0], out[1] = float(self.o.rew_buf.astype(np.float64).sum()), float(self.o.progress_buf.sum())
+        out[2], out[3] = float(self.o.episode.sum()), float(self.o.num_envs)
+        return out
+
+
+def _async_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from isaacgym_amd import distributed as D
+    from isaacgym_amd import scene
+    from oracle import binding as ob
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    off, cnt = D.shard_range(N_GLOBAL, rank, world)
+    env = ob.OracleEnv(scene.build_config("TT", num_envs=cnt, seed=SEED, env_id_offset=off))
+    stats = D.AsyncHorizonStats(_FakeEnv(env), depth=2)
+    for t in range(STEPS):
+        env.step(_actions(t)[off:off + cnt])
+        if (t + 1) % 10 == 0:
+            stats.push()          # 6 horizons through 2 rotating buffers
+    if rank == 0:
+        np.save(os.path.join(out_dir, "async_stats.npy"), stats.latest().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_horizon_stats_two_ranks(oracle_lib, tmp_path):
+    from isaacgym_amd import scene
+    oracle_lib.build()
+    mp.spawn(_async_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "async_stats.npy")
+    env = oracle_lib.OracleEnv(scene.build_config("TT", num_envs=N_GLOBAL, seed=SEED))
+    for t in range(STEPS):
+        env.step(_actions(t))
+    want = [env.rew_buf.astype(np.float64).mean(), env.progress_buf.astype(np.float64).mean(), float(env.episode.sum())]
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-9)
+
+
 def test_single_process_helpers_are_identity():
     from isaacgym_amd import distributed as D
     x = torch.arange(12.0).view(6, 2)
