@@ -261,3 +261,27 @@ def test_vec_task_surface(torch_cuda):
     assert task.no_bounce_before_half_mask.dtype == torch.bool
     with pytest.raises(ValueError):
         isaacgym_amd.make(task="HumanoidPingpongTiltG1", num_envs=4, sim_device="cpu", rl_device="cpu")
+
+
+def test_rlgames_adapter_drives_the_native_task(torch_cuda):
+    """The train.py wiring (reference train.py:122-150,167): env creator thunk + RLGPUEnv, with a yaml-shaped task cfg."""
+    torch = torch_cuda
+    from isaacgym_amd.rlgames_utils import RLGPUEnv, get_rlgames_env_creator
+    yaml_like = {"name": "HumanoidPingpongTiltNoEarlyStopG1",   # keys as in cfg/task/HumanoidPingpongTiltNoEarlyStopG1.yaml
+                 "env": {"numEnvs": 256, "episodeLength": 170, "alphaVelocityReward": 1000, "powerCoefficient": 0.002, "penalty": -600,
+                         "hitTableReward": 2000, "nothitTablePenalty": -1000, "clipActions": 1.0,
+                         "bodyStatesId": [0, 31, 32, 33, 34, 35, 36, 37, 38, 39],
+                         "plane": {"staticFriction": 1.0, "dynamicFriction": 1.0, "restitution": 0.0}},
+                 "task": {"randomize": False}}
+    thunk = get_rlgames_env_creator(seed=3, task_config=yaml_like, task_name=yaml_like["name"], sim_device="cuda:0", rl_device="cuda:0",
+                                    graphics_device_id=-1, headless=True)
+    venv = RLGPUEnv("rlgpu", 256, env_creator=thunk)
+    info = venv.get_env_info()
+    assert info["observation_space"].shape == (80,) and info["action_space"].shape == (7,) and venv.get_number_of_agents() == 1
+    obs = venv.reset()["obs"]
+    total = torch.zeros(256, device="cuda")
+    for _ in range(200):
+        obs_d, rew, done, extras = venv.step(torch.rand(256, 7, device="cuda") * 2 - 1)
+        total += rew
+    assert obs_d["obs"].shape == (256, 80) and bool(torch.isfinite(total).all()) and int(done.sum()) >= 0
+    assert int(venv.env.env.episode.sum()) >= 256          # 170-step episodes: everyone timed out once

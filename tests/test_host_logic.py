@@ -156,3 +156,81 @@ def test_oracle_physics_known_answers(oracle_lib):
     off, _ = scene.pd_action_offset_scale(cfg)
     assert np.abs(env2.dof_vel[:, 0]).max() < 0.02
     assert np.abs(env2.dof_pos[:, 0] - off).max() < 0.35   # Kp = 20: gravity torque / Kp of droop at most
+
+
+def _ball_env(oracle_lib, variant="TN", **kw):
+    cfg = scene.build_config(variant, num_envs=1, seed=0, **kw)
+    env = oracle_lib.OracleEnv(cfg)
+    return cfg, env
+
+
+def test_contact_model_known_answers(oracle_lib):
+    """Closed-form checks of the ball contact specification through the oracle."""
+    zero = np.zeros((1, 7), np.float32)
+    # (a) oblique bounce on the table: e = 1 (clamped) reverses vz; Coulomb friction mu = 0.3 (avg of 0.2, 0.4 in TT)
+    #     slows vx by mu * jn while sliding and spins the ball up about +y by (jt / (k r)).
+    cfg, env = _ball_env(oracle_lib, "TT")
+    vx0, vz0 = 3.0, -2.0
+    env.ball[:, 0] = [2.6, 0.0, 0.76 + 0.02 + 0.004, 0, 0, 0, 1, vx0, 0.0, vz0, 0, 0, 0]
+    env.step(zero)
+    vx, vz, wy = float(env.ball[7, 0]), float(env.ball[9, 0]), float(env.ball[11, 0])
+    assert vz > 1.9                                          # bounced with e = 1 (minus a little gravity)
+    hb = cfg.dt / cfg.substeps / cfg.ball_substeps
+    damp = (1 - cfg.ball_angular_damping * hb)
+    jn_lo, jn_hi = 2 * 2.0, 2 * (2.0 + 9.8 * 0.0083)          # normal impulse per unit mass, bracketing the gravity kick
+    mu = cfg.table.friction
+    assert vx0 - mu * jn_hi - 1e-3 <= vx <= vx0 - mu * jn_lo + 1e-3      # slipping: tangential impulse = mu * jn
+    jt = vx0 - vx
+    k, r = cfg.ball_inertia_factor, cfg.ball_radius
+    # spin about +y of magnitude jt / (k r), then a few micro-steps of angular damping
+    assert abs(wy) == pytest.approx(jt / (k * r), rel=0.02) and wy > 0
+    # (b) slow oblique contact sticks: the stick impulse s k/(1+k) leaves v' = v/(1+k) (3/5 for a thin shell, the classic
+    #     5/7 for a solid sphere) and the ball rolls without slipping afterwards
+    cfg, env = _ball_env(oracle_lib, "TT")
+    env.ball[:, 0] = [2.6, 0.0, 0.76 + 0.02 + 0.0005, 0, 0, 0, 1, 0.05, 0.0, -3.0, 0, 0, 0]
+    env.step(zero)
+    vx, wy = float(env.ball[7, 0]), float(env.ball[11, 0])
+    assert vx == pytest.approx(0.05 / (1 + k), rel=0.03)
+    assert vx - wy * r == pytest.approx(0.0, abs=2e-3)              # rolling without slipping: v = w r
+    # (c) below the bounce threshold (0.2 m/s) restitution is off: the ball stays on the table
+    cfg, env = _ball_env(oracle_lib, "TN")
+    env.ball[:, 0] = [2.6, 0.0, 0.76 + 0.02 + 0.0001, 0, 0, 0, 1, 0.0, 0.0, -0.1, 0, 0, 0]
+    for _ in range(20):
+        env.step(zero)
+    assert abs(float(env.ball[2, 0]) - 0.78) < 2e-3 and abs(float(env.ball[9, 0])) < 0.06
+    # (d) the net stops a low ball: e = 0.5 against the default-material net (DESIGN.md), vx changes sign
+    cfg, env = _ball_env(oracle_lib, "TT")
+    env.ball[:, 0] = [1.80, 0.0, 0.85, 0, 0, 0, 1, -6.0, 0.0, 0.0, 0, 0, 0]
+    for _ in range(3):
+        env.step(zero)
+    assert float(env.ball[7, 0]) == pytest.approx(0.5 * 6.0, rel=0.05) and float(env.ball[0, 0]) > 1.75
+    # (e) a ball above the net height flies over it
+    cfg, env = _ball_env(oracle_lib, "TT")
+    env.ball[:, 0] = [1.80, 0.0, 1.0, 0, 0, 0, 1, -6.0, 0.0, 0.0, 0, 0, 0]
+    for _ in range(3):
+        env.step(zero)
+    assert float(env.ball[7, 0]) == pytest.approx(-6.0) and float(env.ball[0, 0]) < 1.7
+
+
+def test_paddle_contact_known_answer(oracle_lib):
+    """A ball thrown at the resting paddle face comes back with the combined restitution 0.8 (ball 1.0 clamped, humanoid 0.6)."""
+    cfg = scene.build_config("TN", num_envs=1, seed=0)
+    env = oracle_lib.OracleEnv(cfg)
+    zero = np.zeros((1, 7), np.float32)
+    for _ in range(2500):            # let the arm settle at its mid-range pose
+        env.step(zero)
+    rb = env.refresh_rigid_body_states()[0]
+    paddle_pos, paddle_q = rb[39, 0:3].astype(np.float64), rb[39, 3:7].astype(np.float64)
+    n_local = np.array(list(cfg.paddle_normal), np.float64)
+    normal = scene.quat_to_rot(paddle_q) @ n_local
+    speed = 4.0
+    start = paddle_pos + normal * 0.08
+    env.ball[:, 0] = list(start) + [0, 0, 0, 1] + list(-normal * speed) + [0, 0, 0]
+    blob = env.get_state()
+    vn = []
+    for _ in range(6):
+        env.step(zero)
+        vn.append(float(np.dot(env.ball[7:10, 0].astype(np.float64), normal)))
+    assert min(vn) < -3.5                                    # approached ...
+    assert max(vn) == pytest.approx(cfg.paddle_restitution * speed, rel=0.12)   # ... and left with e = 0.8 (gravity perturbs slightly)
+    assert cfg.paddle_restitution == pytest.approx(0.8)
