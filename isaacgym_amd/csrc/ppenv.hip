@@ -96,7 +96,10 @@ __device__ __forceinline__ void flush_obs(const float* s_obs, float* obs, int ba
     for (int k = lane * 4; k < total; k += kBlock * 4) {
         int r = k / PPENV_NUM_OBS, c = k - r * PPENV_NUM_OBS;
         const float* src = &s_obs[r * kObsStride + c];
-        dst[k >> 2] = make_float4(src[0], src[1], src[2], src[3]);
+        // non-temporal: the env never reads obs_buf back, so the rows need not displace its state in L2
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v val = {src[0], src[1], src[2], src[3]};
+        __builtin_nontemporal_store(val, reinterpret_cast<f4v*>(&dst[k >> 2]));
     }
 }
 

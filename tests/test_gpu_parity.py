@@ -263,6 +263,38 @@ def test_vec_task_surface(torch_cuda):
         isaacgym_amd.make(task="HumanoidPingpongTiltG1", num_envs=4, sim_device="cpu", rl_device="cpu")
 
 
+def test_step_is_graph_capturable(torch_cuda):
+    """ppenv_step only enqueues work on the caller's stream (no sync, no allocation), so a rollout step can be captured
+    into a HIP graph and replayed; the replayed steps must equal eager ones bit for bit."""
+    torch = torch_cuda
+    n = 2048
+    eager = make_env(scene.build_config("TT", num_envs=n, seed=9))
+    graphed = make_env(scene.build_config("TT", num_envs=n, seed=9))
+    actions = torch.zeros(n, 7, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step(actions)                 # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    eager.step(actions)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step(actions)                 # one captured launch reading `actions` in place
+    eager.step(actions)                       # capture does not execute: keep the twins in lockstep by ...
+    g.replay()                                # ... replaying once here
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for _ in range(50):
+        a = torch.rand(n, 7, device="cuda", generator=gen) * 2 - 1
+        actions.copy_(a)
+        g.replay()
+        eager.step(a)
+    torch.cuda.synchronize()
+    for name in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "ball", "dof_pos", "flags"):
+        assert torch.equal(getattr(eager, name), getattr(graphed, name)), name
+    eager.close()
+    graphed.close()
+
+
 def test_rlgames_adapter_drives_the_native_task(torch_cuda):
     """The train.py wiring (reference train.py:122-150,167): env creator thunk + RLGPUEnv, with a yaml-shaped task cfg."""
     torch = torch_cuda
