@@ -167,43 +167,41 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
 // ------------------------------------------------- the fused step, two waves per 64 envs
 // Same arithmetic as step_kernel, different schedule.  At N = 16384 step_kernel puts one wave on each CU
 // and leaves three of its four SIMDs idle, and a lone wave is bound by its own serial instruction
-// stream.  Here a workgroup is two waves that own the same 64 envs:
-//   wave 0 ("arm")  : actions -> PD targets, then per substep ABA + integration + FK, publishing the
-//                     collision geometry of every substep boundary (and finally the observed bodies and
-//                     the dof state) in LDS;
-//   wave 1 ("ball") : per substep the ball's micro-stepped contacts against that geometry — which run
-//                     while wave 0 is already in the next substep's ABA — then reward, masked reset,
-//                     observations and every store.
-// One s_barrier per substep is the only synchronisation; geometry sets rotate through three LDS slots
-// so the arm wave can run one substep ahead.
-constexpr int kGeomFloats = 24;   // paddle centre 3 + normal 3 + 3 moving shapes x 2 end points x 3
-static_assert(ModelG1::kShapes == 6, "LDS geometry record is laid out for the G1 shape list");
+// stream (one VALU instruction per >= 4 cycles).  Here a workgroup is two waves that own the same 64 envs:
+//   wave 0 ("arm")  : joint space only.  actions -> PD targets; per substep the velocity recursion, ABA and
+//                     integration, publishing q right after each integration; then, while the ball wave is in
+//                     its last substep, the world-frame FK of the final state, the 60 body-observation values,
+//                     the flush of those columns of the obs tile, and — once the reset decision is known —
+//                     the dof stores.
+//   wave 1 ("ball") : world space.  The collision geometry of every substep boundary (its own FK sweep of the
+//                     published q; the arm's velocities are not needed), the ball's micro-stepped contacts —
+//                     substep s runs while wave 0 is already in the ABA of substep s+1 — then reward, masked
+//                     reset, the last 20 observation values, their flush and the ball / bookkeeping stores.
+// One s_barrier per substep plus one at the end; q travels through two alternating LDS slots.
+struct NullVisitor {
+    __device__ __forceinline__ void operator()(int, const M3&, V3, V3, V3) {}
+};
 
-template <class T>
-__device__ __forceinline__ void geom_to_lds(float (*slot)[kBlock], int lane, const ArmGeom<T::kShapes>& g) {
-    int k = 0;
-    auto put = [&](V3 v) { slot[k][lane] = v.x; slot[k + 1][lane] = v.y; slot[k + 2][lane] = v.z; k += 3; };
-    put(g.pc); put(g.pn);
-#pragma unroll
-    for (int s = 0; s < T::kShapes; s++)
-        if (T::shape_link(s) >= 0) { put(g.a[s]); put(g.b[s]); }
-}
-template <class T>
-__device__ __forceinline__ void geom_from_lds(float (*slot)[kBlock], int lane, ArmGeom<T::kShapes>& g) {
-    int k = 0;
-    auto get = [&]() { V3 v = mk(slot[k][lane], slot[k + 1][lane], slot[k + 2][lane]); k += 3; return v; };
-    g.pc = get(); g.pn = get();
-#pragma unroll
-    for (int s = 0; s < T::kShapes; s++)
-        if (T::shape_link(s) >= 0) { g.a[s] = get(); g.b[s] = get(); }
+// obs tile -> obs_buf for the columns [C0, C1) of every row, as float4 (both bounds multiples of 4)
+template <int C0, int C1>
+__device__ __forceinline__ void flush_obs_cols(const float* s_obs, float* obs, int base, int nvalid, int lane) {
+    constexpr int per_row = (C1 - C0) / 4;
+    const int total = nvalid * per_row;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    for (int k = lane; k < total; k += kBlock) {
+        int r = k / per_row, c = C0 + 4 * (k - r * per_row);
+        const float* src = &s_obs[r * kObsStride + c];
+        f4v val = {src[0], src[1], src[2], src[3]};
+        __builtin_nontemporal_store(val, reinterpret_cast<f4v*>(obs + ((size_t)(base + r) * PPENV_NUM_OBS + c)));
+    }
 }
 
 template <class T>
 __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
     __shared__ float s_obs[kBlock * kObsStride];
-    __shared__ float s_geom[3][kGeomFloats][kBlock];
-    __shared__ float s_paddle[3][kBlock];            // paddle position after the last substep (the reward reads it)
-    __shared__ float s_dof[3 * ND][kBlock];          // q, qd, dof_force after the last substep
+    __shared__ float s_q[2][ND][kBlock];       // joint positions at a substep boundary, two alternating slots
+    __shared__ float s_dof[3 * ND][kBlock];    // q, qd, dof_force after the last substep
+    __shared__ int s_reset[kBlock];            // the ball wave's reset decision, for the arm wave's dof stores
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int n = K.num_envs;
@@ -215,10 +213,9 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
 
     if (wave == 0) {
         // ------------------------------------------------------------------ arm wave
+        PP_STAMP_AT(0);
         float q[ND], qd[ND], target[ND], tau[ND];
         JointSave js[ND];
-        ArmGeom<T::kShapes> g;
-        BodyState bodies[NB];
         if (active) {
 #pragma unroll
             for (int d = 0; d < ND; d++) {
@@ -229,47 +226,66 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
                 const float lo = T::drive(d).lower, hi = T::drive(d).upper;
                 target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;                                     // TT:1008, 664-665
             }
-            GeomVisitor<T> gv(g);
-            fk_sweep<T>(K, q, qd, js, gv);
-            geom_to_lds<T>(s_geom[0], lane, g);
         }
+        PP_STAMP_AT(1);
         for (int s = 0; s < substeps; s++) {
             if (active) {
+                NullVisitor nv;   // velocity recursion only: the world transforms of this sweep are dead code
+                fk_sweep<T>(K, q, qd, js, nv);
                 arm_substep<T>(K, js, q, qd, target, K.h, tau);
-                if (s + 1 < substeps) {
-                    GeomVisitor<T> gv(g);
-                    fk_sweep<T>(K, q, qd, js, gv);
-                } else {
-                    BodyVisitor<T, false> bv(g, bodies);
-                    fk_sweep<T>(K, q, qd, js, bv);
-                    static_body<false>(K, bodies[0]);
-                    s_paddle[0][lane] = bodies[NB - 1].pos.x; s_paddle[1][lane] = bodies[NB - 1].pos.y; s_paddle[2][lane] = bodies[NB - 1].pos.z;
+#pragma unroll
+                for (int d = 0; d < ND; d++) s_q[(s + 1) & 1][d][lane] = q[d];
+                if (s + 1 == substeps) {
 #pragma unroll
                     for (int d = 0; d < ND; d++) { s_dof[d][lane] = q[d]; s_dof[ND + d][lane] = qd[d]; s_dof[2 * ND + d][lane] = tau[d]; }
                 }
-                geom_to_lds<T>(s_geom[(s + 1) % 3], lane, g);
             }
-            __syncthreads();   // geometry of boundary s+1 (and, last time, paddle position + dof state) is published
+            PP_STAMP_AT(2 + 2 * s);
+            __syncthreads();   // q of boundary s+1 (and, last time, the final dof state) is published
+            PP_STAMP_AT(3 + 2 * s);
         }
-        // While the ball wave runs its last substep: the body block of the observation row, obs[0:60]
-        // (TT:1696-1697) — it depends on the pre-reset body states only (TT:1039).
+        // While the ball wave runs its last substep: world-frame FK of the final state and the body block of the
+        // observation row, obs[0:60] (TT:1696-1697) — it depends on the pre-reset body states only (TT:1039).
         if (active) {
+            ArmGeom<T::kShapes> g;
+            BodyState bodies[NB];
+            BodyVisitor<T, false> bv(g, bodies);
+            fk_sweep<T>(K, q, qd, js, bv);
+            static_body<false>(K, bodies[0]);
             V3 bpos[NB], bvel[NB];
 #pragma unroll
             for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
             LdsRowStore store{&s_obs[lane * kObsStride]};
             write_obs_bodies(bpos, bvel, K.hinv, store);
         }
-        __syncthreads();   // obs[0:60] of every row is in the tile
+        __builtin_amdgcn_wave_barrier();       // columns [0,60) were written by this wave only
+        flush_obs_cols<0, 6 * NB>(s_obs, b.obs, base, nvalid, lane);
+        PP_STAMP_AT(6);
+        __syncthreads();   // the ball wave's reset decision is in s_reset
+        PP_STAMP_AT(7);
+        if (active) {
+            const bool rst = s_reset[lane] != 0 && K.rc.variant != PPENV_VARIANT_TN;   // TN:888-901 keeps the dof state
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                b.dof_pos[(size_t)d * n + i] = rst ? K.init_dof_pos[d] : q[d];
+                b.dof_vel[(size_t)d * n + i] = rst ? K.init_dof_vel[d] : qd[d];
+                b.dof_force[(size_t)d * n + i] = tau[d];
+            }
+        }
         return;
     }
 
     // ---------------------------------------------------------------------- ball wave
+    PP_STAMP_AT(16);
     EnvState st;
     float rew = 0.f, pre_vx = 0.f;
     long long reset = 0;
+    V3 next_serve = mk(0, 0, 0);
     ArmGeom<T::kShapes> g0, g1;
     if (active) {
+        float q0[ND], zero[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) { q0[d] = b.dof_pos[(size_t)d * n + i]; zero[d] = 0.f; }
         float bl[13];
 #pragma unroll
         for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
@@ -284,33 +300,56 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
         pre_vx = st.ball.v.x;   // TT:1020
         static_geometry<T>(K, g0);
         static_geometry<T>(K, g1);
+        JointSave js[ND];        // dead: only the geometry of this sweep is used
+        GeomVisitor<T> gv(g0);
+        fk_sweep<T>(K, q0, zero, js, gv);
+        // This wave now waits for the arm's first substep anyway: draw the serve the env would get if it resets at the
+        // end of this step (counter RNG: a pure function of seed, env id and episode + 1), off the critical tail.
+        next_serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
+                              : serve_velocity(K, (uint32_t)(K.env_id_offset + i), st.episode + 1u);
     }
+    PP_STAMP_AT(17);
     for (int s = 0; s < substeps; s++) {
         __syncthreads();
+        PP_STAMP_AT(18 + 2 * s);
         if (active) {
-            geom_from_lds<T>(s_geom[s % 3], lane, g0);
-            geom_from_lds<T>(s_geom[(s + 1) % 3], lane, g1);
+            float qs[ND], zero[ND];
+#pragma unroll
+            for (int d = 0; d < ND; d++) { qs[d] = s_q[(s + 1) & 1][d][lane]; zero[d] = 0.f; }
+            JointSave js[ND];
+            GeomVisitor<T> gv(g1);
+            fk_sweep<T>(K, qs, zero, js, gv);
             ball_substep<T>(K, st.ball, g0, g1);
+            g0 = g1;
         }
+        PP_STAMP_AT(19 + 2 * s);
     }
     if (active) {
         BodyState bodies[NB];   // the task part reads the pelvis (row 0) and the paddle (row 9) only
         static_body<false>(K, bodies[0]);
-        bodies[NB - 1].pos = mk(s_paddle[0][lane], s_paddle[1][lane], s_paddle[2][lane]);
+        bodies[NB - 1].pos = g1.pc;   // the paddle body frame sits at the blade centre (scene.py: obs_body[9] == paddle_center)
 #pragma unroll
         for (int d = 0; d < ND; d++) { st.q[d] = s_dof[d][lane]; st.qd[d] = s_dof[ND + d][lane]; st.dof_force[d] = s_dof[2 * ND + d][lane]; }
-        V3 ov = mk(0, 0, 0);
-        if (serve_on) ov = mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i]);
         LdsRowStore store{&s_obs[lane * kObsStride]};
-        post_physics_env<false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, rew, reset, store);
+        post_physics_env<false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, &next_serve, rew, reset, store);
+        s_reset[lane] = (int)reset;
     }
-    __syncthreads();   // the arm wave's obs[0:60] and this wave's obs[60:80] are both in the tile
-    flush_obs(s_obs, b.obs, base, nvalid, lane);
+    PP_STAMP_AT(22);
+    __syncthreads();   // hands the reset decision to the arm wave
+    PP_STAMP_AT(23);
+    flush_obs_cols<6 * NB, PPENV_NUM_OBS>(s_obs, b.obs, base, nvalid, lane);   // columns [60,80) were written by this wave only
     if (active) {
-        store_state(b, n, i, st);
+        const float bl[13] = {st.ball.p.x, st.ball.p.y, st.ball.p.z, st.ball.quat[0], st.ball.quat[1], st.ball.quat[2], st.ball.quat[3],
+                              st.ball.v.x, st.ball.v.y, st.ball.v.z, st.ball.w.x, st.ball.w.y, st.ball.w.z};
+#pragma unroll
+        for (int k = 0; k < 13; k++) b.ball[(size_t)k * n + i] = bl[k];
+        b.progress[i] = st.progress;
+        b.flags[i] = st.flags;
+        b.episode[i] = st.episode;
         b.rew[i] = rew;
         b.reset[i] = reset;
     }
+    PP_STAMP_AT(24);
 }
 
 // create (mode 0: creation is episode 0) / reset_all (mode 1: next episode): state as after

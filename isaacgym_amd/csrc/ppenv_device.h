@@ -39,7 +39,7 @@
         unsigned long long t_;                                                              \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");      \
         __builtin_amdgcn_sched_barrier(0);                                                  \
-        if (threadIdx.x == 0) pp_stamp_buf[blockIdx.x * 32 + (k)] = t_;                      \
+        if ((threadIdx.x & 63) == 0) pp_stamp_buf[blockIdx.x * 32 + (k)] = t_;                      \
     } while (0)
 extern __device__ unsigned long long pp_stamp_buf[];
 #else
@@ -997,6 +997,10 @@ inline bool model_matches(const ppenv_config& c) {
         if (f.link != j - 1 || f.xyz[0] != 0.f || f.xyz[1] != 0.f || f.xyz[2] != 0.f) return false;
         for (int k = 0; k < 9; k++)
             if (f.rot[k] != ((k % 4 == 0) ? 1.f : 0.f)) return false;
+    }
+    {   // step_kernel_split takes the paddle body position from the blade centre of its geometry sweep
+        const JointKin t = T::tip_frame(NB - 1);
+        if (!same(t.origin_xyz, p.center, 3)) return false;
     }
     for (int j = ND + 1; j < NB; j++) {
         const JointKin t = T::tip_frame(j);

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "gpurun_out", "libppenv_stamp.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only",
-                "-fPIC", "-shared", "-DPP_STAMP=1", "-o", lib, os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv.hip")], check=True)
+                "-fPIC", "-shared", "-DPP_STAMP=1", "-o", lib, os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv.hip"), os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv_ta.hip")], check=True)
 os.environ["PPENV_LIB"] = lib
 import torch  # noqa: E402
 from isaacgym_amd import _lib, scene  # noqa: E402
@@ -31,11 +31,25 @@ buf = np.zeros(nb * 32, np.uint64)
 L.ppenv_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.ppenv_debug_read_stamps(buf.ctypes.data, buf.size) == 0
 t = buf.reshape(nb, 32).astype(np.int64)
-names = {0: "start", 1: "loads done", 2: "FK0", 3: "arm substep 1", 4: "FK1", 5: "ball substep 1", 6: "arm substep 2", 7: "FK2 (+bodies)",
-         8: "ball substep 2", 9: "reward/reset/obs", 10: "stores + obs flush"}
-prev = t[:, 0]
-tot = np.median(t[:, 10] - t[:, 0])
-print(f"N={n}: median wave lifetime between first and last stamp: {tot:.0f} shader cycles")
-for k in range(1, 11):
-    d = np.median(t[:, k] - t[:, k - 1])
-    print(f"  {names[k]:24s} {d:9.0f} cycles  {100 * d / tot:5.1f} %")
+if os.environ.get("PPENV_STEP_KERNEL", "split" if n <= 32768 else "fused") == "fused":
+    names = {0: "start", 1: "loads done", 2: "FK0", 3: "arm substep 1", 4: "FK1", 5: "ball substep 1", 6: "arm substep 2", 7: "FK2 (+bodies)",
+             8: "ball substep 2", 9: "reward/reset/obs", 10: "stores + obs flush"}
+    tot = np.median(t[:, 10] - t[:, 0])
+    print(f"N={n}: median wave lifetime between first and last stamp: {tot:.0f} shader cycles")
+    for k in range(1, 11):
+        d = np.median(t[:, k] - t[:, k - 1])
+        print(f"  {names[k]:24s} {d:9.0f} cycles  {100 * d / tot:5.1f} %")
+else:
+    t0 = np.minimum(t[:, 0], t[:, 16])
+    arm = {1: "arm: load + FK0 + publish g0", 2: "arm: ABA1 + FK1 + publish", 3: "arm: barrier 1 wait", 4: "arm: ABA2 + FK2 + publish",
+           5: "arm: barrier 2 wait", 6: "arm: body obs", 7: "arm: final barrier wait"}
+    ball = {17: "ball: loads", 18: "ball: wait for g1 (barrier 1)", 19: "ball: substep 1", 20: "ball: wait for g2 (barrier 2)",
+            21: "ball: substep 2", 22: "ball: reward/reset/obs tail", 23: "ball: final barrier wait", 24: "ball: flush + stores"}
+    tot = np.median(t[:, 24] - t0)
+    print(f"N={n}: median workgroup span (first stamp -> last stamp): {tot:.0f} shader cycles")
+    for k, name in arm.items():
+        prev = t[:, k - 1]
+        print(f"  {name:34s} {np.median(t[:, k] - prev):8.0f} cycles   (ends at {np.median(t[:, k] - t0):6.0f})")
+    for k, name in ball.items():
+        prev = t[:, k - 1]
+        print(f"  {name:34s} {np.median(t[:, k] - prev):8.0f} cycles   (ends at {np.median(t[:, k] - t0):6.0f})")
