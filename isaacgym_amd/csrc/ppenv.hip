@@ -167,17 +167,18 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
 // ------------------------------------------------- the fused step, two waves per 64 envs
 // Same arithmetic as step_kernel, different schedule.  At N = 16384 step_kernel puts one wave on each CU
 // and leaves three of its four SIMDs idle, and a lone wave is bound by its own serial instruction
-// stream (one VALU instruction per >= 4 cycles).  Here a workgroup is two waves that own the same 64 envs:
-//   wave 0 ("arm")  : joint space only.  actions -> PD targets; per substep the velocity recursion, ABA and
-//                     integration, publishing q right after each integration; then, while the ball wave is in
-//                     its last substep, the world-frame FK of the final state, the 60 body-observation values,
-//                     the flush of those columns of the obs tile, and — once the reset decision is known —
-//                     the dof stores.
-//   wave 1 ("ball") : world space.  The collision geometry of every substep boundary (its own FK sweep of the
-//                     published q; the arm's velocities are not needed), the ball's micro-stepped contacts —
-//                     substep s runs while wave 0 is already in the ABA of substep s+1 — then reward, masked
-//                     reset, the last 20 observation values, their flush and the ball / bookkeeping stores.
-// One s_barrier per substep plus one at the end; q travels through two alternating LDS slots.
+// stream (one VALU instruction per >= 4 cycles).  Here a workgroup is two waves that own the same 64 envs.
+// Within a substep the arm and the ball depend only on the state at the substep's start (ball_substep), so:
+//   wave 0 ("arm")  : joint space.  actions -> PD targets; per substep the velocity recursion, ABA and
+//                     integration, publishing (q, qd) in LDS after each one.
+//   wave 1 ("ball") : world space.  Per substep its own FK sweep of the published (q, qd) for the collision
+//                     geometry, then the ball's micro-stepped contacts; substep 0 starts straight from the
+//                     loaded state, substep s >= 1 as soon as the arm wave has published boundary s.
+// After the last integration the arm wave runs the FK of the final state, publishes the paddle position and
+// writes the 60 body-observation values; the ball wave computes reward, masked reset and the last 20 values;
+// then each flushes half of the obs tile and stores its half of the state.  The hand-offs arm -> ball are
+// one-way (an LDS sequence number the ball wave polls: the arm never waits); a single s_barrier before the
+// flush is the only rendezvous.  (q, qd) travel through two alternating LDS slots.
 struct NullVisitor {
     __device__ __forceinline__ void operator()(int, const M3&, V3, V3, V3) {}
 };
@@ -196,12 +197,27 @@ __device__ __forceinline__ void flush_obs_cols(const float* s_obs, float* obs, i
     }
 }
 
+// One-way hand-off inside the workgroup: the arm wave publishes data in LDS and then a sequence number; the
+// ball wave polls it.  (An s_barrier would make the producer wait for the consumer as well.)  Both waves of a
+// workgroup are co-resident, so the producer always makes progress; the poll is bounded all the same.
+__device__ __forceinline__ void publish(int* flag, int value) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void await(int* flag, int value) {
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= value) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
     __shared__ float s_obs[kBlock * kObsStride];
-    __shared__ float s_q[2][ND][kBlock];       // joint positions at a substep boundary, two alternating slots
-    __shared__ float s_dof[3 * ND][kBlock];    // q, qd, dof_force after the last substep
+    __shared__ float s_q[2][2 * ND][kBlock];   // (q, qd) at a substep boundary, two alternating slots
+    __shared__ float s_tau[ND][kBlock];        // drive torques of the last substep (dof_force)
+    __shared__ float s_paddle[3][kBlock];      // paddle position of the final state (the reward reads it)
     __shared__ int s_reset[kBlock];            // the ball wave's reset decision, for the arm wave's dof stores
+    __shared__ int s_flag;                     // boundaries published so far; substeps + 1 = paddle position too
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int n = K.num_envs;
@@ -210,6 +226,8 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
     const int nvalid = min(kBlock, n - base);
     const bool active = i < n;
     const int substeps = K.substeps;
+    if (threadIdx.x == 0) s_flag = 0;
+    __syncthreads();
 
     if (wave == 0) {
         // ------------------------------------------------------------------ arm wave
@@ -234,35 +252,38 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
                 fk_sweep<T>(K, q, qd, js, nv);
                 arm_substep<T>(K, js, q, qd, target, K.h, tau);
 #pragma unroll
-                for (int d = 0; d < ND; d++) s_q[(s + 1) & 1][d][lane] = q[d];
+                for (int d = 0; d < ND; d++) { s_q[(s + 1) & 1][d][lane] = q[d]; s_q[(s + 1) & 1][ND + d][lane] = qd[d]; }
                 if (s + 1 == substeps) {
 #pragma unroll
-                    for (int d = 0; d < ND; d++) { s_dof[d][lane] = q[d]; s_dof[ND + d][lane] = qd[d]; s_dof[2 * ND + d][lane] = tau[d]; }
+                    for (int d = 0; d < ND; d++) s_tau[d][lane] = tau[d];
                 }
             }
+            publish(&s_flag, s + 1);   // (q, qd) of boundary s+1 (and, last time, the drive torques)
             PP_STAMP_AT(2 + 2 * s);
-            __syncthreads();   // q of boundary s+1 (and, last time, the final dof state) is published
-            PP_STAMP_AT(3 + 2 * s);
         }
-        // While the ball wave runs its last substep: world-frame FK of the final state and the body block of the
-        // observation row, obs[0:60] (TT:1696-1697) — it depends on the pre-reset body states only (TT:1039).
+        // FK of the final state: paddle position for the reward, then the body block of the observation row,
+        // obs[0:60] (TT:1696-1697) — it depends on the pre-reset body states only (TT:1039)
+        BodyState bodies[NB];
         if (active) {
             ArmGeom<T::kShapes> g;
-            BodyState bodies[NB];
             BodyVisitor<T, false> bv(g, bodies);
             fk_sweep<T>(K, q, qd, js, bv);
             static_body<false>(K, bodies[0]);
+            s_paddle[0][lane] = bodies[NB - 1].pos.x; s_paddle[1][lane] = bodies[NB - 1].pos.y; s_paddle[2][lane] = bodies[NB - 1].pos.z;
+        }
+        publish(&s_flag, substeps + 1);
+        PP_STAMP_AT(5);
+        if (active) {
             V3 bpos[NB], bvel[NB];
 #pragma unroll
             for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
             LdsRowStore store{&s_obs[lane * kObsStride]};
             write_obs_bodies(bpos, bvel, K.hinv, store);
         }
-        __builtin_amdgcn_wave_barrier();       // columns [0,60) were written by this wave only
-        flush_obs_cols<0, 6 * NB>(s_obs, b.obs, base, nvalid, lane);
         PP_STAMP_AT(6);
-        __syncthreads();   // the ball wave's reset decision is in s_reset
+        __syncthreads();   // the whole obs tile and the ball wave's reset decision are in LDS
         PP_STAMP_AT(7);
+        flush_obs_cols<0, PPENV_NUM_OBS / 2>(s_obs, b.obs, base, nvalid, lane);
         if (active) {
             const bool rst = s_reset[lane] != 0 && K.rc.variant != PPENV_VARIANT_TN;   // TN:888-901 keeps the dof state
 #pragma unroll
@@ -281,11 +302,11 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
     float rew = 0.f, pre_vx = 0.f;
     long long reset = 0;
     V3 next_serve = mk(0, 0, 0);
-    ArmGeom<T::kShapes> g0, g1;
+    ArmGeom<T::kShapes> g;
+    float qs[ND], qds[ND];
     if (active) {
-        float q0[ND], zero[ND];
 #pragma unroll
-        for (int d = 0; d < ND; d++) { q0[d] = b.dof_pos[(size_t)d * n + i]; zero[d] = 0.f; }
+        for (int d = 0; d < ND; d++) { qs[d] = b.dof_pos[(size_t)d * n + i]; qds[d] = b.dof_vel[(size_t)d * n + i]; }
         float bl[13];
 #pragma unroll
         for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
@@ -298,46 +319,45 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
         st.flags = b.flags[i];
         st.episode = b.episode[i];
         pre_vx = st.ball.v.x;   // TT:1020
-        static_geometry<T>(K, g0);
-        static_geometry<T>(K, g1);
-        JointSave js[ND];        // dead: only the geometry of this sweep is used
-        GeomVisitor<T> gv(g0);
-        fk_sweep<T>(K, q0, zero, js, gv);
-        // This wave now waits for the arm's first substep anyway: draw the serve the env would get if it resets at the
-        // end of this step (counter RNG: a pure function of seed, env id and episode + 1), off the critical tail.
+        static_geometry<T>(K, g);
+        // the serve this env gets if it resets at the end of the step: the counter RNG is a pure function of
+        // (seed, env id, episode + 1), so it can be drawn now, off the tail of the step
         next_serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
                               : serve_velocity(K, (uint32_t)(K.env_id_offset + i), st.episode + 1u);
     }
     PP_STAMP_AT(17);
     for (int s = 0; s < substeps; s++) {
-        __syncthreads();
+        if (s > 0) {
+            await(&s_flag, s);   // the arm wave has published boundary s
+            if (active) {
+#pragma unroll
+                for (int d = 0; d < ND; d++) { qs[d] = s_q[s & 1][d][lane]; qds[d] = s_q[s & 1][ND + d][lane]; }
+            }
+        }
         PP_STAMP_AT(18 + 2 * s);
         if (active) {
-            float qs[ND], zero[ND];
-#pragma unroll
-            for (int d = 0; d < ND; d++) { qs[d] = s_q[(s + 1) & 1][d][lane]; zero[d] = 0.f; }
-            JointSave js[ND];
-            GeomVisitor<T> gv(g1);
-            fk_sweep<T>(K, qs, zero, js, gv);
-            ball_substep<T>(K, st.ball, g0, g1);
-            g0 = g1;
+            JointSave js[ND];        // dead: only the geometry (points + velocities) of this sweep is used
+            GeomVisitor<T> gv(g);
+            fk_sweep<T>(K, qs, qds, js, gv);
+            ball_substep<T>(K, st.ball, g);
         }
         PP_STAMP_AT(19 + 2 * s);
     }
+    await(&s_flag, substeps + 1);   // final dof state, drive torques and paddle position
     if (active) {
+#pragma unroll
+        for (int d = 0; d < ND; d++) { st.q[d] = s_q[substeps & 1][d][lane]; st.qd[d] = s_q[substeps & 1][ND + d][lane]; st.dof_force[d] = s_tau[d][lane]; }
         BodyState bodies[NB];   // the task part reads the pelvis (row 0) and the paddle (row 9) only
         static_body<false>(K, bodies[0]);
-        bodies[NB - 1].pos = g1.pc;   // the paddle body frame sits at the blade centre (scene.py: obs_body[9] == paddle_center)
-#pragma unroll
-        for (int d = 0; d < ND; d++) { st.q[d] = s_dof[d][lane]; st.qd[d] = s_dof[ND + d][lane]; st.dof_force[d] = s_dof[2 * ND + d][lane]; }
+        bodies[NB - 1].pos = mk(s_paddle[0][lane], s_paddle[1][lane], s_paddle[2][lane]);
         LdsRowStore store{&s_obs[lane * kObsStride]};
         post_physics_env<false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, &next_serve, rew, reset, store);
         s_reset[lane] = (int)reset;
     }
     PP_STAMP_AT(22);
-    __syncthreads();   // hands the reset decision to the arm wave
+    __syncthreads();   // the whole obs tile is in LDS; hands the reset decision to the arm wave
     PP_STAMP_AT(23);
-    flush_obs_cols<6 * NB, PPENV_NUM_OBS>(s_obs, b.obs, base, nvalid, lane);   // columns [60,80) were written by this wave only
+    flush_obs_cols<PPENV_NUM_OBS / 2, PPENV_NUM_OBS>(s_obs, b.obs, base, nvalid, lane);
     if (active) {
         const float bl[13] = {st.ball.p.x, st.ball.p.y, st.ball.p.z, st.ball.quat[0], st.ball.quat[1], st.ball.quat[2], st.ball.quat[3],
                               st.ball.v.x, st.ball.v.y, st.ball.v.z, st.ball.w.x, st.ball.w.y, st.ball.w.z};

@@ -257,11 +257,12 @@ struct ModelPaddle { float center[3], normal[3]; float radius, half_thickness; }
 // T::shape_link(s), T::shape(s), T::paddle(), T::tip_frame(j) — all constexpr, so with the per-joint
 // loops unrolled they fold into instruction literals and exact zeros / identities drop out.
 
-// world-frame collision geometry of the moving parts, sampled at a substep boundary
+// world-frame collision geometry of the arm at the start of a substep: points and their velocities
 template <int NSHAPES>
 struct ArmGeom {
-    V3 pc, pn;                 // paddle centre, blade normal
-    V3 a[NSHAPES], b[NSHAPES]; // capsule end points (static shapes: constants)
+    V3 pc, pn, vpc, pnd;          // paddle centre, blade normal, centre velocity, normal rate (omega x n)
+    V3 a[NSHAPES], b[NSHAPES];    // capsule end points (static shapes: constants)
+    V3 va[NSHAPES], vb[NSHAPES];  // their velocities (static shapes: zero)
 };
 
 // per-joint quantities pass 1 leaves for passes 2 and 3
@@ -306,18 +307,23 @@ template <class T>
 struct GeomVisitor {
     ArmGeom<T::kShapes>& g;
     PP_HD explicit GeomVisitor(ArmGeom<T::kShapes>& gg) : g(gg) {}
-    PP_HD void operator()(int i, const M3& Rw, V3 pw, V3, V3) {
+    PP_HD void operator()(int i, const M3& Rw, V3 pw, V3 w, V3 v) {
+        const V3 ww = mul(Rw, w), vw = mul(Rw, v);   // link angular / origin velocity in world axes
         if (i == ND - 1) {   // paddle_link is validated to be the last link at create time
             const ModelPaddle P = T::paddle();
-            g.pc = pw + mul(Rw, ld3(P.center));
+            V3 off = mul(Rw, ld3(P.center));
+            g.pc = pw + off;
+            g.vpc = vw + cross(ww, off);
             g.pn = mul(Rw, ld3(P.normal));
+            g.pnd = cross(ww, g.pn);
         }
 #pragma unroll
         for (int s = 0; s < T::kShapes; s++)
             if (T::shape_link(s) == i) {
                 const ModelShape sh = T::shape(s);
-                g.a[s] = pw + mul(Rw, ld3(sh.a));
-                g.b[s] = pw + mul(Rw, ld3(sh.b));
+                V3 oa = mul(Rw, ld3(sh.a)), ob = mul(Rw, ld3(sh.b));
+                g.a[s] = pw + oa; g.va[s] = vw + cross(ww, oa);
+                g.b[s] = pw + ob; g.vb[s] = vw + cross(ww, ob);
             }
     }
 };
@@ -325,7 +331,7 @@ template <class T>
 PP_HD void static_geometry(const StepConsts& K, ArmGeom<T::kShapes>& g) {
 #pragma unroll
     for (int s = 0; s < T::kShapes; s++)
-        if (T::shape_link(s) < 0) { g.a[s] = ld3(K.static_a[s]); g.b[s] = ld3(K.static_b[s]); }
+        if (T::shape_link(s) < 0) { g.a[s] = ld3(K.static_a[s]); g.b[s] = ld3(K.static_b[s]); g.va[s] = mk(0, 0, 0); g.vb[s] = mk(0, 0, 0); }
 }
 
 // geometry + the observed bodies (obs_body[1..7] are the chain links, [8],[9] ride on the last link).
@@ -583,12 +589,14 @@ PP_HD void contact_disc(const BallConsts& k, Ball& b, V3 cc, V3 nn, V3 uc, V3 nd
 
 PP_HD V3 lerp(V3 a, V3 b, float f) { return madd(a, b - a, f); }
 
-// one physics substep of the ball: ball_substeps micro-steps against the static scene
-// and the arm geometry interpolated between the substep's two ends (g0 -> g1)
+// One physics substep of the ball: ball_substeps micro-steps against the static scene and the arm's shapes,
+// which move linearly from their pose at the START of the substep with the velocities they have there
+// (contacts are generated from start-of-step poses, as PhysX does).  Within a substep the ball and the arm
+// therefore do not depend on each other — which is what lets the two-wave kernel run them concurrently.
 template <class T>
-PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes>& g0, const ArmGeom<T::kShapes>& g1) {
+PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes>& g) {
     const int M = K.ball_substeps;
-    const float inv_m = K.inv_m, hb = K.hb, inv_h = K.inv_h, h = K.h;
+    const float hb = K.hb, h = K.h;
     BallConsts k;
     k.contact_offset = K.contact_offset;
     k.bounce_threshold = K.bounce_threshold;
@@ -604,23 +612,21 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes>&
     // broad-phase spheres of the humanoid shapes for this substep
     const ModelPaddle P = T::paddle();
     const float pad_e = K.paddle_e, pad_mu = K.paddle_mu;
-    const V3 pdc = g1.pc - g0.pc;
     const float reach = k.r + k.contact_offset + 1e-4f;
     const float pad_rr = sqrtf(P.radius * P.radius + P.half_thickness * P.half_thickness) + reach;
     const float pad_r2 = pad_rr * pad_rr;
-    V3 sc0[T::kShapes], sdc[T::kShapes];
+    V3 sc0[T::kShapes], svc[T::kShapes];
     float sr2[T::kShapes];
 #pragma unroll
     for (int s = 0; s < T::kShapes; s++) {
-        V3 c0 = (g0.a[s] + g0.b[s]) * 0.5f;
-        sc0[s] = c0;
-        sdc[s] = T::shape_link(s) < 0 ? mk(0, 0, 0) : (g1.a[s] + g1.b[s]) * 0.5f - c0;
-        V3 hl = (g0.b[s] - g0.a[s]) * 0.5f;   // rigid shape: the half length is the same at both ends of the substep
+        sc0[s] = (g.a[s] + g.b[s]) * 0.5f;
+        svc[s] = (g.va[s] + g.vb[s]) * 0.5f;
+        V3 hl = (g.b[s] - g.a[s]) * 0.5f;
         float rr = sqrtf(dot(hl, hl)) + T::shape(s).radius + reach;
         sr2[s] = rr * rr;
     }
     for (int m = 0; m < M; m++) {
-        float f = (float)m * inv_m;
+        const float t = (float)m * hb;   // time since the start of the substep
         b.v.z += gdv;
         b.w = b.w * damp;
         contact_resolve(k, b, mk(0, 0, 1), b.p.z - ground_z - k.r, mk(0, 0, 0), ground_e, ground_mu);
@@ -636,23 +642,22 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes>&
             // narrow phase behind it is unchanged, and a ball outside the sphere cannot touch the shape,
             // so results are identical; but some lane of a wave is nearly always near the arm, and the
             // wave then pays ~10 instructions per shape instead of the full closest-point code.
-            V3 dpc = b.p - madd(g0.pc, pdc, f);
+            V3 cc = madd(g.pc, g.vpc, t);
+            V3 dpc = b.p - cc;
             if (dot(dpc, dpc) < pad_r2) {
-                V3 nn = lerp(g0.pn, g1.pn, f);
+                V3 nn = madd(g.pn, g.pnd, t);
                 nn = nn * rsq_fast(dot(nn, nn));
-                contact_disc(k, b, madd(g0.pc, pdc, f), nn, pdc * inv_h, (g1.pn - g0.pn) * inv_h, P.radius, P.half_thickness,
-                             pad_e, pad_mu);
+                contact_disc(k, b, cc, nn, g.vpc, g.pnd, P.radius, P.half_thickness, pad_e, pad_mu);
             }
 #pragma unroll
             for (int s = 0; s < T::kShapes; s++) {
-                V3 dsc = b.p - madd(sc0[s], sdc[s], f);
+                V3 dsc = b.p - madd(sc0[s], svc[s], t);
                 if (dot(dsc, dsc) < sr2[s]) {
                     const float radius = T::shape(s).radius, e = K.shape_e[s], mu = K.shape_mu[s];
                     if (T::shape_link(s) < 0)
-                        contact_capsule(k, b, g0.a[s], g0.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
+                        contact_capsule(k, b, g.a[s], g.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
                     else
-                        contact_capsule(k, b, lerp(g0.a[s], g1.a[s], f), lerp(g0.b[s], g1.b[s], f), (g1.a[s] - g0.a[s]) * inv_h,
-                                        (g1.b[s] - g0.b[s]) * inv_h, radius, e, mu);
+                        contact_capsule(k, b, madd(g.a[s], g.va[s], t), madd(g.b[s], g.vb[s], t), g.va[s], g.vb[s], radius, e, mu);
                 }
             }
         }
@@ -785,28 +790,26 @@ PP_HD void simulate_env(const StepConsts& K, const float* actions, EnvState& st,
     const int substeps = K.substeps;
     const float h = K.h;
     JointSave js[ND];
-    ArmGeom<T::kShapes> g0, g1;
-    static_geometry<T>(K, g0);
-    static_geometry<T>(K, g1);
+    ArmGeom<T::kShapes> g;
+    static_geometry<T>(K, g);
     {
-        GeomVisitor<T> gv(g0);
+        GeomVisitor<T> gv(g);
         fk_sweep<T>(K, st.q, st.qd, js, gv);
     }
     PP_STAMP_AT(2);
     for (int s = 0; s < substeps; s++) {
-        arm_substep<T>(K, js, st.q, st.qd, target, h, st.dof_force);
+        ball_substep<T>(K, st.ball, g);                                   // against the arm as it is at the substep's start
         PP_STAMP_AT(3 + 3 * s);
+        arm_substep<T>(K, js, st.q, st.qd, target, h, st.dof_force);
+        PP_STAMP_AT(4 + 3 * s);
         if (s + 1 < substeps) {
-            GeomVisitor<T> gv(g1);
+            GeomVisitor<T> gv(g);
             fk_sweep<T>(K, st.q, st.qd, js, gv);
         } else {
-            BodyVisitor<T, false> bv(g1, bodies);
+            BodyVisitor<T, false> bv(g, bodies);
             fk_sweep<T>(K, st.q, st.qd, js, bv);
         }
-        PP_STAMP_AT(4 + 3 * s);
-        ball_substep<T>(K, st.ball, g0, g1);
         PP_STAMP_AT(5 + 3 * s);
-        g0 = g1;
     }
     static_body<false>(K, bodies[0]);
 }
@@ -839,11 +842,11 @@ PP_HD void reset_state(const StepConsts& K, EnvState& st, V3 serve, bool reset_d
 // `hinv` = calc_heading_quat_inv(root_rot) (TT:1684).  The fused path passes the value computed once
 // at create time (the pelvis is fixed); tensor-API mode computes it per env from the caller's tensor.
 // compute_humanoid_observations, body part (TT:1696-1697): obs[0:30] local positions, obs[30:60] local velocities
-template <class Store>
+template <int J0 = 0, int J1 = NB, class Store>
 PP_HD void write_obs_bodies(const V3* body_pos, const V3* body_vel, const float hinv[4], Store& store) {
     V3 root = body_pos[0];
 #pragma unroll
-    for (int j = 0; j < NB; j++) {
+    for (int j = J0; j < J1; j++) {
         V3 lp = quat_rotate(hinv, body_pos[j] - root);   // TT:1696
         V3 lv = quat_rotate(hinv, body_vel[j]);          // TT:1697
         store(3 * j, lp.x); store(3 * j + 1, lp.y); store(3 * j + 2, lp.z);

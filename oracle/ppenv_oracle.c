@@ -258,10 +258,6 @@ static void frame_state(const ppenv_config* c, const arm_fk* k, const ppenv_fram
     *ang = k->w[f->link];
     *lin = vadd(k->v[f->link], vcross(k->w[f->link], off));
 }
-static v3 link_point(const arm_fk* k, int link, const float* local) {
-    if (link < 0) return vf(local);
-    return vadd(k->p[link], mv(&k->R[link], vf(local)));
-}
 
 /* ---------------------------------------------------------------- ball contacts */
 typedef struct { v3 p, v, w; } ball_t;
@@ -350,27 +346,36 @@ static void contact_disc(const ppenv_config* c, ball_t* b, v3 cc, v3 nn, v3 uc, 
     contact_resolve(c, b, n, s, u, c->paddle_restitution, c->paddle_friction, hb);
 }
 
-/* moving collision geometry sampled at both ends of a substep */
+/* collision geometry of the arm at the start of a substep: points and their velocities */
 typedef struct {
-    v3 pc, pn;                    /* paddle centre, axis */
-    v3 sa[PPENV_MAX_SHAPES], sb[PPENV_MAX_SHAPES];
+    v3 pc, pn, vpc, pnd;          /* paddle centre, axis, centre velocity, axis rate (omega x n) */
+    v3 sa[PPENV_MAX_SHAPES], sb[PPENV_MAX_SHAPES], va[PPENV_MAX_SHAPES], vb[PPENV_MAX_SHAPES];
 } arm_geom;
 
+static void link_point_state(const arm_fk* k, int link, const float* local, v3* p, v3* v) {
+    if (link < 0) { *p = vf(local); *v = V(0, 0, 0); return; }
+    v3 off = mv(&k->R[link], vf(local));
+    *p = vadd(k->p[link], off);
+    *v = vadd(k->v[link], vcross(k->w[link], off));
+}
 static void arm_geometry(const ppenv_config* c, const arm_fk* k, arm_geom* g) {
-    g->pc = link_point(k, c->paddle_link, c->paddle_center);
+    link_point_state(k, c->paddle_link, c->paddle_center, &g->pc, &g->vpc);
     g->pn = mv(&k->R[c->paddle_link], vf(c->paddle_normal));
+    g->pnd = vcross(k->w[c->paddle_link], g->pn);
     for (int s = 0; s < c->num_shapes; s++) {
-        g->sa[s] = link_point(k, c->shape[s].link, c->shape[s].a);
-        g->sb[s] = link_point(k, c->shape[s].link, c->shape[s].b);
+        link_point_state(k, c->shape[s].link, c->shape[s].a, &g->sa[s], &g->va[s]);
+        link_point_state(k, c->shape[s].link, c->shape[s].b, &g->sb[s], &g->vb[s]);
     }
 }
-static v3 vlerp(v3 a, v3 b, double f) { return vadd(a, vscale(vsub(b, a), f)); }
 
-static void ball_substep(const ppenv_config* c, ball_t* b, double quat[4], const arm_geom* g0, const arm_geom* g1, double h) {
+/* One substep of the ball.  The arm's shapes move linearly from their pose at the START of the substep with
+ * the velocities they have there (contacts are generated from start-of-step poses, as PhysX does); within the
+ * substep the ball and the arm therefore do not depend on each other. */
+static void ball_substep(const ppenv_config* c, ball_t* b, double quat[4], const arm_geom* g, double h) {
     int M = c->ball_substeps;
     double hb = h / M;
     for (int m = 0; m < M; m++) {
-        double f = (double)m / M;
+        double t = (double)m / M * h;
         b->v.z += c->gravity_z * hb;
         double damp = 1.0 - c->ball_angular_damping * hb;
         b->w = vscale(b->w, damp > 0 ? damp : 0);
@@ -380,15 +385,14 @@ static void ball_substep(const ppenv_config* c, ball_t* b, double quat[4], const
         contact_box(c, b, &c->table, hb);
         contact_box(c, b, &c->net, hb);
         if (vnorm(vsub(b->p, vf(c->humanoid_bound_center))) < c->humanoid_bound_radius) {
-            v3 cc = vlerp(g0->pc, g1->pc, f);
-            v3 nn = vlerp(g0->pn, g1->pn, f);
+            v3 cc = vadd(g->pc, vscale(g->vpc, t));
+            v3 nn = vadd(g->pn, vscale(g->pnd, t));
             nn = vscale(nn, 1.0 / vnorm(nn));
-            contact_disc(c, b, cc, nn, vscale(vsub(g1->pc, g0->pc), 1.0 / h), vscale(vsub(g1->pn, g0->pn), 1.0 / h), hb);
+            contact_disc(c, b, cc, nn, g->vpc, g->pnd, hb);
             for (int s = 0; s < c->num_shapes; s++) {
                 const ppenv_shape* sh = &c->shape[s];
-                v3 a = vlerp(g0->sa[s], g1->sa[s], f), bb = vlerp(g0->sb[s], g1->sb[s], f);
-                v3 ua = vscale(vsub(g1->sa[s], g0->sa[s]), 1.0 / h), ub = vscale(vsub(g1->sb[s], g0->sb[s]), 1.0 / h);
-                contact_capsule(c, b, a, bb, ua, ub, sh->radius, sh->restitution, sh->friction, hb);
+                v3 a = vadd(g->sa[s], vscale(g->va[s], t)), bb = vadd(g->sb[s], vscale(g->vb[s], t));
+                contact_capsule(c, b, a, bb, g->va[s], g->vb[s], sh->radius, sh->restitution, sh->friction, hb);
             }
         }
         b->p = vadd(b->p, vscale(b->v, hb));
@@ -694,11 +698,10 @@ static void step_env(ppo_env* e, int i, const float* actions) {
             if (q_new < j->lower) { q_new = j->lower; if (v_new < 0) v_new = 0; }
             q[d] = q_new; qd[d] = v_new;
         }
+        arm_geom g;
+        arm_geometry(c, &k0, &g);              /* pose and velocities at the start of the substep */
+        ball_substep(c, &b, bq, &g, h);
         arm_forward_kinematics(c, q, qd, &k1);
-        arm_geom g0, g1;
-        arm_geometry(c, &k0, &g0);
-        arm_geometry(c, &k1, &g1);
-        ball_substep(c, &b, bq, &g0, &g1, h);
         k0 = k1;
     }
 

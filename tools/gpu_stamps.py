@@ -41,14 +41,14 @@ if os.environ.get("PPENV_STEP_KERNEL", "split" if n <= 32768 else "fused") == "f
         print(f"  {names[k]:24s} {d:9.0f} cycles  {100 * d / tot:5.1f} %")
 else:
     t0 = np.minimum(t[:, 0], t[:, 16])
-    arm = {1: "arm: load + FK0 + publish g0", 2: "arm: ABA1 + FK1 + publish", 3: "arm: barrier 1 wait", 4: "arm: ABA2 + FK2 + publish",
-           5: "arm: barrier 2 wait", 6: "arm: body obs", 7: "arm: final barrier wait"}
-    ball = {17: "ball: loads", 18: "ball: wait for g1 (barrier 1)", 19: "ball: substep 1", 20: "ball: wait for g2 (barrier 2)",
-            21: "ball: substep 2", 22: "ball: reward/reset/obs tail", 23: "ball: final barrier wait", 24: "ball: flush + stores"}
+    arm = {1: "arm: loads + targets", 2: "arm: substep 1 (vel sweep + ABA) + publish", 4: "arm: substep 2 + publish",
+           5: "arm: FK of final state + publish paddle", 6: "arm: body obs", 7: "arm: final barrier wait"}
+    ball = {17: "ball: loads + next serve", 18: "ball: (no wait)", 19: "ball: FK + substep 1", 20: "ball: wait for boundary 1",
+            21: "ball: FK + substep 2", 22: "ball: wait final + reward/reset/obs tail", 23: "ball: final barrier wait", 24: "ball: flush + stores"}
     tot = np.median(t[:, 24] - t0)
     print(f"N={n}: median workgroup span (first stamp -> last stamp): {tot:.0f} shader cycles")
     for k, name in arm.items():
-        prev = t[:, k - 1]
+        prev = t[:, k - 1] if k != 4 else t[:, 2]
         print(f"  {name:34s} {np.median(t[:, k] - prev):8.0f} cycles   (ends at {np.median(t[:, k] - t0):6.0f})")
     for k, name in ball.items():
         prev = t[:, k - 1]
