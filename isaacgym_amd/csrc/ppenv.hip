@@ -176,9 +176,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
 //                     loaded state, substep s >= 1 as soon as the arm wave has published boundary s.
 // After the last integration the arm wave runs the FK of the final state, publishes the paddle position and
 // writes the 60 body-observation values; the ball wave computes reward, masked reset and the last 20 values;
-// then each flushes half of the obs tile and stores its half of the state.  The hand-offs arm -> ball are
-// one-way (an LDS sequence number the ball wave polls: the arm never waits); a single s_barrier before the
-// flush is the only rendezvous.  (q, qd) travel through two alternating LDS slots.
+// then each flushes the obs columns it wrote and stores its half of the state.  Every hand-off is one-way (an
+// LDS sequence number the consumer polls: the producer never waits); the only s_barrier is the one after the
+// flags are initialised.  (q, qd) travel through two alternating LDS slots.
 struct NullVisitor {
     __device__ __forceinline__ void operator()(int, const M3&, V3, V3, V3) {}
 };
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
     __shared__ float s_tau[ND][kBlock];        // drive torques of the last substep (dof_force)
     __shared__ float s_paddle[3][kBlock];      // paddle position of the final state (the reward reads it)
     __shared__ int s_reset[kBlock];            // the ball wave's reset decision, for the arm wave's dof stores
-    __shared__ int s_flag;                     // boundaries published so far; substeps + 1 = paddle position too
+    __shared__ int s_flag;                     // arm -> ball: boundaries published so far; substeps + 1 = paddle position too
+    __shared__ int s_flag_ball;                // ball -> arm: 1 once the reset decision is in s_reset
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int n = K.num_envs;
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
     const int nvalid = min(kBlock, n - base);
     const bool active = i < n;
     const int substeps = K.substeps;
-    if (threadIdx.x == 0) s_flag = 0;
-    __syncthreads();
+    if (threadIdx.x == 0) { s_flag = 0; s_flag_ball = 0; }
+    __syncthreads();   // the only rendezvous of the launch: the flags are initialised
 
     if (wave == 0) {
         // ------------------------------------------------------------------ arm wave
@@ -281,9 +282,10 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
             write_obs_bodies(bpos, bvel, K.hinv, store);
         }
         PP_STAMP_AT(6);
-        __syncthreads();   // the whole obs tile and the ball wave's reset decision are in LDS
+        __builtin_amdgcn_wave_barrier();   // columns [0,60) were written by this wave only: no rendezvous needed
+        flush_obs_cols<0, 6 * NB>(s_obs, b.obs, base, nvalid, lane);
+        await(&s_flag_ball, 1);            // the ball wave's reset decision
         PP_STAMP_AT(7);
-        flush_obs_cols<0, PPENV_NUM_OBS / 2>(s_obs, b.obs, base, nvalid, lane);
         if (active) {
             const bool rst = s_reset[lane] != 0 && K.rc.variant != PPENV_VARIANT_TN;   // TN:888-901 keeps the dof state
 #pragma unroll
@@ -354,10 +356,11 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
         post_physics_env<false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, &next_serve, rew, reset, store);
         s_reset[lane] = (int)reset;
     }
+    publish(&s_flag_ball, 1);          // hands the reset decision to the arm wave
     PP_STAMP_AT(22);
-    __syncthreads();   // the whole obs tile is in LDS; hands the reset decision to the arm wave
+    __builtin_amdgcn_wave_barrier();   // columns [60,80) were written by this wave only
     PP_STAMP_AT(23);
-    flush_obs_cols<PPENV_NUM_OBS / 2, PPENV_NUM_OBS>(s_obs, b.obs, base, nvalid, lane);
+    flush_obs_cols<6 * NB, PPENV_NUM_OBS>(s_obs, b.obs, base, nvalid, lane);
     if (active) {
         const float bl[13] = {st.ball.p.x, st.ball.p.y, st.ball.p.z, st.ball.quat[0], st.ball.quat[1], st.ball.quat[2], st.ball.quat[3],
                               st.ball.v.x, st.ball.v.y, st.ball.v.z, st.ball.w.x, st.ball.w.y, st.ball.w.z};
