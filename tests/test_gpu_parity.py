@@ -263,6 +263,38 @@ def test_vec_task_surface(torch_cuda):
         isaacgym_amd.make(task="HumanoidPingpongTiltG1", num_envs=4, sim_device="cpu", rl_device="cpu")
 
 
+@pytest.mark.parametrize("variant", ["TT", "TN", "T3"])
+def test_long_run_stays_physical(torch_cuda, variant):
+    """3000 steps of random actions: nothing blows up, limits hold, the ball stays in the scene, episodes turn over."""
+    torch = torch_cuda
+    n = 4096
+    env = make_env(scene.build_config(variant, num_envs=n, seed=17))
+    lo = torch.tensor([env.config.joint[j].lower for j in range(7)], device="cuda")[:, None]
+    hi = torch.tensor([env.config.joint[j].upper for j in range(7)], device="cuda")[:, None]
+    vmax = torch.tensor([env.config.joint[j].vel_limit for j in range(7)], device="cuda")[:, None]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    rew_sum = torch.zeros(n, device="cuda", dtype=torch.float64)
+    max_speed = torch.zeros((), device="cuda")
+    for t in range(3000):
+        env.step(torch.rand(n, 7, device="cuda", generator=gen) * 2 - 1)
+        rew_sum += env.rew_buf
+        if t % 50 == 0:
+            max_speed = torch.maximum(max_speed, env.ball[7:10].norm(dim=0).max())
+    assert bool(torch.isfinite(env.obs_buf).all()) and bool(torch.isfinite(rew_sum).all()) and bool(torch.isfinite(env.ball).all())
+    assert bool((env.dof_pos >= lo - 1e-6).all()) and bool((env.dof_pos <= hi + 1e-6).all())
+    assert bool((env.dof_vel.abs() <= vmax + 1e-4).all())
+    # the effort limit is tested on the explicit PD estimate (DESIGN.md §3.2.1); the torque the implicit branch ends up
+    # applying, Kp(e - h qd+) - Kd qd+, is not re-clamped and exceeds it when inertial coupling swings qd+ far from qd
+    effort = torch.tensor([env.config.joint[j].effort for j in range(7)], device="cuda")[:, None]
+    assert bool((env.dof_force.abs() <= 4.0 * effort).all()), float((env.dof_force.abs() / effort).max())
+    assert float((env.ball[3:7].pow(2).sum(0) - 1).abs().max()) < 1e-4
+    assert float(env.ball[2].min()) > -0.05 and float(env.ball[0:3].abs().max()) < 50.0
+    assert float(max_speed) < 60.0                           # restitution <= 1: the ball cannot keep gaining energy
+    episodes = env.episode.to(torch.int64)
+    assert int(episodes.min()) >= (3000 // env.config.max_episode_length)   # every env hit at least its time-outs
+    env.close()
+
+
 def test_step_is_graph_capturable(torch_cuda):
     """ppenv_step only enqueues work on the caller's stream (no sync, no allocation), so a rollout step can be captured
     into a HIP graph and replayed; the replayed steps must equal eager ones bit for bit."""
