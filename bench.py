@@ -86,9 +86,8 @@ def pmc_traffic(num_envs):
 
 
 def kernel_name(num_envs):
-    """The schedule ppenv_create picks (isaacgym_amd/csrc/ppenv.hip): two waves per 64 envs up to 32768 envs."""
-    forced = os.environ.get("PPENV_STEP_KERNEL")
-    split = (forced == "split") if forced else (num_envs <= 32768)
+    """The schedule ppenv_create picks (isaacgym_amd/csrc/ppenv.hip): two waves per 64 envs unless the one-wave kernel is forced."""
+    split = os.environ.get("PPENV_STEP_KERNEL") != "fused"
     return "step_kernel_split<ModelG1>" if split else "step_kernel<ModelG1>"
 
 

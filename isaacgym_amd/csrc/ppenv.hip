@@ -696,10 +696,10 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
     e->lay = layout_for(cfg->num_envs);
     e->serve_on = 0;
     {   // PPENV_STEP_KERNEL=fused|split forces a schedule (same arithmetic either way)
-        // Two waves per 64 envs pay off while the one-wave grid leaves SIMDs idle (N <= 32768: at most 512 of
-        // 1024 SIMDs); beyond that the extra waves only compete (measured: N = 65536 22.7 vs 33.4 us).
+        // The two-wave schedule wins at every size measured (us per step, split vs one-wave: N = 16384 13.1 / 20.5,
+        // 65536 19.6 / 22.8, 131072 35.3 / 41.5): it needs 187 VGPRs (two waves per SIMD) against 256 + 79 AGPRs.
         const char* k = getenv("PPENV_STEP_KERNEL");
-        e->split = k ? (strcmp(k, "split") == 0) : (cfg->num_envs <= 32768);
+        e->split = k ? (strcmp(k, "fused") != 0) : 1;
     }
     e->arena = nullptr;
     e->owns_arena = false;
