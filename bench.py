@@ -29,6 +29,8 @@ if ROOT not in sys.path:
 
 NUM_ENVS = 16384
 VARIANT = "TT"
+WORKLOAD_NAMES = {"TT": "tilt (HumanoidPingpongTiltG1)", "TN": "tilt, no early stop (HumanoidPingpongTiltNoEarlyStopG1)",
+                  "T3": "(HumanoidPingpongG1)"}
 HORIZON = 32
 # SURVEY.md §8(d) "minimal algorithmic bytes / env-step" for the 7-DoF variants (R 156 + W 452)
 ALGO_BYTES_PER_ENV_STEP = 608
@@ -48,7 +50,7 @@ def usable_cores():
     return max(1, min(cores, 16))
 
 
-def cpu_baseline(num_envs, target_seconds=12.0):
+def cpu_baseline(num_envs, target_seconds=12.0, variant=VARIANT):
     """The CPU oracle (oracle/ppenv_oracle.c, kind 'port') timed on this box's host cores on a bounded
     sample of the same workload.  Reported, not targeted."""
     import numpy as np
@@ -56,7 +58,7 @@ def cpu_baseline(num_envs, target_seconds=12.0):
     from oracle import binding as ob
     ob.build()
     cores = usable_cores()
-    env = ob.OracleEnv(scene.build_config(VARIANT, num_envs=num_envs, seed=0), threads=cores)
+    env = ob.OracleEnv(scene.build_config(variant, num_envs=num_envs, seed=0), threads=cores)
     rng = np.random.default_rng(0)
     actions = [rng.uniform(-1, 1, (num_envs, 7)).astype(np.float32) for _ in range(4)]
     env.step(actions[0])   # warm-up
@@ -69,7 +71,7 @@ def cpu_baseline(num_envs, target_seconds=12.0):
         if dt >= target_seconds or steps >= 2000:
             break
     return {"value": num_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of the {VARIANT} variant at num_envs={num_envs}, OpenMP over envs, {dt:.1f} s"}
+            "sample": f"{steps} steps of the {variant} variant at num_envs={num_envs}, OpenMP over envs, {dt:.1f} s"}
 
 
 def pmc_traffic(num_envs):
@@ -98,6 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default=VARIANT, choices=["TT", "TN", "T3"],
+                    help="task variant; the headline workload is TT (BASELINE.json configs[2]), the others are parity-test cases")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL (default); gloo only to rehearse the rank logic on one GPU")
     args = ap.parse_args()
 
@@ -131,7 +135,7 @@ def main():
 
     n = args.num_envs
     off, cnt = D.shard_range(n * world, rank, world)   # contiguous global env ids; trajectories do not depend on the split
-    env = PPEnv(scene.build_config(VARIANT, num_envs=cnt, seed=0, device_id=device.index, env_id_offset=off), device=device)
+    env = PPEnv(scene.build_config(args.variant, num_envs=cnt, seed=0, device_id=device.index, env_id_offset=off), device=device)
     gen = torch.Generator(device=device).manual_seed(rank)
     pool = [(torch.rand(n, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
     stats = D.AsyncHorizonStats(env)   # what the reference prints every 40 steps (TT:763-766) + finished episodes
@@ -194,8 +198,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"humanoid_pingpong 3-actor tilt (HumanoidPingpongTiltG1), num_envs={n} per GPU, "
-                                   "random U(-1,1) actions, dt 0.0083 x 2 substeps, fused step kernel",
+            "config": {"workload": f"humanoid_pingpong 3-actor {WORKLOAD_NAMES[args.variant]}, num_envs={n} per GPU, "
+                                   "random U(-1,1) actions, 2 physics substeps per step, fused step kernel",
+                       "variant": args.variant,
                        "num_envs_per_gpu": n, "global_envs": n * world, "horizon_stats_every": HORIZON,
                        "parallelism": f"env-shard x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -206,7 +211,7 @@ def main():
                               "episodes_finished": final_stats[2]},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n)
+            out["cpu_baseline"] = cpu_baseline(n, variant=args.variant)
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:
