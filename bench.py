@@ -29,11 +29,13 @@ if ROOT not in sys.path:
 
 NUM_ENVS = 16384
 VARIANT = "TT"
-WORKLOAD_NAMES = {"TT": "tilt (HumanoidPingpongTiltG1)", "TN": "tilt, no early stop (HumanoidPingpongTiltNoEarlyStopG1)",
-                  "T3": "(HumanoidPingpongG1)"}
+WORKLOAD_NAMES = {"TT": "3-actor tilt (HumanoidPingpongTiltG1)", "TN": "3-actor tilt, no early stop (HumanoidPingpongTiltNoEarlyStopG1)",
+                  "T3": "3-actor (HumanoidPingpongG1)", "T4": "4-actor tilt (Humanoid12PingpongTiltG1: two humanoids, two agent rows per env)"}
 HORIZON = 32
-# SURVEY.md §8(d) "minimal algorithmic bytes / env-step" for the 7-DoF variants (R 156 + W 452)
-ALGO_BYTES_PER_ENV_STEP = 608
+# SURVEY.md §8(d) "minimal algorithmic bytes / env-step": 7-DoF variants R 156 + W 452 = 608; 4-actor ("~1.1 KB"): R actions 56 +
+# q,qd 112 + ball 52 + progress/flags/prev-vx 16 + rng 8 = 244, W q,qd 112 + ball 52 + misc 24 + obs 640 + rew 8 + reset 8 = 844
+ALGO_BYTES = {"TT": 608, "TN": 608, "T3": 608, "T4": 1088}
+ALGO_BYTES_PER_ENV_STEP = ALGO_BYTES["TT"]
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -60,7 +62,7 @@ def cpu_baseline(num_envs, target_seconds=12.0, variant=VARIANT):
     cores = usable_cores()
     env = ob.OracleEnv(scene.build_config(variant, num_envs=num_envs, seed=0), threads=cores)
     rng = np.random.default_rng(0)
-    actions = [rng.uniform(-1, 1, (num_envs, 7)).astype(np.float32) for _ in range(4)]
+    actions = [rng.uniform(-1, 1, (num_envs * env.num_agents, 7)).astype(np.float32) for _ in range(4)]
     env.step(actions[0])   # warm-up
     t0 = time.perf_counter()
     steps = 0
@@ -87,10 +89,13 @@ def pmc_traffic(num_envs):
     return best
 
 
-def kernel_name(num_envs):
-    """The schedule ppenv_create picks (isaacgym_amd/csrc/ppenv.hip): two waves per 64 envs unless the one-wave kernel is forced."""
+def kernel_name(variant):
+    """The schedule ppenv_create picks (isaacgym_amd/csrc/ppenv.hip): two waves per 64 envs unless the one-wave kernel is
+    forced; three waves (two arm waves + the ball wave) for the 4-actor variant."""
+    if variant == "T4":
+        return "step_kernel_split<ModelG1, 2>"
     split = os.environ.get("PPENV_STEP_KERNEL") != "fused"
-    return "step_kernel_split<ModelG1>" if split else "step_kernel<ModelG1>"
+    return "step_kernel_split<ModelG1, 1>" if split else "step_kernel<ModelG1>"
 
 
 def main():
@@ -100,7 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", default=VARIANT, choices=["TT", "TN", "T3"],
+    ap.add_argument("--variant", default=VARIANT, choices=["TT", "TN", "T3", "T4"],
                     help="task variant; the headline workload is TT (BASELINE.json configs[2]), the others are parity-test cases")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL (default); gloo only to rehearse the rank logic on one GPU")
     args = ap.parse_args()
@@ -137,7 +142,7 @@ def main():
     off, cnt = D.shard_range(n * world, rank, world)   # contiguous global env ids; trajectories do not depend on the split
     env = PPEnv(scene.build_config(args.variant, num_envs=cnt, seed=0, device_id=device.index, env_id_offset=off), device=device)
     gen = torch.Generator(device=device).manual_seed(rank)
-    pool = [(torch.rand(n, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
+    pool = [(torch.rand(n * env.num_agents, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
     stats = D.AsyncHorizonStats(env)   # what the reference prints every 40 steps (TT:763-766) + finished episodes
 
     def horizon_stats():
@@ -184,7 +189,8 @@ def main():
 
     if rank == 0:
         total_env_steps = n * world * args.steps
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_us * 1e-6) / 1e9
+        algo_bytes = ALGO_BYTES[args.variant]
+        achieved = algo_bytes * n / (kernel_us * 1e-6) / 1e9
         out = {
             "metric": "env-steps/sec at N_envs=16384 (1/2/4/8 GPUs) + achieved HBM GB/s vs roofline",
             "value": total_env_steps / wall,
@@ -198,15 +204,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"humanoid_pingpong 3-actor {WORKLOAD_NAMES[args.variant]}, num_envs={n} per GPU, "
+            "config": {"workload": f"humanoid_pingpong {WORKLOAD_NAMES[args.variant]}, num_envs={n} per GPU, "
                                    "random U(-1,1) actions, 2 physics substeps per step, fused step kernel",
                        "variant": args.variant,
                        "num_envs_per_gpu": n, "global_envs": n * world, "horizon_stats_every": HORIZON,
                        "parallelism": f"env-shard x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(n), "kernel": kernel_name(n), "avg_kernel_us": kernel_us,
+                         "traffic": pmc_traffic(n) if args.variant == VARIANT else None, "kernel": kernel_name(args.variant), "avg_kernel_us": kernel_us,
                          "timed_region_us_per_step": dev_ms * 1e3 / args.steps,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n},
+                         "algorithmic_bytes_per_launch": algo_bytes * n},
             "episode_stats": {"mean_reward_last_step": final_stats[0], "mean_progress": final_stats[1],
                               "episodes_finished": final_stats[2]},
         }

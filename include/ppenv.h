@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PPENV_ABI_VERSION 1
+#define PPENV_ABI_VERSION 2
 
 struct ppenv; /* opaque handle */
 typedef struct ppenv ppenv;
@@ -56,7 +56,12 @@ typedef struct ppenv ppenv;
 enum {
     PPENV_VARIANT_T3 = 0, /* HumanoidPingpongG1: tasks/humanoid_interos_edit_pingpong_only_3_actor.py */
     PPENV_VARIANT_TT = 1, /* HumanoidPingpongTiltG1: tasks/humanoid_pingpong_3_actor_tilt.py */
-    PPENV_VARIANT_TN = 2  /* HumanoidPingpongTiltNoEarlyStopG1: ..._tilt_no_earlystop.py */
+    PPENV_VARIANT_TN = 2, /* HumanoidPingpongTiltNoEarlyStopG1: ..._tilt_no_earlystop.py */
+    PPENV_VARIANT_T4 = 3  /* Humanoid12PingpongTiltG1: tasks/humanoid_pingpong_4_actor_tilt.py — two humanoids, one ball.
+                             The reference class is unfinished (T4:743,786-803); the two-agent wiring below is the build's
+                             completion of it: agent a of env e owns row 2e + a of obs / rew / reset /
+                             progress and of the [2N, 7] action tensor (the rl_games multi-agent convention), humanoid 2
+                             stands at x = 3.5 facing humanoid 1 (T4:555-556), sticky flags per side, TT's serve and reset. */
 };
 
 /* Sticky per-env flag bits (one uint32 per env).
@@ -182,6 +187,14 @@ typedef struct ppenv_config {
     float penalty;
     float hit_table_reward;
     float not_hit_table_penalty;
+
+    /* second humanoid (PPENV_VARIANT_T4 only; num_humanoids = 1 otherwise).  It is the same compiled arm model on
+     * another base; its link-attached shapes are humanoid 1's, only the world-frame data differ. */
+    int32_t num_humanoids;
+    float base2_pos[3], base2_rot[9];
+    float humanoid2_root_pos[3], humanoid2_root_quat[4];
+    ppenv_shape shape2[PPENV_MAX_SHAPES];
+    float humanoid2_bound_center[3];
 } ppenv_config;
 
 /* Device pointers of the buffers a handle owns, for zero-copy wrapping (the
@@ -189,17 +202,18 @@ typedef struct ppenv_config {
  * [field][num_envs]; surface tensors use the reference's AoS layouts. */
 typedef struct ppenv_buffers {
     int32_t num_envs;
+    int32_t num_agents;    /* A = 1, or 2 for PPENV_VARIANT_T4; agent a of env e owns row A*e + a of the surface tensors */
     /* VecTask surface */
-    float* obs_buf;        /* [N, 80] f32 */
-    float* rew_buf;        /* [N] f32 */
-    int64_t* reset_buf;    /* [N] i64 */
-    int64_t* progress_buf; /* [N] i64 */
+    float* obs_buf;        /* [A*N, 80] f32 */
+    float* rew_buf;        /* [A*N] f32 */
+    int64_t* reset_buf;    /* [A*N] i64 */
+    int64_t* progress_buf; /* [A*N] i64 */
     /* SoA simulation state */
-    float* dof_pos;        /* [7][N] */
-    float* dof_vel;        /* [7][N] */
-    float* dof_force;      /* [7][N]  drive torque of the last substep */
+    float* dof_pos;        /* [7*A][N]  (humanoid 1's seven rows first) */
+    float* dof_vel;        /* [7*A][N] */
+    float* dof_force;      /* [7*A][N]  drive torque of the last substep */
     float* ball;           /* [13][N] pos3 quat4 linvel3 angvel3 */
-    uint32_t* flags;       /* [N] PPENV_FLAG_* */
+    uint32_t* flags;       /* [A][N] PPENV_FLAG_*, one word per side */
     uint32_t* episode;     /* [N] resets so far (RNG counter) */
     float* serve_override; /* [3][N]; used instead of the RNG while the override is on */
 } ppenv_buffers;
@@ -226,7 +240,7 @@ int ppenv_config_of(struct ppenv* env, ppenv_config* out);
  * ball vx (TT:1020), `substeps` physics substeps (gym.simulate), progress += 1
  * (TT:1023), reward + reset decision (TT:739-758), masked reset (TT:847-906),
  * observations (TT:770-799) — one fused kernel launch.
- * actions_dev: [N, 7] f32 row-major (the policy's tensor, not copied). */
+ * actions_dev: [A*N, 7] f32 row-major (the policy's tensor, not copied; A = 2 for PPENV_VARIANT_T4). */
 int ppenv_step(struct ppenv* env, const float* actions_dev, void* stream);
 
 /* Reset every env to its initial state with a fresh serve and recompute
@@ -352,8 +366,8 @@ int ppenv_t4_rewards(const ppenv_t4_params* params, const float* rb_states_dev /
 int ppenv_set_serve_override(struct ppenv* env, const float* serve_dev /* [N,3] row-major or NULL */, int on, void* stream);
 
 /* Host-side blob of the full per-env state, SoA, in this order:
- *   dof_pos f32[7][N], dof_vel f32[7][N], dof_force f32[7][N], ball f32[13][N],
- *   flags u32[N], episode u32[N], progress i64[N], reset i64[N]. */
+ *   dof_pos f32[7A][N], dof_vel f32[7A][N], dof_force f32[7A][N], ball f32[13][N],
+ *   flags u32[A][N], episode u32[N], progress i64[A*N], reset i64[A*N]      (A = num_agents). */
 size_t ppenv_state_bytes(struct ppenv* env);
 int ppenv_get_state(struct ppenv* env, void* dst_host, size_t n);
 int ppenv_set_state(struct ppenv* env, const void* src_host, size_t n);

@@ -50,9 +50,10 @@ struct DevBuffers {
 };
 
 // ------------------------------------------------------------- SoA state <-> registers
-__device__ __forceinline__ void load_state(const DevBuffers& b, int n, int i, EnvState& st) {
+template <int A>
+__device__ __forceinline__ void load_state(const DevBuffers& b, int n, int i, EnvStateT<A>& st) {
 #pragma unroll
-    for (int d = 0; d < ND; d++) {
+    for (int d = 0; d < A * ND; d++) {
         st.q[d] = b.dof_pos[(size_t)d * n + i];
         st.qd[d] = b.dof_vel[(size_t)d * n + i];
     }
@@ -64,24 +65,39 @@ __device__ __forceinline__ void load_state(const DevBuffers& b, int n, int i, En
     for (int k = 0; k < 4; k++) st.ball.quat[k] = bl[3 + k];
     st.ball.v = mk(bl[7], bl[8], bl[9]);
     st.ball.w = mk(bl[10], bl[11], bl[12]);
-    st.progress = b.progress[i];
-    st.flags = b.flags[i];
+    st.progress = b.progress[(size_t)i * A];   // rows A*e .. A*e + A-1 carry the same value
+#pragma unroll
+    for (int a = 0; a < A; a++) st.flags[a] = b.flags[(size_t)a * n + i];
     st.episode = b.episode[i];
 }
-__device__ __forceinline__ void store_state(const DevBuffers& b, int n, int i, const EnvState& st) {
+__device__ __forceinline__ void store_ball(const DevBuffers& b, int n, int i, const Ball& ball) {
+    const float bl[13] = {ball.p.x, ball.p.y, ball.p.z, ball.quat[0], ball.quat[1], ball.quat[2], ball.quat[3],
+                          ball.v.x, ball.v.y, ball.v.z, ball.w.x, ball.w.y, ball.w.z};
 #pragma unroll
-    for (int d = 0; d < ND; d++) {
+    for (int k = 0; k < 13; k++) b.ball[(size_t)k * n + i] = bl[k];
+}
+// progress / flags / episode and the per-agent rows of rew / reset
+template <int A>
+__device__ __forceinline__ void store_task(const DevBuffers& b, int n, int i, const EnvStateT<A>& st, const float* rew, long long reset) {
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        b.progress[(size_t)i * A + a] = st.progress;
+        b.flags[(size_t)a * n + i] = st.flags[a];
+        b.rew[(size_t)i * A + a] = rew[a];
+        b.reset[(size_t)i * A + a] = reset;
+    }
+    b.episode[i] = st.episode;
+}
+template <int A>
+__device__ __forceinline__ void store_state(const DevBuffers& b, int n, int i, const EnvStateT<A>& st, const float* rew, long long reset) {
+#pragma unroll
+    for (int d = 0; d < A * ND; d++) {
         b.dof_pos[(size_t)d * n + i] = st.q[d];
         b.dof_vel[(size_t)d * n + i] = st.qd[d];
         b.dof_force[(size_t)d * n + i] = st.dof_force[d];
     }
-    const float bl[13] = {st.ball.p.x, st.ball.p.y, st.ball.p.z, st.ball.quat[0], st.ball.quat[1], st.ball.quat[2], st.ball.quat[3],
-                          st.ball.v.x, st.ball.v.y, st.ball.v.z, st.ball.w.x, st.ball.w.y, st.ball.w.z};
-#pragma unroll
-    for (int k = 0; k < 13; k++) b.ball[(size_t)k * n + i] = bl[k];
-    b.progress[i] = st.progress;
-    b.flags[i] = st.flags;
-    b.episode[i] = st.episode;
+    store_ball(b, n, i, st.ball);
+    store_task<A>(b, n, i, st, rew, reset);
 }
 
 struct LdsRowStore {
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
         float act[ND];
 #pragma unroll
         for (int d = 0; d < ND; d++) act[d] = actions[(size_t)i * ND + d];
-        load_state(b, n, i, st);
+        load_state<1>(b, n, i, st);
 #if defined(PP_STAMP)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // attribute the load latency to phase 0->1
 #endif
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
 #pragma unroll
         for (int j = 0; j < NB; j++) { bodies[j].pos = mk(act[0], act[1], (float)j); bodies[j].lin = mk(act[2], act[3], act[4]); }
 #else
-        simulate_env<T>(K, act, st, bodies, pre_vx);
+        simulate_env<T, 1>(K, act, st, bodies, pre_vx);
 #endif
         V3 ov = mk(0, 0, 0);
         if (serve_on) ov = mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i]);
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
 #pragma unroll
         for (int k = 0; k < PPENV_NUM_OBS; k++) store(k, bodies[k % NB].pos.x);
 #else
-        post_physics_env(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, rew, reset, store);
+        post_physics_env<1>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, &rew, reset, &store);
 #endif
         PP_STAMP_AT(9);
     }
@@ -157,9 +173,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
     __builtin_amdgcn_wave_barrier();
     flush_obs(s_obs, b.obs, base, nvalid, lane);
     if (active) {
-        store_state(b, n, i, st);   // fire and forget: nothing in this launch reads the state again
-        b.rew[i] = rew;
-        b.reset[i] = reset;
+        store_state<1>(b, n, i, st, &rew, reset);   // fire and forget: nothing in this launch reads the state again
     }
     PP_STAMP_AT(10);
 }
@@ -183,17 +197,19 @@ struct NullVisitor {
     __device__ __forceinline__ void operator()(int, const M3&, V3, V3, V3) {}
 };
 
-// obs tile -> obs_buf for the columns [C0, C1) of every row, as float4 (both bounds multiples of 4)
+// obs tile -> obs_buf for the columns [C0, C1) (both multiples of 4) of `nrows` tile rows starting at tile row
+// `t0`, as float4.  Tile row t0 + r goes to obs_buf row `g0 + r * gstep` (the tile is [agent][lane], obs_buf rows
+// are A * env + agent).
 template <int C0, int C1>
-__device__ __forceinline__ void flush_obs_cols(const float* s_obs, float* obs, int base, int nvalid, int lane) {
+__device__ __forceinline__ void flush_obs_cols(const float* s_obs, float* obs, int t0, int nrows, size_t g0, int gstep, int lane) {
     constexpr int per_row = (C1 - C0) / 4;
-    const int total = nvalid * per_row;
+    const int total = nrows * per_row;
     typedef float f4v __attribute__((ext_vector_type(4)));
     for (int k = lane; k < total; k += kBlock) {
         int r = k / per_row, c = C0 + 4 * (k - r * per_row);
-        const float* src = &s_obs[r * kObsStride + c];
+        const float* src = &s_obs[(t0 + r) * kObsStride + c];
         f4v val = {src[0], src[1], src[2], src[3]};
-        __builtin_nontemporal_store(val, reinterpret_cast<f4v*>(obs + ((size_t)(base + r) * PPENV_NUM_OBS + c)));
+        __builtin_nontemporal_store(val, reinterpret_cast<f4v*>(obs + ((g0 + (size_t)r * gstep) * PPENV_NUM_OBS + c)));
     }
 }
 
@@ -210,16 +226,18 @@ __device__ __forceinline__ void await(int* flag, int value) {
     }
 }
 
-template <class T>
-__global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
-    __shared__ float s_obs[kBlock * kObsStride];
-    __shared__ float s_q[2][2 * ND][kBlock];   // (q, qd) at a substep boundary, two alternating slots
-    __shared__ float s_tau[ND][kBlock];        // drive torques of the last substep (dof_force)
-    __shared__ float s_paddle[3][kBlock];      // paddle position of the final state (the reward reads it)
-    __shared__ int s_reset[kBlock];            // the ball wave's reset decision, for the arm wave's dof stores
-    __shared__ int s_flag;                     // arm -> ball: boundaries published so far; substeps + 1 = paddle position too
-    __shared__ int s_flag_ball;                // ball -> arm: 1 once the reset decision is in s_reset
-    const int wave = threadIdx.x >> 6;
+// A = humanoids per env.  A = 1: two waves (arm, ball).  A = 2 (4-actor variant): three waves — one per arm, each
+// on its own base (K.site[arm]), and the ball wave, which sweeps both arms' collision geometry.
+template <class T, int A>
+__global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
+    __shared__ float s_obs[A * kBlock * kObsStride];   // tile row = agent * kBlock + lane
+    __shared__ float s_q[2][A * 2 * ND][kBlock];       // (q, qd) at a substep boundary, two alternating slots
+    __shared__ float s_tau[A * ND][kBlock];            // drive torques of the last substep (dof_force)
+    __shared__ float s_paddle[A * 3][kBlock];          // paddle position of the final state (the reward reads it)
+    __shared__ int s_reset[kBlock];                    // the ball wave's reset decision, for the arm waves' dof stores
+    __shared__ int s_flag[A];                          // arm -> ball: boundaries published so far; substeps + 1 = paddle position too
+    __shared__ int s_flag_ball;                        // ball -> arm: 1 once the reset decision is in s_reset
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int n = K.num_envs;
     const int base = blockIdx.x * kBlock;
@@ -227,21 +245,23 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
     const int nvalid = min(kBlock, n - base);
     const bool active = i < n;
     const int substeps = K.substeps;
-    if (threadIdx.x == 0) { s_flag = 0; s_flag_ball = 0; }
+    if (threadIdx.x <= A) { if (threadIdx.x < A) s_flag[threadIdx.x] = 0; else s_flag_ball = 0; }
     __syncthreads();   // the only rendezvous of the launch: the flags are initialised
 
-    if (wave == 0) {
+    if (wave < A) {
         // ------------------------------------------------------------------ arm wave
+        const int arm = wave;
+        const ArmSite& S = K.site[A == 1 ? 0 : arm];
         PP_STAMP_AT(0);
         float q[ND], qd[ND], target[ND], tau[ND];
         JointSave js[ND];
         if (active) {
 #pragma unroll
             for (int d = 0; d < ND; d++) {
-                q[d] = b.dof_pos[(size_t)d * n + i];
-                qd[d] = b.dof_vel[(size_t)d * n + i];
+                q[d] = b.dof_pos[(size_t)(arm * ND + d) * n + i];
+                qd[d] = b.dof_vel[(size_t)(arm * ND + d) * n + i];
                 tau[d] = 0.f;
-                float a = fminf(fmaxf(actions[(size_t)i * ND + d], -K.clip_actions), K.clip_actions);   // VecTask.step clamp
+                float a = fminf(fmaxf(actions[((size_t)i * A + arm) * ND + d], -K.clip_actions), K.clip_actions);   // VecTask.step clamp
                 const float lo = T::drive(d).lower, hi = T::drive(d).upper;
                 target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;                                     // TT:1008, 664-665
             }
@@ -250,16 +270,16 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
         for (int s = 0; s < substeps; s++) {
             if (active) {
                 NullVisitor nv;   // velocity recursion only: the world transforms of this sweep are dead code
-                fk_sweep<T>(K, q, qd, js, nv);
-                arm_substep<T>(K, js, q, qd, target, K.h, tau);
+                fk_sweep<T>(S, q, qd, js, nv);
+                arm_substep<T>(S, js, q, qd, target, K.h, tau);
 #pragma unroll
-                for (int d = 0; d < ND; d++) { s_q[(s + 1) & 1][d][lane] = q[d]; s_q[(s + 1) & 1][ND + d][lane] = qd[d]; }
+                for (int d = 0; d < ND; d++) { s_q[(s + 1) & 1][arm * 2 * ND + d][lane] = q[d]; s_q[(s + 1) & 1][arm * 2 * ND + ND + d][lane] = qd[d]; }
                 if (s + 1 == substeps) {
 #pragma unroll
-                    for (int d = 0; d < ND; d++) s_tau[d][lane] = tau[d];
+                    for (int d = 0; d < ND; d++) s_tau[arm * ND + d][lane] = tau[d];
                 }
             }
-            publish(&s_flag, s + 1);   // (q, qd) of boundary s+1 (and, last time, the drive torques)
+            publish(&s_flag[arm], s + 1);   // (q, qd) of boundary s+1 (and, last time, the drive torques)
             PP_STAMP_AT(2 + 2 * s);
         }
         // FK of the final state: paddle position for the reward, then the body block of the observation row,
@@ -268,31 +288,31 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
         if (active) {
             ArmGeom<T::kShapes> g;
             BodyVisitor<T, false> bv(g, bodies);
-            fk_sweep<T>(K, q, qd, js, bv);
-            static_body<false>(K, bodies[0]);
-            s_paddle[0][lane] = bodies[NB - 1].pos.x; s_paddle[1][lane] = bodies[NB - 1].pos.y; s_paddle[2][lane] = bodies[NB - 1].pos.z;
+            fk_sweep<T>(S, q, qd, js, bv);
+            static_body<false>(S, bodies[0]);
+            s_paddle[arm * 3 + 0][lane] = bodies[NB - 1].pos.x; s_paddle[arm * 3 + 1][lane] = bodies[NB - 1].pos.y; s_paddle[arm * 3 + 2][lane] = bodies[NB - 1].pos.z;
         }
-        publish(&s_flag, substeps + 1);
+        publish(&s_flag[arm], substeps + 1);
         PP_STAMP_AT(5);
         if (active) {
             V3 bpos[NB], bvel[NB];
 #pragma unroll
             for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
-            LdsRowStore store{&s_obs[lane * kObsStride]};
-            write_obs_bodies(bpos, bvel, K.hinv, store);
+            LdsRowStore store{&s_obs[(arm * kBlock + lane) * kObsStride]};
+            write_obs_bodies(bpos, bvel, S.hinv, store);
         }
         PP_STAMP_AT(6);
-        __builtin_amdgcn_wave_barrier();   // columns [0,60) were written by this wave only: no rendezvous needed
-        flush_obs_cols<0, 6 * NB>(s_obs, b.obs, base, nvalid, lane);
+        __builtin_amdgcn_wave_barrier();   // columns [0,60) of this agent's rows were written by this wave only: no rendezvous needed
+        flush_obs_cols<0, 6 * NB>(s_obs, b.obs, arm * kBlock, nvalid, (size_t)base * A + arm, A, lane);
         await(&s_flag_ball, 1);            // the ball wave's reset decision
         PP_STAMP_AT(7);
         if (active) {
             const bool rst = s_reset[lane] != 0 && K.rc.variant != PPENV_VARIANT_TN;   // TN:888-901 keeps the dof state
 #pragma unroll
             for (int d = 0; d < ND; d++) {
-                b.dof_pos[(size_t)d * n + i] = rst ? K.init_dof_pos[d] : q[d];
-                b.dof_vel[(size_t)d * n + i] = rst ? K.init_dof_vel[d] : qd[d];
-                b.dof_force[(size_t)d * n + i] = tau[d];
+                b.dof_pos[(size_t)(arm * ND + d) * n + i] = rst ? K.init_dof_pos[d] : q[d];
+                b.dof_vel[(size_t)(arm * ND + d) * n + i] = rst ? K.init_dof_vel[d] : qd[d];
+                b.dof_force[(size_t)(arm * ND + d) * n + i] = tau[d];
             }
         }
         return;
@@ -300,15 +320,17 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
 
     // ---------------------------------------------------------------------- ball wave
     PP_STAMP_AT(16);
-    EnvState st;
-    float rew = 0.f, pre_vx = 0.f;
+    EnvStateT<A> st;
+    float rew[A], pre_vx = 0.f;
     long long reset = 0;
     V3 next_serve = mk(0, 0, 0);
-    ArmGeom<T::kShapes> g;
-    float qs[ND], qds[ND];
+    ArmGeom<T::kShapes> g[A];
+    float qs[A * ND], qds[A * ND];
+#pragma unroll
+    for (int a = 0; a < A; a++) rew[a] = 0.f;
     if (active) {
 #pragma unroll
-        for (int d = 0; d < ND; d++) { qs[d] = b.dof_pos[(size_t)d * n + i]; qds[d] = b.dof_vel[(size_t)d * n + i]; }
+        for (int d = 0; d < A * ND; d++) { qs[d] = b.dof_pos[(size_t)d * n + i]; qds[d] = b.dof_vel[(size_t)d * n + i]; }
         float bl[13];
 #pragma unroll
         for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
@@ -317,11 +339,13 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
         for (int k = 0; k < 4; k++) st.ball.quat[k] = bl[3 + k];
         st.ball.v = mk(bl[7], bl[8], bl[9]);
         st.ball.w = mk(bl[10], bl[11], bl[12]);
-        st.progress = b.progress[i];
-        st.flags = b.flags[i];
+        st.progress = b.progress[(size_t)i * A];
+#pragma unroll
+        for (int a = 0; a < A; a++) st.flags[a] = b.flags[(size_t)a * n + i];
         st.episode = b.episode[i];
         pre_vx = st.ball.v.x;   // TT:1020
-        static_geometry<T>(K, g);
+#pragma unroll
+        for (int a = 0; a < A; a++) static_geometry<T>(K.site[a], g[a]);
         // the serve this env gets if it resets at the end of the step: the counter RNG is a pure function of
         // (seed, env id, episode + 1), so it can be drawn now, off the tail of the step
         next_serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
@@ -330,84 +354,99 @@ __global__ __launch_bounds__(2 * kBlock) void step_kernel_split(const StepConsts
     PP_STAMP_AT(17);
     for (int s = 0; s < substeps; s++) {
         if (s > 0) {
-            await(&s_flag, s);   // the arm wave has published boundary s
+#pragma unroll
+            for (int a = 0; a < A; a++) await(&s_flag[a], s);   // the arm waves have published boundary s
             if (active) {
 #pragma unroll
-                for (int d = 0; d < ND; d++) { qs[d] = s_q[s & 1][d][lane]; qds[d] = s_q[s & 1][ND + d][lane]; }
+                for (int a = 0; a < A; a++)
+#pragma unroll
+                    for (int d = 0; d < ND; d++) { qs[a * ND + d] = s_q[s & 1][a * 2 * ND + d][lane]; qds[a * ND + d] = s_q[s & 1][a * 2 * ND + ND + d][lane]; }
             }
         }
         PP_STAMP_AT(18 + 2 * s);
         if (active) {
-            JointSave js[ND];        // dead: only the geometry (points + velocities) of this sweep is used
-            GeomVisitor<T> gv(g);
-            fk_sweep<T>(K, qs, qds, js, gv);
-            ball_substep<T>(K, st.ball, g);
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                JointSave js[ND];        // dead: only the geometry (points + velocities) of this sweep is used
+                GeomVisitor<T> gv(g[a]);
+                fk_sweep<T>(K.site[a], &qs[a * ND], &qds[a * ND], js, gv);
+            }
+            ball_substep<T, A>(K, st.ball, g);
         }
         PP_STAMP_AT(19 + 2 * s);
     }
-    await(&s_flag, substeps + 1);   // final dof state, drive torques and paddle position
-    if (active) {
 #pragma unroll
-        for (int d = 0; d < ND; d++) { st.q[d] = s_q[substeps & 1][d][lane]; st.qd[d] = s_q[substeps & 1][ND + d][lane]; st.dof_force[d] = s_tau[d][lane]; }
-        BodyState bodies[NB];   // the task part reads the pelvis (row 0) and the paddle (row 9) only
-        static_body<false>(K, bodies[0]);
-        bodies[NB - 1].pos = mk(s_paddle[0][lane], s_paddle[1][lane], s_paddle[2][lane]);
-        LdsRowStore store{&s_obs[lane * kObsStride]};
-        post_physics_env<false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, &next_serve, rew, reset, store);
+    for (int a = 0; a < A; a++) await(&s_flag[a], substeps + 1);   // final dof state, drive torques and paddle position
+    if (active) {
+        BodyState bodies[A * NB];   // the task part reads the pelvis (row 0) and the paddle (row 9) only
+        LdsRowStore stores[A];
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                st.q[a * ND + d] = s_q[substeps & 1][a * 2 * ND + d][lane];
+                st.qd[a * ND + d] = s_q[substeps & 1][a * 2 * ND + ND + d][lane];
+                st.dof_force[a * ND + d] = s_tau[a * ND + d][lane];
+            }
+            static_body<false>(K.site[a], bodies[a * NB]);
+            bodies[a * NB + NB - 1].pos = mk(s_paddle[a * 3 + 0][lane], s_paddle[a * 3 + 1][lane], s_paddle[a * 3 + 2][lane]);
+            stores[a].row = &s_obs[(a * kBlock + lane) * kObsStride];
+        }
+        post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, &next_serve, rew, reset, stores);
         s_reset[lane] = (int)reset;
     }
-    publish(&s_flag_ball, 1);          // hands the reset decision to the arm wave
+    publish(&s_flag_ball, 1);          // hands the reset decision to the arm waves
     PP_STAMP_AT(22);
     __builtin_amdgcn_wave_barrier();   // columns [60,80) were written by this wave only
     PP_STAMP_AT(23);
-    flush_obs_cols<6 * NB, PPENV_NUM_OBS>(s_obs, b.obs, base, nvalid, lane);
-    if (active) {
-        const float bl[13] = {st.ball.p.x, st.ball.p.y, st.ball.p.z, st.ball.quat[0], st.ball.quat[1], st.ball.quat[2], st.ball.quat[3],
-                              st.ball.v.x, st.ball.v.y, st.ball.v.z, st.ball.w.x, st.ball.w.y, st.ball.w.z};
 #pragma unroll
-        for (int k = 0; k < 13; k++) b.ball[(size_t)k * n + i] = bl[k];
-        b.progress[i] = st.progress;
-        b.flags[i] = st.flags;
-        b.episode[i] = st.episode;
-        b.rew[i] = rew;
-        b.reset[i] = reset;
+    for (int a = 0; a < A; a++)
+        flush_obs_cols<6 * NB, PPENV_NUM_OBS>(s_obs, b.obs, a * kBlock, nvalid, (size_t)base * A + a, A, lane);
+    if (active) {
+        store_ball(b, n, i, st.ball);
+        store_task<A>(b, n, i, st, rew, reset);
     }
     PP_STAMP_AT(24);
 }
 
 // create (mode 0: creation is episode 0) / reset_all (mode 1: next episode): state as after
 // _create_envs (TT:512-643) plus the observations of that state
-template <class T>
+template <class T, int A>
 __global__ __launch_bounds__(kBlock) void init_kernel(const StepConsts K, DevBuffers b, int mode, int serve_on) {
-    __shared__ float s_obs[kBlock * kObsStride];
+    __shared__ float s_obs[A * kBlock * kObsStride];   // tile row = agent * kBlock + lane
     const int n = K.num_envs;
     const int base = blockIdx.x * kBlock;
     const int lane = threadIdx.x;
     const int i = base + lane;
     const int nvalid = min(kBlock, n - base);
     if (i < n) {
-        EnvState st;
+        EnvStateT<A> st;
         st.episode = mode == 0 ? 0u : b.episode[i] + 1u;
         V3 serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
                             : serve_velocity(K, (uint32_t)(K.env_id_offset + i), st.episode);
         reset_state(K, st, serve, true);
 #pragma unroll
-        for (int d = 0; d < ND; d++) st.dof_force[d] = 0.f;
+        for (int d = 0; d < A * ND; d++) st.dof_force[d] = 0.f;
         st.progress = 0;
-        st.flags = PPENV_FLAG_NO_BOUNCE;
-        BodyState bodies[NB];
-        bodies_of_state<T>(K, st.q, st.qd, bodies);
-        V3 bpos[NB], bvel[NB];
+        float rew[A];
 #pragma unroll
-        for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
-        LdsRowStore store{&s_obs[lane * kObsStride]};
-        write_obs(bpos, bvel, K.hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
-        store_state(b, n, i, st);
-        b.rew[i] = 0.f;
-        b.reset[i] = 1;   // upstream VecTask.allocate_buffers: ones; overwritten by the first step (TT:740)
+        for (int a = 0; a < A; a++) {
+            st.flags[a] = PPENV_FLAG_NO_BOUNCE;
+            rew[a] = 0.f;
+            BodyState bodies[NB];
+            bodies_of_state<T>(K.site[a], &st.q[a * ND], &st.qd[a * ND], bodies);
+            V3 bpos[NB], bvel[NB];
+#pragma unroll
+            for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
+            LdsRowStore store{&s_obs[(a * kBlock + lane) * kObsStride]};
+            write_obs(bpos, bvel, K.site[a].hinv, &st.q[a * ND], &st.qd[a * ND], st.ball.p, st.ball.v, store);
+        }
+        store_state<A>(b, n, i, st, rew, 1);   // reset_buf: upstream VecTask.allocate_buffers has ones; overwritten by the first step (TT:740)
     }
     __syncthreads();
-    flush_obs(s_obs, b.obs, base, nvalid, lane);
+#pragma unroll
+    for (int a = 0; a < A; a++)
+        flush_obs_cols<0, PPENV_NUM_OBS>(s_obs, b.obs, a * kBlock, nvalid, (size_t)base * A + a, A, lane);
 }
 
 // ---------------------------------------- Isaac-Gym tensor-API mode: TT:1022-1039 on caller tensors
@@ -444,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void post_physics_kernel(const StepConsts K
         st.ball.p = mk(be[0], be[1], be[2]);
         st.ball.v = mk(be[7], be[8], be[9]);
         st.progress = b.progress[i] + 1;                                   // TT:1023
-        st.flags = b.flags[i];
+        st.flags[0] = b.flags[i];
         st.episode = b.episode[i];
         RewardIn in;
         in.humanoid_x = roote[0];
@@ -458,13 +497,13 @@ __global__ __launch_bounds__(kBlock) void post_physics_kernel(const StepConsts K
         in.power = power;
         in.progress = st.progress;
         long long reset;
-        float rew = compute_reward(K.rc, in, st.flags, reset);
+        float rew = compute_reward(K.rc, in, st.flags[0], reset);
         if (reset) {                                                        // TT:847-906
             st.episode += 1;
             V3 serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
                                 : serve_velocity(K, (uint32_t)(K.env_id_offset + i), st.episode);
-            const float* ipos[3] = {K.root_pos, K.table_pos, K.ball_init_pos};
-            const float* iquat[3] = {K.root_quat, K.table_quat, K.ball_init_quat};
+            const float* ipos[3] = {K.site[0].root_pos, K.table_pos, K.ball_init_pos};
+            const float* iquat[3] = {K.site[0].root_quat, K.table_quat, K.ball_init_quat};
 #pragma unroll
             for (int a = 0; a < 3; a++) {                                   // TT:853-855
 #pragma unroll
@@ -485,14 +524,14 @@ __global__ __launch_bounds__(kBlock) void post_physics_kernel(const StepConsts K
                 }
             }
             st.progress = 0;
-            st.flags = PPENV_FLAG_NO_BOUNCE;
+            st.flags[0] = PPENV_FLAG_NO_BOUNCE;
         }
         LdsRowStore store{&s_obs[lane * kObsStride]};
         float hinv[4];
         heading_quat_inv(root_quat, hinv);
         write_obs(bpos, bvel, hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
         b.progress[i] = st.progress;
-        b.flags[i] = st.flags;
+        b.flags[i] = st.flags[0];
         b.episode[i] = st.episode;
         b.rew[i] = rew;
         b.reset[i] = reset;
@@ -502,74 +541,85 @@ __global__ __launch_bounds__(kBlock) void post_physics_kernel(const StepConsts K
 }
 
 // ------------------------------------------------------------ gym.refresh_* equivalents
+// Layouts: 3-actor [N,3,13] / [N,7,2] / [N,7] / [N,42,13] (TT:166-183,208-211); 4-actor [N,4,13] (humanoid1, humanoid2,
+// table, ball: T4:181-185) / [N,14,2] / [N,14] / [N,82,13] (humanoid1 0-39, humanoid2 40-79, table 80, ball 81: T4:169-172).
 __global__ void refresh_root_kernel(const StepConsts K, DevBuffers b, float* out) {
-    const int n = K.num_envs;
+    const int n = K.num_envs, A = K.num_arms;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float* r = out + (size_t)i * 39;
-    for (int k = 0; k < 39; k++) r[k] = 0.f;
-    for (int k = 0; k < 3; k++) { r[k] = K.root_pos[k]; r[13 + k] = K.table_pos[k]; }
-    for (int k = 0; k < 4; k++) { r[3 + k] = K.root_quat[k]; r[16 + k] = K.table_quat[k]; }
-    for (int k = 0; k < 13; k++) r[26 + k] = b.ball[(size_t)k * n + i];
+    const int rows = A + 2;
+    float* r = out + (size_t)i * rows * 13;
+    for (int k = 0; k < rows * 13; k++) r[k] = 0.f;
+    for (int a = 0; a < A; a++) {
+        for (int k = 0; k < 3; k++) r[a * 13 + k] = K.site[a].root_pos[k];
+        for (int k = 0; k < 4; k++) r[a * 13 + 3 + k] = K.site[a].root_quat[k];
+    }
+    for (int k = 0; k < 3; k++) r[A * 13 + k] = K.table_pos[k];
+    for (int k = 0; k < 4; k++) r[A * 13 + 3 + k] = K.table_quat[k];
+    for (int k = 0; k < 13; k++) r[(A + 1) * 13 + k] = b.ball[(size_t)k * n + i];
 }
 __global__ void refresh_dof_kernel(const StepConsts K, DevBuffers b, float* out) {
-    const int n = K.num_envs;
+    const int n = K.num_envs, D = K.num_arms * ND;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int d = 0; d < ND; d++) {
-        out[((size_t)i * ND + d) * 2] = b.dof_pos[(size_t)d * n + i];
-        out[((size_t)i * ND + d) * 2 + 1] = b.dof_vel[(size_t)d * n + i];
+    for (int d = 0; d < D; d++) {
+        out[((size_t)i * D + d) * 2] = b.dof_pos[(size_t)d * n + i];
+        out[((size_t)i * D + d) * 2 + 1] = b.dof_vel[(size_t)d * n + i];
     }
 }
 __global__ void refresh_dof_force_kernel(const StepConsts K, DevBuffers b, float* out) {
-    const int n = K.num_envs;
+    const int n = K.num_envs, D = K.num_arms * ND;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int d = 0; d < ND; d++) out[(size_t)i * ND + d] = b.dof_force[(size_t)d * n + i];
+    for (int d = 0; d < D; d++) out[(size_t)i * D + d] = b.dof_force[(size_t)d * n + i];
 }
 template <class T>
 __global__ __launch_bounds__(kBlock) void refresh_rb_kernel(const StepConsts K, DevBuffers b, float* out) {
-    const int n = K.num_envs;
+    const int n = K.num_envs, A = K.num_arms;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float q[ND], qd[ND];
-    for (int d = 0; d < ND; d++) { q[d] = b.dof_pos[(size_t)d * n + i]; qd[d] = b.dof_vel[(size_t)d * n + i]; }
-    BodyState bodies[NB];
-    bodies_of_state<T>(K, q, qd, bodies);
-    float* rb = out + (size_t)i * PPENV_NUM_BODIES * 13;
-    for (int body = 0; body < PPENV_NUM_HUMANOID_BODIES; body++) {
-        float* r = rb + body * 13;
-        for (int k = 0; k < 3; k++) r[k] = K.root_pos[k];
-        for (int k = 0; k < 4; k++) r[3 + k] = K.root_quat[k];
-        for (int k = 7; k < 13; k++) r[k] = 0.f;
-    }
-    const int body_ids[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};
+    float* rb = out + (size_t)i * (A * PPENV_NUM_HUMANOID_BODIES + 2) * 13;
+    for (int a = 0; a < A; a++) {
+        const ArmSite& S = K.site[a];
+        float q[ND], qd[ND];
+        for (int d = 0; d < ND; d++) { q[d] = b.dof_pos[(size_t)(a * ND + d) * n + i]; qd[d] = b.dof_vel[(size_t)(a * ND + d) * n + i]; }
+        BodyState bodies[NB];
+        bodies_of_state<T>(S, q, qd, bodies);
+        float* rba = rb + a * PPENV_NUM_HUMANOID_BODIES * 13;
+        for (int body = 0; body < PPENV_NUM_HUMANOID_BODIES; body++) {
+            float* r = rba + body * 13;
+            for (int k = 0; k < 3; k++) r[k] = S.root_pos[k];
+            for (int k = 0; k < 4; k++) r[3 + k] = S.root_quat[k];
+            for (int k = 7; k < 13; k++) r[k] = 0.f;
+        }
+        const int body_ids[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};
 #pragma unroll
-    for (int j = 0; j < NB; j++) {
-        float* r = rb + body_ids[j] * 13;
-        r[0] = bodies[j].pos.x; r[1] = bodies[j].pos.y; r[2] = bodies[j].pos.z;
-        float qt[4];
-        rot_to_quat(bodies[j].rot, qt);
-        r[3] = qt[0]; r[4] = qt[1]; r[5] = qt[2]; r[6] = qt[3];
-        r[7] = bodies[j].lin.x; r[8] = bodies[j].lin.y; r[9] = bodies[j].lin.z;
-        r[10] = bodies[j].ang.x; r[11] = bodies[j].ang.y; r[12] = bodies[j].ang.z;
+        for (int j = 0; j < NB; j++) {
+            float* r = rba + body_ids[j] * 13;
+            r[0] = bodies[j].pos.x; r[1] = bodies[j].pos.y; r[2] = bodies[j].pos.z;
+            float qt[4];
+            rot_to_quat(bodies[j].rot, qt);
+            r[3] = qt[0]; r[4] = qt[1]; r[5] = qt[2]; r[6] = qt[3];
+            r[7] = bodies[j].lin.x; r[8] = bodies[j].lin.y; r[9] = bodies[j].lin.z;
+            r[10] = bodies[j].ang.x; r[11] = bodies[j].ang.y; r[12] = bodies[j].ang.z;
+        }
     }
-    float* t = rb + 40 * 13;
+    float* t = rb + A * PPENV_NUM_HUMANOID_BODIES * 13;
     for (int k = 0; k < 13; k++) t[k] = 0.f;
     for (int k = 0; k < 3; k++) t[k] = K.table_pos[k];
     for (int k = 0; k < 4; k++) t[3 + k] = K.table_quat[k];
-    float* bl = rb + 41 * 13;
+    float* bl = t + 13;
     for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
 }
 
 // sums of rew / progress / episode over the envs (ppenv_reduce_stats): wave reduction + one atomic per wave
-__global__ __launch_bounds__(256) void stats_kernel(int n, const float* __restrict__ rew, const long long* __restrict__ progress,
+__global__ __launch_bounds__(256) void stats_kernel(int n, int agents, const float* __restrict__ rew, const long long* __restrict__ progress,
                                                      const uint32_t* __restrict__ episode, double* out) {
     double r = 0.0, p = 0.0, e = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {   // i = agents * env + agent
         r += (double)rew[i];
         p += (double)progress[i];
-        e += (double)episode[i];
+        e += (double)episode[i / agents];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -613,19 +663,20 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Layout {
     size_t obs, rew, reset, progress, dof_pos, dof_vel, dof_force, ball, flags, episode, serve, total;
 };
-Layout layout_for(int n) {
+int agents_of(const ppenv_config* c) { return c->variant == PPENV_VARIANT_T4 ? 2 : 1; }
+Layout layout_for(int n, int A) {
     Layout l;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
-    l.obs = take((size_t)n * PPENV_NUM_OBS * 4);
-    l.rew = take((size_t)n * 4);
-    l.reset = take((size_t)n * 8);
-    l.progress = take((size_t)n * 8);
-    l.dof_pos = take((size_t)n * ND * 4);
-    l.dof_vel = take((size_t)n * ND * 4);
-    l.dof_force = take((size_t)n * ND * 4);
+    l.obs = take((size_t)n * A * PPENV_NUM_OBS * 4);
+    l.rew = take((size_t)n * A * 4);
+    l.reset = take((size_t)n * A * 8);
+    l.progress = take((size_t)n * A * 8);
+    l.dof_pos = take((size_t)n * A * ND * 4);
+    l.dof_vel = take((size_t)n * A * ND * 4);
+    l.dof_force = take((size_t)n * A * ND * 4);
     l.ball = take((size_t)n * 13 * 4);
-    l.flags = take((size_t)n * 4);
+    l.flags = take((size_t)n * A * 4);
     l.episode = take((size_t)n * 4);
     l.serve = take((size_t)n * 3 * 4);
     l.total = o;
@@ -636,7 +687,8 @@ bool validate(const ppenv_config* c) {
     if (!c) { set_err("config is NULL"); return false; }
     if (c->abi_version != PPENV_ABI_VERSION) { set_err("config.abi_version does not match this library"); return false; }
     if (c->num_envs <= 0) { set_err("num_envs must be positive"); return false; }
-    if (c->variant < PPENV_VARIANT_T3 || c->variant > PPENV_VARIANT_TN) { set_err("unknown task variant"); return false; }
+    if (c->variant < PPENV_VARIANT_T3 || c->variant > PPENV_VARIANT_T4) { set_err("unknown task variant"); return false; }
+    if (c->num_humanoids != agents_of(c)) { set_err("num_humanoids must be 2 for PPENV_VARIANT_T4 and 1 otherwise"); return false; }
     if (c->substeps < 1 || c->substeps > 16 || c->ball_substeps < 1 || c->ball_substeps > 64) { set_err("substeps / ball_substeps out of range"); return false; }
     if (!(c->dt > 0.f)) { set_err("dt must be positive"); return false; }
     if (!model_matches<ModelG1>(*c)) {
@@ -662,6 +714,7 @@ struct ppenv {
     bool owns_arena;
     int serve_on;
     int split;               // 1: step_kernel_split (two waves per 64 envs), 0: step_kernel
+    int agents;              // 1, or 2 for PPENV_VARIANT_T4
 };
 
 namespace {
@@ -680,7 +733,7 @@ const char* ppenv_last_error(void) { return g_err; }
 
 size_t ppenv_arena_bytes(const ppenv_config* cfg) {
     if (!cfg || cfg->num_envs <= 0) return 0;
-    return layout_for(cfg->num_envs).total;
+    return layout_for(cfg->num_envs, agents_of(cfg)).total;
 }
 
 int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, void* stream, ppenv** out) {
@@ -693,13 +746,15 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
     ppenv* e = new (std::nothrow) ppenv;
     if (!e) { set_err("out of host memory"); return PPENV_ENOMEM; }
     e->cfg = *cfg;
-    e->lay = layout_for(cfg->num_envs);
+    e->agents = agents_of(cfg);
+    e->lay = layout_for(cfg->num_envs, e->agents);
     e->serve_on = 0;
     {   // PPENV_STEP_KERNEL=fused|split forces a schedule (same arithmetic either way)
         // The two-wave schedule wins at every size measured (us per step, split vs one-wave: N = 16384 13.1 / 20.5,
         // 65536 19.6 / 22.8, 131072 35.3 / 41.5): it needs 187 VGPRs (two waves per SIMD) against 256 + 79 AGPRs.
         const char* k = getenv("PPENV_STEP_KERNEL");
         e->split = k ? (strcmp(k, "fused") != 0) : 1;
+        if (e->agents == 2) e->split = 1;   // the 4-actor variant has the three-wave schedule only
     }
     e->arena = nullptr;
     e->owns_arena = false;
@@ -724,7 +779,8 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
     hipStream_t s = (hipStream_t)stream;
     hipError_t err = hipMemsetAsync(e->arena, 0, l.total, s);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->K, e->buf, 0, 0);
+        if (e->agents == 2) hipLaunchKernelGGL((init_kernel<ModelG1, 2>), dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->K, e->buf, 0, 0);
+        else hipLaunchKernelGGL((init_kernel<ModelG1, 1>), dim3(grid_for(cfg->num_envs)), dim3(kBlock), 0, s, e->K, e->buf, 0, 0);
         err = hipGetLastError();
     }
     if (err != hipSuccess) {
@@ -749,6 +805,7 @@ void ppenv_destroy(ppenv* e) {
 int ppenv_buffers_of(ppenv* e, ppenv_buffers* out) {
     if (!e || !out) { set_err("NULL argument"); return PPENV_EINVAL; }
     out->num_envs = e->cfg.num_envs;
+    out->num_agents = e->agents;
     out->obs_buf = e->buf.obs; out->rew_buf = e->buf.rew;
     out->reset_buf = (int64_t*)e->buf.reset; out->progress_buf = (int64_t*)e->buf.progress;
     out->dof_pos = e->buf.dof_pos; out->dof_vel = e->buf.dof_vel; out->dof_force = e->buf.dof_force; out->ball = e->buf.ball;
@@ -765,8 +822,11 @@ int ppenv_config_of(ppenv* e, ppenv_config* out) {
 int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    if (e->split)
-        hipLaunchKernelGGL(step_kernel_split<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+    if (e->agents == 2)
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+                           actions_dev, e->serve_on);
+    else if (e->split)
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
                            actions_dev, e->serve_on);
     else
         hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
@@ -778,7 +838,8 @@ int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
 int ppenv_reset_all(ppenv* e, void* stream) {
     if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    hipLaunchKernelGGL(init_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, 1, e->serve_on);
+    if (e->agents == 2) hipLaunchKernelGGL((init_kernel<ModelG1, 2>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, 1, e->serve_on);
+    else hipLaunchKernelGGL((init_kernel<ModelG1, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, 1, e->serve_on);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
@@ -787,8 +848,9 @@ int ppenv_reduce_stats(ppenv* e, double* out_dev, void* stream) {
     if (!e || !out_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
     PP_HIP(hipMemsetAsync(out_dev, 0, 4 * sizeof(double), (hipStream_t)stream));
-    const int blocks = min(256, (e->cfg.num_envs + 255) / 256);
-    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e->cfg.num_envs, e->buf.rew, e->buf.progress,
+    const int rows = e->cfg.num_envs * e->agents;   // one row per agent: out[3] counts agents
+    const int blocks = min(256, (rows + 255) / 256);
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, e->agents, e->buf.rew, e->buf.progress,
                        e->buf.episode, out_dev);
     PP_HIP(hipGetLastError());
     return PPENV_OK;
@@ -800,6 +862,7 @@ int ppenv_post_physics_step(ppenv* e, const float* rigid_body_states_dev, float*
         set_err("NULL argument");
         return PPENV_EINVAL;
     }
+    if (e->agents != 1) { set_err("ppenv_post_physics_step serves the 3-actor variants; the 4-actor entry is ppenv_t4_rewards"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
     hipLaunchKernelGGL(post_physics_kernel, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf,
                        rigid_body_states_dev, root_states_dev, dof_states_dev, dof_force_dev, pre_ball_vx_dev, e->serve_on);
@@ -858,7 +921,8 @@ int ppenv_debug_read_stamps(unsigned long long* dst, size_t count) {
 
 size_t ppenv_state_bytes(ppenv* e) {
     if (!e) return 0;
-    return (size_t)e->cfg.num_envs * ((ND * 3 + 13) * 4 + 4 + 4 + 8 + 8);
+    const size_t A = (size_t)e->agents;
+    return (size_t)e->cfg.num_envs * ((A * ND * 3 + 13) * 4 + A * 4 + 4 + A * 8 + A * 8);
 }
 
 static int state_io(ppenv* e, char* blob, size_t nbytes, bool to_host) {
@@ -866,10 +930,10 @@ static int state_io(ppenv* e, char* blob, size_t nbytes, bool to_host) {
     if (nbytes != ppenv_state_bytes(e)) { set_err("state blob size does not match this handle"); return PPENV_ESTATE; }
     if (int rc = use_device(e)) return rc;
     PP_HIP(hipDeviceSynchronize());
-    const size_t n = (size_t)e->cfg.num_envs;
+    const size_t n = (size_t)e->cfg.num_envs, A = (size_t)e->agents;
     struct Part { void* dev; size_t bytes; };
-    const Part parts[] = {{e->buf.dof_pos, n * ND * 4}, {e->buf.dof_vel, n * ND * 4}, {e->buf.dof_force, n * ND * 4}, {e->buf.ball, n * 13 * 4},
-                          {e->buf.flags, n * 4}, {e->buf.episode, n * 4}, {e->buf.progress, n * 8}, {e->buf.reset, n * 8}};
+    const Part parts[] = {{e->buf.dof_pos, n * A * ND * 4}, {e->buf.dof_vel, n * A * ND * 4}, {e->buf.dof_force, n * A * ND * 4}, {e->buf.ball, n * 13 * 4},
+                          {e->buf.flags, n * A * 4}, {e->buf.episode, n * 4}, {e->buf.progress, n * A * 8}, {e->buf.reset, n * A * 8}};
     for (const Part& p : parts) {
         if (to_host) PP_HIP(hipMemcpy(blob, p.dev, p.bytes, hipMemcpyDeviceToHost));
         else PP_HIP(hipMemcpy(p.dev, blob, p.bytes, hipMemcpyHostToDevice));

@@ -82,23 +82,31 @@ struct RewardConsts {
     int32_t variant, max_episode_length;
     float alpha, power_coefficient, penalty, hit_table_reward, not_hit_table_penalty;
 };
+// Where one humanoid stands: everything that differs between humanoid 1 and humanoid 2 of the 4-actor variant
+// (the arm model itself is the same compiled chain).
+struct ArmSite {
+    float base_pos[3], base_rot[9], base_grav[3];                         // chain base; base_grav = base_rot^T (0, 0, -gravity_z)
+    float static_a[PPENV_MAX_SHAPES][3], static_b[PPENV_MAX_SHAPES][3];   // world end points of the static shapes
+    float bound_center[3];
+    float root_pos[3], root_rot[9], root_quat[4], hinv[4];   // pelvis (obs_body[0]); hinv = calc_heading_quat_inv(root_quat)
+};
+constexpr int kMaxArms = 2;
 struct StepConsts {
     int32_t num_envs, env_id_offset, substeps, ball_substeps;
+    int32_t num_arms, pad_;                      // humanoids per env (1; 2 for the 4-actor variant)
     uint64_t seed;
     RewardConsts rc;
     float h, clip_actions;                       // substep length dt / substeps
-    float base_pos[3], base_rot[9], base_grav[3]; // chain base; base_grav = base_rot^T (0, 0, -gravity_z)
+    ArmSite site[kMaxArms];                      // site[1] is used by PPENV_VARIANT_T4 only
     // ball / contacts
     float hb, inv_m, inv_h;                      // micro-step length, 1 / ball_substeps, 1 / h
     float contact_offset, bounce_threshold, depen_cap, ball_r, inv_kr, stick_factor, gdv, damp;
     float ground_z, ground_e, ground_mu;
     ppenv_box table, net;
-    float bound_center[3], bound_r2;
+    float bound_r2;
     float paddle_e, paddle_mu;
     float shape_e[PPENV_MAX_SHAPES], shape_mu[PPENV_MAX_SHAPES];
-    float static_a[PPENV_MAX_SHAPES][3], static_b[PPENV_MAX_SHAPES][3];   // world end points of the static shapes
     // task
-    float root_pos[3], root_rot[9], root_quat[4], hinv[4];   // pelvis (obs_body[0]); hinv = calc_heading_quat_inv(root_quat)
     float table_pos[3], table_quat[4];
     float serve_speed_lo, serve_speed_hi, serve_tilt_lo_deg, serve_tilt_hi_deg, serve_tilt_z_lo_deg, serve_tilt_z_hi_deg;
     float ball_init_pos[3], ball_init_quat[4];
@@ -185,6 +193,13 @@ PP_HD M3 joint_rot(const float* r0, float c, float s) {
     return e;
 }
 
+// xyzw unit quaternion -> row-major rotation matrix
+PP_HD void quat_to_rot(const float q[4], float r[9]) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    r[0] = 1.f - 2.f * (y * y + z * z); r[1] = 2.f * (x * y - z * w); r[2] = 2.f * (x * z + y * w);
+    r[3] = 2.f * (x * y + z * w); r[4] = 1.f - 2.f * (x * x + z * z); r[5] = 2.f * (y * z - x * w);
+    r[6] = 2.f * (x * z - y * w); r[7] = 2.f * (y * z + x * w); r[8] = 1.f - 2.f * (x * x + y * y);
+}
 // rotation matrix -> xyzw quaternion with w >= 0
 PP_HD void rot_to_quat(const M3& r, float q[4]) {
     float tr = r.m[0] + r.m[4] + r.m[8];
@@ -228,7 +243,7 @@ PP_HD void sincos_small(float x, float& s, float& c) {
     c = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
 }
 // generate_random_speed_for_ball: TT:296-323 / T3:289-305 / TN:301-328
-PP_HD V3 serve_velocity(const StepConsts& K, uint32_t gid, uint32_t episode) {
+PP_HD V3 serve_velocity(const StepConsts& K, uint32_t gid, uint32_t episode) {   // T4:299-326 = TT's
     const float deg = 0.017453292519943295f;
     float u0 = rng_uniform(K.seed, gid, episode, 0);
     float u1 = rng_uniform(K.seed, gid, episode, 1);
@@ -240,7 +255,7 @@ PP_HD V3 serve_velocity(const StepConsts& K, uint32_t gid, uint32_t episode) {
     sincos_small(a, sa, ca);
     sincos_small(az, sz, cz);
     if (K.rc.variant == PPENV_VARIANT_T3) return mk(-speed * ca, -speed * sa, 0.f);                 // T3:296-300
-    if (K.rc.variant == PPENV_VARIANT_TT) return mk(-speed * ca * cz, -speed * sa * sz, -speed * sa); // TT:307-318 (sic)
+    if (K.rc.variant == PPENV_VARIANT_TT || K.rc.variant == PPENV_VARIANT_T4) return mk(-speed * ca * cz, -speed * sa * sz, -speed * sa); // TT:307-318 (sic)
     return mk(-speed * ca * cz, speed * sa * cz, speed * sz);                                     // TN:312-323
 }
 
@@ -280,9 +295,9 @@ struct BodyState { V3 pos; M3 rot; V3 lin, ang; };
 // Forward kinematics sweep base -> tip.  Fills JointSave::{c,s,w,v}; hands every
 // link's world transform to `vis(i, Rw, pw, w_link, v_link)`.
 template <class T, class Visitor>
-PP_HD void fk_sweep(const StepConsts& K, const float* q, const float* qd, JointSave* js, Visitor& vis) {
-    M3 Rp = ldm(K.base_rot);
-    V3 pp = ld3(K.base_pos);
+PP_HD void fk_sweep(const ArmSite& S, const float* q, const float* qd, JointSave* js, Visitor& vis) {
+    M3 Rp = ldm(S.base_rot);
+    V3 pp = ld3(S.base_pos);
     V3 wp = mk(0, 0, 0), vp = mk(0, 0, 0);
 #pragma unroll
     for (int i = 0; i < ND; i++) {
@@ -328,10 +343,10 @@ struct GeomVisitor {
     }
 };
 template <class T>
-PP_HD void static_geometry(const StepConsts& K, ArmGeom<T::kShapes>& g) {
+PP_HD void static_geometry(const ArmSite& S, ArmGeom<T::kShapes>& g) {
 #pragma unroll
     for (int s = 0; s < T::kShapes; s++)
-        if (T::shape_link(s) < 0) { g.a[s] = ld3(K.static_a[s]); g.b[s] = ld3(K.static_b[s]); g.va[s] = mk(0, 0, 0); g.vb[s] = mk(0, 0, 0); }
+        if (T::shape_link(s) < 0) { g.a[s] = ld3(S.static_a[s]); g.b[s] = ld3(S.static_b[s]); g.va[s] = mk(0, 0, 0); g.vb[s] = mk(0, 0, 0); }
 }
 
 // geometry + the observed bodies (obs_body[1..7] are the chain links, [8],[9] ride on the last link).
@@ -362,16 +377,16 @@ struct BodyVisitor {
     }
 };
 template <bool FULL>
-PP_HD void static_body(const StepConsts& K, BodyState& b) {   // obs_body[0]: the pelvis, fixed at the root pose
-    b.pos = ld3(K.root_pos); b.lin = mk(0, 0, 0);
-    if (FULL) { b.rot = ldm(K.root_rot); b.ang = mk(0, 0, 0); }
+PP_HD void static_body(const ArmSite& S, BodyState& b) {   // obs_body[0]: the pelvis, fixed at the root pose
+    b.pos = ld3(S.root_pos); b.lin = mk(0, 0, 0);
+    if (FULL) { b.rot = ldm(S.root_rot); b.ang = mk(0, 0, 0); }
 }
 
 // --------------------------------------------------- ABA passes 2 and 3 (RBDA 7.1)
 // tau / arm_eff: drive torque and joint-space inertia added on the diagonal
 // (armature + the implicit PD terms).  Returns qdd.
 template <class T>
-PP_HD void aba_solve(const StepConsts& K, JointSave* js, const float* qd, const float* tau, const float* arm_eff, float* qdd) {
+PP_HD void aba_solve(const ArmSite& S, JointSave* js, const float* qd, const float* tau, const float* arm_eff, float* qdd) {
     // articulated inertia / bias force handed down by the child, in this link's coordinates
     S3 cA = {0, 0, 0, 0, 0, 0}, cD = {0, 0, 0, 0, 0, 0};
     M3 cB = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
@@ -440,7 +455,7 @@ PP_HD void aba_solve(const StepConsts& K, JointSave* js, const float* qd, const 
     }
     // pass 3: accelerations base -> tip; the base "accelerates" upward by |g|
     V3 aw = mk(0, 0, 0);
-    V3 av = ld3(K.base_grav);
+    V3 av = ld3(S.base_grav);
 #pragma unroll
     for (int i = 0; i < ND; i++) {
         const JointKin J = T::kin(i);
@@ -462,7 +477,7 @@ PP_HD void aba_solve(const StepConsts& K, JointSave* js, const float* qd, const 
 // the joint-space inertia diagonal); a joint whose explicit PD torque exceeds the
 // effort limit gets the constant limit torque instead.
 template <class T>
-PP_HD void arm_substep(const StepConsts& K, JointSave* js, float* q, float* qd, const float* target, float h, float* tau_drive) {
+PP_HD void arm_substep(const ArmSite& S, JointSave* js, float* q, float* qd, const float* target, float h, float* tau_drive) {
     float tau[ND], arm[ND], qdd[ND];
     bool sat[ND];
 #pragma unroll
@@ -475,7 +490,7 @@ PP_HD void arm_substep(const StepConsts& K, JointSave* js, float* q, float* qd, 
         tau[d] = sat[d] ? copysignf(J.effort, t_exp) : t_imp;
         arm[d] = sat[d] ? J.armature : J.armature + h * J.kd + h * h * J.kp;
     }
-    aba_solve<T>(K, js, qd, tau, arm, qdd);
+    aba_solve<T>(S, js, qd, tau, arm, qdd);
 #pragma unroll
     for (int d = 0; d < ND; d++) {
         const JointDrive J = T::drive(d);
@@ -593,8 +608,9 @@ PP_HD V3 lerp(V3 a, V3 b, float f) { return madd(a, b - a, f); }
 // which move linearly from their pose at the START of the substep with the velocities they have there
 // (contacts are generated from start-of-step poses, as PhysX does).  Within a substep the ball and the arm
 // therefore do not depend on each other — which is what lets the two-wave kernel run them concurrently.
-template <class T>
-PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes>& g) {
+// A = number of humanoids (2 for the 4-actor variant: humanoid 1's shapes are visited first, then humanoid 2's).
+template <class T, int A>
+PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> (&g)[A]) {
     const int M = K.ball_substeps;
     const float hb = K.hb, h = K.h;
     BallConsts k;
@@ -606,7 +622,6 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes>&
     k.stick_factor = K.stick_factor;
     const float gdv = K.gdv, damp = K.damp;
     const float ground_z = K.ground_z, ground_e = K.ground_e, ground_mu = K.ground_mu;
-    const V3 bc = ld3(K.bound_center);
     const ppenv_box& table = K.table;
     const ppenv_box& net = K.net;
     // broad-phase spheres of the humanoid shapes for this substep
@@ -615,16 +630,18 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes>&
     const float reach = k.r + k.contact_offset + 1e-4f;
     const float pad_rr = sqrtf(P.radius * P.radius + P.half_thickness * P.half_thickness) + reach;
     const float pad_r2 = pad_rr * pad_rr;
-    V3 sc0[T::kShapes], svc[T::kShapes];
-    float sr2[T::kShapes];
+    V3 sc0[A][T::kShapes], svc[A][T::kShapes];
+    float sr2[A][T::kShapes];
 #pragma unroll
-    for (int s = 0; s < T::kShapes; s++) {
-        sc0[s] = (g.a[s] + g.b[s]) * 0.5f;
-        svc[s] = (g.va[s] + g.vb[s]) * 0.5f;
-        V3 hl = (g.b[s] - g.a[s]) * 0.5f;
-        float rr = sqrtf(dot(hl, hl)) + T::shape(s).radius + reach;
-        sr2[s] = rr * rr;
-    }
+    for (int arm = 0; arm < A; arm++)
+#pragma unroll
+        for (int s = 0; s < T::kShapes; s++) {
+            sc0[arm][s] = (g[arm].a[s] + g[arm].b[s]) * 0.5f;
+            svc[arm][s] = (g[arm].va[s] + g[arm].vb[s]) * 0.5f;
+            V3 hl = (g[arm].b[s] - g[arm].a[s]) * 0.5f;
+            float rr = sqrtf(dot(hl, hl)) + T::shape(s).radius + reach;
+            sr2[arm][s] = rr * rr;
+        }
     for (int m = 0; m < M; m++) {
         const float t = (float)m * hb;   // time since the start of the substep
         b.v.z += gdv;
@@ -632,32 +649,36 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes>&
         contact_resolve(k, b, mk(0, 0, 1), b.p.z - ground_z - k.r, mk(0, 0, 0), ground_e, ground_mu);
         contact_box(k, b, table);
         contact_box(k, b, net);
-        V3 db = b.p - bc;
-#if defined(PP_ABLATE) && PP_ABLATE == 1   // profiling build: no humanoid shapes
-        if (false) {
-#else
-        if (dot(db, db) < K.bound_r2) {
-#endif
-            // Broad phase: one bounding sphere per shape (centre moves linearly over the substep).  The
-            // narrow phase behind it is unchanged, and a ball outside the sphere cannot touch the shape,
-            // so results are identical; but some lane of a wave is nearly always near the arm, and the
-            // wave then pays ~10 instructions per shape instead of the full closest-point code.
-            V3 cc = madd(g.pc, g.vpc, t);
-            V3 dpc = b.p - cc;
-            if (dot(dpc, dpc) < pad_r2) {
-                V3 nn = madd(g.pn, g.pnd, t);
-                nn = nn * rsq_fast(dot(nn, nn));
-                contact_disc(k, b, cc, nn, g.vpc, g.pnd, P.radius, P.half_thickness, pad_e, pad_mu);
-            }
 #pragma unroll
-            for (int s = 0; s < T::kShapes; s++) {
-                V3 dsc = b.p - madd(sc0[s], svc[s], t);
-                if (dot(dsc, dsc) < sr2[s]) {
-                    const float radius = T::shape(s).radius, e = K.shape_e[s], mu = K.shape_mu[s];
-                    if (T::shape_link(s) < 0)
-                        contact_capsule(k, b, g.a[s], g.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
-                    else
-                        contact_capsule(k, b, madd(g.a[s], g.va[s], t), madd(g.b[s], g.vb[s], t), g.va[s], g.vb[s], radius, e, mu);
+        for (int arm = 0; arm < A; arm++) {
+            const ArmGeom<T::kShapes>& ga = g[arm];
+            V3 db = b.p - ld3(K.site[arm].bound_center);
+#if defined(PP_ABLATE) && PP_ABLATE == 1   // profiling build: no humanoid shapes
+            if (false) {
+#else
+            if (dot(db, db) < K.bound_r2) {
+#endif
+                // Broad phase: one bounding sphere per shape (centre moves linearly over the substep).  The
+                // narrow phase behind it is unchanged, and a ball outside the sphere cannot touch the shape,
+                // so results are identical; but some lane of a wave is nearly always near the arm, and the
+                // wave then pays ~10 instructions per shape instead of the full closest-point code.
+                V3 cc = madd(ga.pc, ga.vpc, t);
+                V3 dpc = b.p - cc;
+                if (dot(dpc, dpc) < pad_r2) {
+                    V3 nn = madd(ga.pn, ga.pnd, t);
+                    nn = nn * rsq_fast(dot(nn, nn));
+                    contact_disc(k, b, cc, nn, ga.vpc, ga.pnd, P.radius, P.half_thickness, pad_e, pad_mu);
+                }
+#pragma unroll
+                for (int s = 0; s < T::kShapes; s++) {
+                    V3 dsc = b.p - madd(sc0[arm][s], svc[arm][s], t);
+                    if (dot(dsc, dsc) < sr2[arm][s]) {
+                        const float radius = T::shape(s).radius, e = K.shape_e[s], mu = K.shape_mu[s];
+                        if (T::shape_link(s) < 0)
+                            contact_capsule(k, b, ga.a[s], ga.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
+                        else
+                            contact_capsule(k, b, madd(ga.a[s], ga.va[s], t), madd(ga.b[s], ga.vb[s], t), ga.va[s], ga.vb[s], radius, e, mu);
+                    }
                 }
             }
         }
@@ -724,7 +745,7 @@ PP_HD float compute_reward(const RewardConsts& c, const RewardIn& in, uint32_t& 
         bool missed = Bx < in.paddle.x - 1e-3f;                                                 // T3:1146
         if (missed) { reward = reward + penalty; die = 1; }                                     // T3:1149,1158
         if (Bz < threshold) die = 1;                                                            // T3:1161
-    } else if (variant == PPENV_VARIANT_TT) {
+    } else if (variant == PPENV_VARIANT_TT || variant == PPENV_VARIANT_T4) {   // T4:1113-1278 == TT:1105-1270
         V3 dp = in.paddle - in.bp;
         float dist = sqrtf(dp.x * dp.x + dp.y * dp.y + dp.z * dp.z);                            // TT:1144-1146
         float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                                  // TT:1147
@@ -766,66 +787,109 @@ PP_HD float compute_reward(const RewardConsts& c, const RewardIn& in, uint32_t& 
     return reward;
 }
 
+// compute_humanoid2_pingpong_reward T4:1280-1439: TT's reward mirrored for the humanoid at the far end of the table
+PP_HD float compute_reward_side2(const RewardConsts& c, const RewardIn& in, uint32_t& flags, long long& reset) {
+    const float Bx = in.bp.x, By = in.bp.y, Bz = in.bp.z, vx = in.vx, pre_vx = in.pre_vx;
+    uint32_t f = flags;
+    V3 dp = in.paddle - in.bp;
+    float dist = sqrtf(dp.x * dp.x + dp.y * dp.y + dp.z * dp.z);
+    float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                                     // T4:1305-1308
+    bool cond = pre_vx > 0.f && vx < 0.f;                                                      // T4:1328
+    float vel_reward = (cond && !(f & PPENV_FLAG_COND_CALC)) ? c.alpha * fabsf(vx) : 0.f;
+    if (cond) f |= PPENV_FLAG_COND_CALC;
+    bool missed = Bx > in.humanoid_x + 0.05f;                                                  // T4:1344
+    float reward = missed ? 0.f + c.penalty : 0.f;
+    bool bounce = Bz < 0.83f && vx < 0.f && By < 0.6f && By > -0.6f;                           // T4:1359
+    float hit = 0.f;
+    bool early = Bx > 1.06f && bounce;                                                         // T4:1363
+    if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.not_hit_table_penalty;
+    if (early) { f |= PPENV_FLAG_REWARD_CALC; f &= ~PPENV_FLAG_NO_BOUNCE; }
+    bool inx = Bx < 1.06f && Bx > 0.4f;                                                        // T4:1374
+    bool good = inx && bounce && (f & PPENV_FLAG_NO_BOUNCE);
+    if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.hit_table_reward;
+    if (good) f |= PPENV_FLAG_REWARD_CALC;
+    if (Bx <= 0.4f && vx < 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = c.not_hit_table_penalty;   // T4:1384
+    if (Bx <= 0.4f) f |= PPENV_FLAG_REWARD_CALC;                                               // T4:1389
+    float net = (Bx > 1.7f && Bx < 1.8f && vx < 0.f && By < 0.4f && By > -0.4f && Bz > 0.98f && Bz < 1.14f) ? 400.f : 0.f;   // T4:1401-1409
+    float power_reward = -c.power_coefficient * in.power;
+    reward += (((pos_reward + power_reward) + vel_reward) + hit) + net;                        // T4:1426
+    flags = f;
+    reset = (in.progress >= (long long)c.max_episode_length - 1) ? 1 : (Bz < 0.1f ? 1 : 0);   // T4:1431-1437
+    return reward;
+}
+
 // ------------------------------------------------------------- the fused step
-struct EnvState {
-    float q[ND], qd[ND], dof_force[ND];
+// A = humanoids per env (1; 2 for the 4-actor variant): arm a's joints are q[a * ND ...], its sticky flags flags[a]
+template <int A>
+struct EnvStateT {
+    float q[A * ND], qd[A * ND], dof_force[A * ND];
     Ball ball;
     long long progress;
-    uint32_t flags, episode;
+    uint32_t flags[A], episode;
 };
+using EnvState = EnvStateT<1>;
 
 // Physics part of one VecTask.step for one env (pre_physics_step + gym.simulate):
-// updates st in place, returns the pre-reset observed-body states and pre_vx.
-template <class T>
-PP_HD void simulate_env(const StepConsts& K, const float* actions, EnvState& st, BodyState* bodies, float& pre_vx) {
-    float target[ND];
+// updates st in place, returns the pre-reset observed-body states (bodies[a * NB + j]) and pre_vx.
+// actions: arm a's seven values at actions[a * ND ...] (rows A*e + a of the [A*N, 7] tensor are adjacent).
+template <class T, int A>
+PP_HD void simulate_env(const StepConsts& K, const float* actions, EnvStateT<A>& st, BodyState* bodies, float& pre_vx) {
+    float target[A * ND];
 #pragma unroll
-    for (int d = 0; d < ND; d++) {   // VecTask.step clamp + TT:1008 (offset/scale TT:664-665)
+    for (int d = 0; d < A * ND; d++) {   // VecTask.step clamp + TT:1008 (offset/scale TT:664-665)
         const float clip = K.clip_actions;
         float a = fminf(fmaxf(actions[d], -clip), clip);
-        const float lo = T::drive(d).lower, hi = T::drive(d).upper;
+        const float lo = T::drive(d % ND).lower, hi = T::drive(d % ND).upper;
         target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;
     }
     pre_vx = st.ball.v.x;   // TT:1020
     const int substeps = K.substeps;
     const float h = K.h;
-    JointSave js[ND];
-    ArmGeom<T::kShapes> g;
-    static_geometry<T>(K, g);
-    {
-        GeomVisitor<T> gv(g);
-        fk_sweep<T>(K, st.q, st.qd, js, gv);
+    JointSave js[A][ND];
+    ArmGeom<T::kShapes> g[A];
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        static_geometry<T>(K.site[a], g[a]);
+        GeomVisitor<T> gv(g[a]);
+        fk_sweep<T>(K.site[a], &st.q[a * ND], &st.qd[a * ND], js[a], gv);
     }
     PP_STAMP_AT(2);
     for (int s = 0; s < substeps; s++) {
-        ball_substep<T>(K, st.ball, g);                                   // against the arm as it is at the substep's start
+        ball_substep<T, A>(K, st.ball, g);                                // against the arms as they are at the substep's start
         PP_STAMP_AT(3 + 3 * s);
-        arm_substep<T>(K, js, st.q, st.qd, target, h, st.dof_force);
+#pragma unroll
+        for (int a = 0; a < A; a++)
+            arm_substep<T>(K.site[a], js[a], &st.q[a * ND], &st.qd[a * ND], &target[a * ND], h, &st.dof_force[a * ND]);
         PP_STAMP_AT(4 + 3 * s);
-        if (s + 1 < substeps) {
-            GeomVisitor<T> gv(g);
-            fk_sweep<T>(K, st.q, st.qd, js, gv);
-        } else {
-            BodyVisitor<T, false> bv(g, bodies);
-            fk_sweep<T>(K, st.q, st.qd, js, bv);
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+            if (s + 1 < substeps) {
+                GeomVisitor<T> gv(g[a]);
+                fk_sweep<T>(K.site[a], &st.q[a * ND], &st.qd[a * ND], js[a], gv);
+            } else {
+                BodyVisitor<T, false> bv(g[a], &bodies[a * NB]);
+                fk_sweep<T>(K.site[a], &st.q[a * ND], &st.qd[a * ND], js[a], bv);
+            }
         }
         PP_STAMP_AT(5 + 3 * s);
     }
-    static_body<false>(K, bodies[0]);
+#pragma unroll
+    for (int a = 0; a < A; a++) static_body<false>(K.site[a], bodies[a * NB]);
 }
 
 // FK only (create / reset_all / refresh): observed-body states of the current dof state
 template <class T>
-PP_HD void bodies_of_state(const StepConsts& K, const float* q, const float* qd, BodyState* bodies) {
+PP_HD void bodies_of_state(const ArmSite& S, const float* q, const float* qd, BodyState* bodies) {
     JointSave js[ND];
     ArmGeom<T::kShapes> g;
     BodyVisitor<T, true> bv(g, bodies);
-    fk_sweep<T>(K, q, qd, js, bv);
-    static_body<true>(K, bodies[0]);
+    fk_sweep<T>(S, q, qd, js, bv);
+    static_body<true>(S, bodies[0]);
 }
 
 // initial simulation state of an env with the serve of `episode` (TT:853-867)
-PP_HD void reset_state(const StepConsts& K, EnvState& st, V3 serve, bool reset_dofs) {
+template <int A>
+PP_HD void reset_state(const StepConsts& K, EnvStateT<A>& st, V3 serve, bool reset_dofs) {
     st.ball.p = ld3(K.ball_init_pos);
 #pragma unroll
     for (int k = 0; k < 4; k++) st.ball.quat[k] = K.ball_init_quat[k];
@@ -833,7 +897,7 @@ PP_HD void reset_state(const StepConsts& K, EnvState& st, V3 serve, bool reset_d
     st.ball.w = mk(0, 0, 0);
     if (reset_dofs) {
 #pragma unroll
-        for (int d = 0; d < ND; d++) { st.q[d] = K.init_dof_pos[d]; st.qd[d] = K.init_dof_vel[d]; }
+        for (int d = 0; d < A * ND; d++) { st.q[d] = K.init_dof_pos[d % ND]; st.qd[d] = K.init_dof_vel[d % ND]; }   // T4:873: both humanoids
     }
 }
 
@@ -877,37 +941,53 @@ PP_HD void write_obs(const V3* body_pos, const V3* body_vel, const float hinv[4]
 // post_physics_step for one env of the fused path (TT:1022-1039): progress, reward,
 // masked reset, observations.  serve_override: used instead of the RNG when non-null.
 // BODY_OBS = false: the body block obs[0:60] has already been written (by the arm wave of step_kernel_split).
-template <bool BODY_OBS = true, class Store>
-PP_HD void post_physics_env(const StepConsts& K, uint32_t gid, EnvState& st, const BodyState* bodies, float pre_vx,
-                            const V3* serve_override, float& rew, long long& reset, Store& store) {
+// A = 2 (4-actor variant, the build's completion of T4's two-agent wiring): agent a gets rew[a] and the obs row
+// stores[a]; both sides see the same ball, progress and reset rule (T4:1431-1437 on either side), so the env resets
+// as one.  Like the class's only call site (T4:746-747) both reward functions receive the WHOLE dof tensors: the
+// power term sums over all A*7 dofs.  Each agent observes its own seven dofs (80 = 30+30+7+7+3+3, T4:98).
+template <int A, bool BODY_OBS = true, class Store>
+PP_HD void post_physics_env(const StepConsts& K, uint32_t gid, EnvStateT<A>& st, const BodyState* bodies, float pre_vx,
+                            const V3* serve_override, float* rew, long long& reset, Store* stores) {
     st.progress += 1;                                                            // TT:1023
     RewardIn in;
-    in.humanoid_x = K.root_pos[0];
+    in.humanoid_x = K.site[0].root_pos[0];
     in.paddle = bodies[NB - 1].pos;
     in.pre_vx = pre_vx;
     in.bp = st.ball.p;
     in.vx = st.ball.v.x;
     float power = 0.f;
 #pragma unroll
-    for (int d = 0; d < ND; d++) power += fabsf(st.dof_force[d] * st.qd[d]);     // TT:1246
+    for (int d = 0; d < A * ND; d++) power += fabsf(st.dof_force[d] * st.qd[d]);   // TT:1246
     in.power = power;
     in.progress = st.progress;
-    rew = compute_reward(K.rc, in, st.flags, reset);
+    rew[0] = compute_reward(K.rc, in, st.flags[0], reset);
+    if (A > 1) {
+        RewardIn in2 = in;
+        in2.humanoid_x = K.site[A - 1].root_pos[0];
+        in2.paddle = bodies[(A - 1) * NB + NB - 1].pos;
+        long long reset2;
+        rew[A - 1] = compute_reward_side2(K.rc, in2, st.flags[A - 1], reset2);
+        reset = (reset | reset2) ? 1 : 0;
+    }
     if (reset) {                                                                 // TT:1034-1036 -> 847-906
         st.episode += 1;
         V3 serve = serve_override ? *serve_override : serve_velocity(K, gid, st.episode);
         reset_state(K, st, serve, K.rc.variant != PPENV_VARIANT_TN);            // TN:888-901 keeps the dof state
         st.progress = 0;                                                         // TT:902
-        st.flags = PPENV_FLAG_NO_BOUNCE;                                         // TT:903-905
+#pragma unroll
+        for (int a = 0; a < A; a++) st.flags[a] = PPENV_FLAG_NO_BOUNCE;          // TT:903-905
     }
     // TT:1039: dof / ball already show the reset state, body states are the pre-reset ones
-    if (BODY_OBS) {
-        V3 bpos[NB], bvel[NB];
 #pragma unroll
-        for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
-        write_obs_bodies(bpos, bvel, K.hinv, store);
+    for (int a = 0; a < A; a++) {
+        if (BODY_OBS) {
+            V3 bpos[NB], bvel[NB];
+#pragma unroll
+            for (int j = 0; j < NB; j++) { bpos[j] = bodies[a * NB + j].pos; bvel[j] = bodies[a * NB + j].lin; }
+            write_obs_bodies(bpos, bvel, K.site[a].hinv, stores[a]);
+        }
+        write_obs_tail(bodies[a * NB].pos, K.site[a].hinv, &st.q[a * ND], &st.qd[a * ND], st.ball.p, st.ball.v, stores[a]);
     }
-    write_obs_tail(bodies[0].pos, K.hinv, st.q, st.qd, st.ball.p, st.ball.v, store);
 }
 
 }  // namespace pp
@@ -925,13 +1005,30 @@ inline StepConsts make_step_consts(const ppenv_config& c) {
     StepConsts K;
     memset(&K, 0, sizeof K);
     K.num_envs = c.num_envs; K.env_id_offset = c.env_id_offset; K.substeps = c.substeps; K.ball_substeps = c.ball_substeps;
+    K.num_arms = c.num_humanoids == 2 ? 2 : 1;
     K.seed = c.seed;
     K.rc = make_reward_consts(c);
     K.h = c.dt / (float)c.substeps;
     K.clip_actions = c.clip_actions;
-    for (int k = 0; k < 3; k++) K.base_pos[k] = c.base_pos[k];
-    for (int k = 0; k < 9; k++) K.base_rot[k] = c.base_rot[k];
-    for (int k = 0; k < 3; k++) K.base_grav[k] = c.base_rot[6 + k] * (-c.gravity_z);   // base_rot^T (0, 0, -g): third row of base_rot
+    for (int a = 0; a < kMaxArms; a++) {
+        const bool second = a == 1 && c.num_humanoids == 2;   // a 3-actor config mirrors site[0] into site[1] (never read)
+        ArmSite& S = K.site[a];
+        const float* bp = second ? c.base2_pos : c.base_pos;
+        const float* br = second ? c.base2_rot : c.base_rot;
+        const float* rp = second ? c.humanoid2_root_pos : c.obs_body[0].xyz;
+        const float* rq = second ? c.humanoid2_root_quat : c.humanoid_root_quat;
+        const float* bc = second ? c.humanoid2_bound_center : c.humanoid_bound_center;
+        const ppenv_shape* sh = second ? c.shape2 : c.shape;
+        for (int k = 0; k < 3; k++) { S.base_pos[k] = bp[k]; S.root_pos[k] = rp[k]; S.bound_center[k] = bc[k]; }
+        for (int k = 0; k < 9; k++) S.base_rot[k] = br[k];
+        for (int k = 0; k < 3; k++) S.base_grav[k] = br[6 + k] * (-c.gravity_z);   // base_rot^T (0, 0, -g): third row of base_rot
+        for (int k = 0; k < 4; k++) S.root_quat[k] = rq[k];
+        if (second) quat_to_rot(rq, S.root_rot);
+        else for (int k = 0; k < 9; k++) S.root_rot[k] = c.obs_body[0].rot[k];
+        heading_quat_inv(rq, S.hinv);   // calc_heading_quat_inv of the fixed pelvis, once (TT:1684)
+        for (int s = 0; s < PPENV_MAX_SHAPES; s++)
+            for (int k = 0; k < 3; k++) { S.static_a[s][k] = sh[s].a[k]; S.static_b[s][k] = sh[s].b[k]; }
+    }
     K.inv_m = 1.0f / (float)c.ball_substeps;
     K.hb = K.h * K.inv_m;
     K.inv_h = 1.0f / K.h;
@@ -944,17 +1041,13 @@ inline StepConsts make_step_consts(const ppenv_config& c) {
     K.damp = fmaxf(1.0f - c.ball_angular_damping * K.hb, 0.0f);
     K.ground_z = c.ground_z; K.ground_e = c.ground_restitution; K.ground_mu = c.ground_friction;
     K.table = c.table; K.net = c.net;
-    for (int k = 0; k < 3; k++) K.bound_center[k] = c.humanoid_bound_center[k];
     K.bound_r2 = c.humanoid_bound_radius * c.humanoid_bound_radius;
     K.paddle_e = c.paddle_restitution; K.paddle_mu = c.paddle_friction;
     for (int s = 0; s < PPENV_MAX_SHAPES; s++) {
         K.shape_e[s] = c.shape[s].restitution; K.shape_mu[s] = c.shape[s].friction;
-        for (int k = 0; k < 3; k++) { K.static_a[s][k] = c.shape[s].a[k]; K.static_b[s][k] = c.shape[s].b[k]; }
     }
-    for (int k = 0; k < 3; k++) { K.root_pos[k] = c.obs_body[0].xyz[k]; K.table_pos[k] = c.table_root_pos[k]; K.ball_init_pos[k] = c.ball_init_pos[k]; }
-    for (int k = 0; k < 9; k++) K.root_rot[k] = c.obs_body[0].rot[k];
-    for (int k = 0; k < 4; k++) { K.root_quat[k] = c.humanoid_root_quat[k]; K.table_quat[k] = c.table_root_quat[k]; K.ball_init_quat[k] = c.ball_init_quat[k]; }
-    heading_quat_inv(c.humanoid_root_quat, K.hinv);   // calc_heading_quat_inv of the fixed pelvis, once (TT:1684)
+    for (int k = 0; k < 3; k++) { K.table_pos[k] = c.table_root_pos[k]; K.ball_init_pos[k] = c.ball_init_pos[k]; }
+    for (int k = 0; k < 4; k++) { K.table_quat[k] = c.table_root_quat[k]; K.ball_init_quat[k] = c.ball_init_quat[k]; }
     K.serve_speed_lo = c.serve_speed_lo; K.serve_speed_hi = c.serve_speed_hi;
     K.serve_tilt_lo_deg = c.serve_tilt_lo_deg; K.serve_tilt_hi_deg = c.serve_tilt_hi_deg;
     K.serve_tilt_z_lo_deg = c.serve_tilt_z_lo_deg; K.serve_tilt_z_hi_deg = c.serve_tilt_z_hi_deg;

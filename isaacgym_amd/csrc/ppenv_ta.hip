@@ -201,37 +201,6 @@ __global__ void ta_clear_counts_kernel(int n, uint32_t* flags, uint32_t* any_res
 
 // ---- 4-actor variant: compute_humanoid1_pingpong_reward (== TT's, T4:1113-1278) and its mirror
 // compute_humanoid2_pingpong_reward T4:1280-1439, both sides in one launch
-__device__ __forceinline__ float t4_reward_side2(const ppenv_t4_params& p, float humanoid_x, V3 paddle, float pre_vx, V3 bp, float vx,
-                                                 float power, long long progress, uint32_t& flags, long long& reset) {
-    const float Bx = bp.x, By = bp.y, Bz = bp.z;
-    uint32_t f = flags;
-    V3 dp = paddle - bp;
-    float dist = sqrtf(dp.x * dp.x + dp.y * dp.y + dp.z * dp.z);
-    float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                                     // T4:1305-1308
-    bool cond = pre_vx > 0.f && vx < 0.f;                                                      // T4:1328
-    float vel_reward = (cond && !(f & PPENV_FLAG_COND_CALC)) ? p.alpha_velocity_reward * fabsf(vx) : 0.f;
-    if (cond) f |= PPENV_FLAG_COND_CALC;
-    bool missed = Bx > humanoid_x + 0.05f;                                                     // T4:1344
-    float reward = missed ? 0.f + p.penalty : 0.f;
-    bool bounce = Bz < 0.83f && vx < 0.f && By < 0.6f && By > -0.6f;                           // T4:1359
-    float hit = 0.f;
-    bool early = Bx > 1.06f && bounce;                                                         // T4:1363
-    if (early && !(f & PPENV_FLAG_REWARD_CALC)) hit = p.not_hit_table_penalty;
-    if (early) { f |= PPENV_FLAG_REWARD_CALC; f &= ~PPENV_FLAG_NO_BOUNCE; }
-    bool inx = Bx < 1.06f && Bx > 0.4f;                                                        // T4:1374
-    bool good = inx && bounce && (f & PPENV_FLAG_NO_BOUNCE);
-    if (good && !(f & PPENV_FLAG_REWARD_CALC)) hit = p.hit_table_reward;
-    if (good) f |= PPENV_FLAG_REWARD_CALC;
-    if (Bx <= 0.4f && vx < 0.f && !(f & PPENV_FLAG_REWARD_CALC)) hit = p.not_hit_table_penalty;   // T4:1384
-    if (Bx <= 0.4f) f |= PPENV_FLAG_REWARD_CALC;                                               // T4:1389
-    float net = (Bx > 1.7f && Bx < 1.8f && vx < 0.f && By < 0.4f && By > -0.4f && Bz > 0.98f && Bz < 1.14f) ? 400.f : 0.f;   // T4:1401-1409
-    float power_reward = -p.power_coefficient * power;
-    reward += (((pos_reward + power_reward) + vel_reward) + hit) + net;                        // T4:1426
-    flags = f;
-    reset = (progress >= (long long)p.max_episode_length - 1) ? 1 : (Bz < 0.1f ? 1 : 0);
-    return reward;
-}
-
 __global__ __launch_bounds__(kTaBlock) void t4_rewards_kernel(const ppenv_t4_params p, const float* __restrict__ rb_states,
                                                                const float* __restrict__ root_states, const float* __restrict__ dof_states,
                                                                const float* __restrict__ dof_force, const float* __restrict__ pre_ball_vx,
@@ -265,7 +234,10 @@ __global__ __launch_bounds__(kTaBlock) void t4_rewards_kernel(const ppenv_t4_par
     uint32_t f1 = flags1_in[i], f2 = flags2_in[i];
     long long r1, r2;
     rew1[i] = compute_reward(c, in, f1, r1);
-    rew2[i] = t4_reward_side2(p, root[13], mk(rb[79 * 13], rb[79 * 13 + 1], rb[79 * 13 + 2]), in.pre_vx, bp, in.vx, power, in.progress, f2, r2);
+    RewardIn in2 = in;
+    in2.humanoid_x = root[13];
+    in2.paddle = mk(rb[79 * 13], rb[79 * 13 + 1], rb[79 * 13 + 2]);
+    rew2[i] = compute_reward_side2(c, in2, f2, r2);
     flags1[i] = f1; flags2[i] = f2; reset1[i] = r1; reset2[i] = r2;
 }
 

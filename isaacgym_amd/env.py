@@ -39,16 +39,19 @@ class PPEnv:
             itemsize = torch.empty((), dtype=dtype).element_size()
             return self.arena[off: off + count * itemsize].view(dtype).view(*shape)
 
-        nd = scene.NUM_DOF
-        self.obs_buf = view(b.obs_buf, n * scene.NUM_OBS, torch.float32, (n, scene.NUM_OBS))
-        self.rew_buf = view(b.rew_buf, n, torch.float32, (n,))
-        self.reset_buf = view(b.reset_buf, n, torch.int64, (n,))
-        self.progress_buf = view(b.progress_buf, n, torch.int64, (n,))
-        self.dof_pos = view(b.dof_pos, nd * n, torch.float32, (nd, n))       # SoA [7][N]
+        # A agents per env (2 for the 4-actor variant): agent a of env e owns row A*e + a of the surface tensors
+        A = self.num_agents = b.num_agents
+        rows = self.num_rows = n * A
+        nd = self.num_dofs = A * scene.NUM_DOF
+        self.obs_buf = view(b.obs_buf, rows * scene.NUM_OBS, torch.float32, (rows, scene.NUM_OBS))
+        self.rew_buf = view(b.rew_buf, rows, torch.float32, (rows,))
+        self.reset_buf = view(b.reset_buf, rows, torch.int64, (rows,))
+        self.progress_buf = view(b.progress_buf, rows, torch.int64, (rows,))
+        self.dof_pos = view(b.dof_pos, nd * n, torch.float32, (nd, n))       # SoA [7A][N]
         self.dof_vel = view(b.dof_vel, nd * n, torch.float32, (nd, n))
         self.dof_force = view(b.dof_force, nd * n, torch.float32, (nd, n))
         self.ball = view(b.ball, 13 * n, torch.float32, (13, n))             # SoA [13][N]
-        self.flags = view(b.flags, n, torch.int32, (n,))
+        self.flags = view(b.flags, A * n, torch.int32, (n,) if A == 1 else (A, n))
         self.episode = view(b.episode, n, torch.int32, (n,))
 
     def _stream(self):
@@ -68,10 +71,10 @@ class PPEnv:
 
     # ---- hot path
     def step(self, actions):
-        """actions: float32 [N, 7] on this device, contiguous.  One fused kernel launch, no sync."""
+        """actions: float32 [A*N, 7] on this device, contiguous.  One fused kernel launch, no sync."""
         if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous() \
-                or tuple(actions.shape) != (self.num_envs, scene.NUM_DOF):
-            actions = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, scene.NUM_DOF).contiguous()
+                or tuple(actions.shape) != (self.num_rows, scene.NUM_DOF):
+            actions = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_rows, scene.NUM_DOF).contiguous()
         _lib.check(self.L.ppenv_step(self.h, actions.data_ptr(), self._stream()))
 
     def reset_all(self):
@@ -103,16 +106,16 @@ class PPEnv:
         return out
 
     def refresh_root_states(self):
-        return self._refresh(self.L.ppenv_refresh_root_states, (self.num_envs, scene.NUM_ACTORS, 13))
+        return self._refresh(self.L.ppenv_refresh_root_states, (self.num_envs, self.num_agents + 2, 13))
 
     def refresh_dof_states(self):
-        return self._refresh(self.L.ppenv_refresh_dof_states, (self.num_envs, scene.NUM_DOF, 2))
+        return self._refresh(self.L.ppenv_refresh_dof_states, (self.num_envs, self.num_dofs, 2))
 
     def refresh_dof_force(self):
-        return self._refresh(self.L.ppenv_refresh_dof_force, (self.num_envs, scene.NUM_DOF))
+        return self._refresh(self.L.ppenv_refresh_dof_force, (self.num_envs, self.num_dofs))
 
     def refresh_rigid_body_states(self):
-        return self._refresh(self.L.ppenv_refresh_rigid_body_states, (self.num_envs, scene.NUM_BODIES, 13))
+        return self._refresh(self.L.ppenv_refresh_rigid_body_states, (self.num_envs, self.num_agents * scene.NUM_HUMANOID_BODIES + 2, 13))
 
     # ---- state I/O
     def set_serve_override(self, serve, on=True):

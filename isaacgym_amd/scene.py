@@ -22,12 +22,13 @@ NUM_DOF = 7
 NUM_OBS_BODIES = 10
 NUM_OBS = 80
 NUM_BODIES = 42
+NUM_HUMANOID_BODIES = 40
 NUM_ACTORS = 3
 MAX_SHAPES = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-VARIANT_T3, VARIANT_TT, VARIANT_TN = 0, 1, 2
-VARIANT_IDS = {"T3": VARIANT_T3, "TT": VARIANT_TT, "TN": VARIANT_TN}
+VARIANT_T3, VARIANT_TT, VARIANT_TN, VARIANT_T4 = 0, 1, 2, 3
+VARIANT_IDS = {"T3": VARIANT_T3, "TT": VARIANT_TT, "TN": VARIANT_TN, "T4": VARIANT_T4}
 
 FLAG_REWARD_CALC, FLAG_COND_CALC, FLAG_NO_BOUNCE, FLAG_MISSED_CALC = 1, 2, 4, 8
 
@@ -36,6 +37,7 @@ TASK_VARIANTS = {
     "HumanoidPingpongG1": "T3",
     "HumanoidPingpongTiltG1": "TT",
     "HumanoidPingpongTiltNoEarlyStopG1": "TN",
+    "Humanoid12PingpongTiltG1": "T4",
 }
 
 
@@ -92,12 +94,15 @@ class Config(C.Structure):
         ("max_episode_length", C.c_int32), ("alpha_velocity_reward", C.c_float),
         ("power_coefficient", C.c_float), ("penalty", C.c_float), ("hit_table_reward", C.c_float),
         ("not_hit_table_penalty", C.c_float),
+        ("num_humanoids", C.c_int32), ("base2_pos", C.c_float * 3), ("base2_rot", C.c_float * 9),
+        ("humanoid2_root_pos", C.c_float * 3), ("humanoid2_root_quat", C.c_float * 4),
+        ("shape2", Shape * MAX_SHAPES), ("humanoid2_bound_center", C.c_float * 3),
     ]
 
 
 class Buffers(C.Structure):
     _fields_ = [
-        ("num_envs", C.c_int32),
+        ("num_envs", C.c_int32), ("num_agents", C.c_int32),
         ("obs_buf", C.c_void_p), ("rew_buf", C.c_void_p), ("reset_buf", C.c_void_p),
         ("progress_buf", C.c_void_p), ("dof_pos", C.c_void_p), ("dof_vel", C.c_void_p),
         ("dof_force", C.c_void_p), ("ball", C.c_void_p), ("flags", C.c_void_p), ("episode", C.c_void_p),
@@ -311,6 +316,17 @@ TASK_CFGS = {
 }
 
 
+# 4-actor variant (T4).  No yaml of its own in the reference (tasks/__init__.py:52,122 register the class, cfg/task has
+# no file): env / sim values are the Tilt yaml's, poses and materials are the class's (T4:525-526,555-556,583-585,625-631).
+TASK_CFGS["T4"] = dict(
+    name="Humanoid12PingpongTiltG1",
+    env=dict(TASK_CFGS["TT"]["env"], numEnvs=1024),
+    sim=dict(_SIM_DEFAULT),
+    scene=dict(TASK_CFGS["TT"]["scene"],
+               humanoid2_pos=(3.5, 0.0, 1.0), humanoid2_quat=(0.0, 0.0, 1.0, 0.0)),   # T4:555-556
+)
+
+
 def default_task_cfg(variant):
     """A fresh copy of the task cfg dict (`env`, `sim`, `scene`) for variant 'T3' | 'TT' | 'TN'."""
     return copy.deepcopy(TASK_CFGS[variant])
@@ -488,6 +504,33 @@ def build_config(variant, cfg=None, num_envs=None, seed=0, device_id=0, env_id_o
     c.penalty = env["penalty"]
     c.hit_table_reward = env["hitTableReward"]
     c.not_hit_table_penalty = env["nothitTablePenalty"]
+
+    # --- second humanoid (T4): the same arm model on another base
+    c.num_humanoids = 1
+    if variant == "T4":
+        c.num_humanoids = 2
+        root2_p = np.asarray(scene["humanoid2_pos"], dtype=np.float64)
+        root2_q = np.asarray(scene["humanoid2_quat"], dtype=np.float64)
+        root2_q = root2_q / np.linalg.norm(root2_q)
+        root2_r = quat_to_rot(root2_q)
+        base2_p = root2_p + root2_r @ np.asarray(PELVIS_TO_TORSO)
+        _set(c.base2_pos, base2_p)
+        _set(c.base2_rot, root2_r.reshape(-1))
+        _set(c.humanoid2_root_pos, root2_p)
+        _set(c.humanoid2_root_quat, root2_q)
+        statics = {3: (base2_p + root2_r @ np.array([0.0, 0.0, 0.05]), base2_p + root2_r @ np.array([0.0, 0.0, 0.30])),
+                   4: (root2_p + root2_r @ np.array([0.0, 0.0, -0.02]),) * 2,
+                   5: (base2_p + root2_r @ np.array([0.0, 0.0, 0.45]),) * 2}
+        for k in range(c.num_shapes):
+            src, dst = c.shape[k], c.shape2[k]
+            dst.link, dst.radius, dst.restitution, dst.friction = src.link, src.radius, src.restitution, src.friction
+            if src.link >= 0:
+                _set(dst.a, list(src.a))
+                _set(dst.b, list(src.b))
+            else:
+                _set(dst.a, statics[k][0])
+                _set(dst.b, statics[k][1])
+        _set(c.humanoid2_bound_center, base2_p + root2_r @ np.asarray(G1_RIGHT_ARM[0]["xyz"]))
     return c
 
 

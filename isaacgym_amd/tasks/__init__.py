@@ -1,8 +1,9 @@
-"""Task registry: the names the reference registers for this path (tasks/__init__.py:49-53,118-120)."""
-from ..vec_task import HumanoidPingpong, HumanoidPingpongTilt, HumanoidPingpongTiltNoEarlyStop
+"""Task registry: the names the reference registers for this path (tasks/__init__.py:49-53,118-122)."""
+from ..vec_task import Humanoid12PingpongTilt, HumanoidPingpong, HumanoidPingpongTilt, HumanoidPingpongTiltNoEarlyStop
 
 isaacgym_task_map = {
     "HumanoidPingpongG1": HumanoidPingpong,
     "HumanoidPingpongTiltG1": HumanoidPingpongTilt,
     "HumanoidPingpongTiltNoEarlyStopG1": HumanoidPingpongTiltNoEarlyStop,
+    "Humanoid12PingpongTiltG1": Humanoid12PingpongTilt,
 }

@@ -61,7 +61,7 @@ class VecTask:
         self.physics_engine = "ppenv"
 
         self.num_envs = int(env_cfg["numEnvs"])
-        self.num_agents = 1
+        self.num_agents = int(getattr(self, "NUM_AGENTS", 1))   # rl_games multi-agent convention: batch rows = num_envs * num_agents
         self.num_observations = self.num_obs = int(env_cfg["numObservations"])
         self.num_states = int(env_cfg.get("numStates", 0))
         self.num_actions = self.num_acts = int(env_cfg["numActions"])
@@ -90,10 +90,11 @@ class VecTask:
         """obs/rew/reset/progress alias the native arena; the rest are plain torch buffers (VecTask.allocate_buffers)."""
         e = self.env
         self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf = e.obs_buf, e.rew_buf, e.reset_buf, e.progress_buf
-        self.states_buf = torch.zeros((self.num_envs, self.num_states), device=self.device, dtype=torch.float)
-        self.timeout_buf = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
+        rows = self.num_envs * self.num_agents
+        self.states_buf = torch.zeros((rows, self.num_states), device=self.device, dtype=torch.float)
+        self.timeout_buf = torch.zeros(rows, device=self.device, dtype=torch.long)
         self.randomize_buf = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
-        self.reset_buf_force = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)   # TT:1037
+        self.reset_buf_force = torch.zeros(rows, device=self.device, dtype=torch.long)   # TT:1037
 
     # -- the surface rl_games drives
     def step(self, actions):
@@ -119,7 +120,7 @@ class VecTask:
         return self._obs_dict(), torch.nonzero(self.reset_buf, as_tuple=False).flatten()
 
     def zero_actions(self):
-        return torch.zeros((self.num_envs, self.num_actions), dtype=torch.float32, device=self.rl_device)
+        return torch.zeros((self.num_envs * self.num_agents, self.num_actions), dtype=torch.float32, device=self.rl_device)
 
     def get_number_of_agents(self):
         return self.num_agents
@@ -159,7 +160,7 @@ class _HumanoidPingpongBase(VecTask):
         self.alpha = env["alphaVelocityReward"]
         self.power_coefficient = env["powerCoefficient"]
         self.penalty = env["penalty"]
-        if self.VARIANT != "T3":
+        if self.VARIANT != "T3":   # TT:106-107, T4:106-107
             self.hit_table_reward = env["hitTableReward"]
             self.not_hit_table_penalty = env["nothitTablePenalty"]
         else:
@@ -168,8 +169,10 @@ class _HumanoidPingpongBase(VecTask):
         self.initial_speed_range = tuple(cfg["scene"]["serve_speed"])
         self.tilt_angle_range = tuple(cfg["scene"]["serve_tilt"])
         self.tilt_z_angle_range = tuple(cfg["scene"]["serve_tilt_z"])
-        self.actors_per_env, self.dofs_per_env, self.rigid_bodies_per_env = scene.NUM_ACTORS, scene.NUM_DOF, scene.NUM_BODIES
+        A = int(getattr(self, "NUM_AGENTS", 1))
+        self.actors_per_env, self.dofs_per_env = A + 2, A * scene.NUM_DOF                    # T4:125-126
         self.num_humanoid_bodies = 40
+        self.rigid_bodies_per_env = A * self.num_humanoid_bodies + 2                          # T4:127
         self._seed = int(cfg.get("seed", 0))
         self._env_id_offset = int(cfg.get("env_id_offset", 0))
         self.dt = cfg["sim"]["dt"]
@@ -191,15 +194,20 @@ class _HumanoidPingpongBase(VecTask):
 
     # gym.refresh_* equivalents (TT:801-807) in the reference's tensor layouts, materialised on demand
     def refresh_sim_tensors(self):
+        A = self.num_agents
         self.root_states = self.env.refresh_root_states()
         self.vec_root_states = self.root_states
         self.humanoid1_root_states = self.root_states[:, 0, :]
-        self.table_root_states = self.root_states[:, 1, :]
-        self.ball2_root_states = self.root_states[:, 2, :]
+        self.table_root_states = self.root_states[:, A, :]         # actor order: humanoid(s), table, ball (TT:179-183 / T4:181-185)
+        self.ball2_root_states = self.root_states[:, A + 1, :]
         self.vec_dof_states = self.env.refresh_dof_states()
         self.dof_pos, self.dof_vel = self.vec_dof_states[..., 0], self.vec_dof_states[..., 1]
         self.body_states = self.vec_rb_states = self.env.refresh_rigid_body_states()
         self.humanoid1_paddle_rb_states = self.body_states[:, 39, :]
+        if A == 2:                                                  # T4:169-172,181-185
+            self.humanoid2_root_states = self.root_states[:, 1, :]
+            self.humanoid1_rb_states, self.humanoid2_rb_states = self.body_states[:, 0:40, :], self.body_states[:, 40:80, :]
+            self.humanoid2_paddle_rb_states = self.body_states[:, 79, :]
         self.dof_force_tensor = self.env.refresh_dof_force()
 
     def step(self, actions):
@@ -243,3 +251,19 @@ class HumanoidPingpongTilt(_HumanoidPingpongBase):
 class HumanoidPingpongTiltNoEarlyStop(_HumanoidPingpongBase):
     """HumanoidPingpongTiltNoEarlyStopG1 — tasks/humanoid_pingpong_3_actor_tilt_no_earlystop.py (TN)."""
     VARIANT = "TN"
+
+
+class Humanoid12PingpongTilt(_HumanoidPingpongBase):
+    """Humanoid12PingpongTiltG1 — tasks/humanoid_pingpong_4_actor_tilt.py:58 (T4): two humanoids, one ball.
+
+    The reference class is unfinished: it declares 14 actions and one 80-wide observation row per env (T4:98-101) but
+    builds 7-wide PD tables (T4:669-674), calls a reward function that does not exist (T4:743) and lets the second
+    humanoid's observations overwrite the first's (T4:786-803, "TODO").  This class is the build's completion of it in the
+    rl_games multi-agent convention: `num_agents = 2`, agent a of env e owns row 2e + a of `obs_buf [2N, 80]`,
+    `rew_buf / reset_buf / progress_buf [2N]` and of the `[2N, 7]` action tensor; both agents share the ball, the
+    progress counter and the reset decision; sticky flags are per side (`flags [2, N]`)."""
+    VARIANT = "T4"
+    NUM_AGENTS = 2
+
+    def _flag(self, bit):   # [2, N]: row a = side a
+        return (self.env.flags & bit) != 0

@@ -29,7 +29,7 @@ def build(force=False):
 
 class OracleBuffers(C.Structure):
     _fields_ = [
-        ("num_envs", C.c_int32),
+        ("num_envs", C.c_int32), ("num_agents", C.c_int32),
         ("obs_buf", C.POINTER(C.c_float)), ("rew_buf", C.POINTER(C.c_float)),
         ("reset_buf", C.POINTER(C.c_int64)), ("progress_buf", C.POINTER(C.c_int64)),
         ("dof_pos", C.POINTER(C.c_float)), ("dof_vel", C.POINTER(C.c_float)),
@@ -98,15 +98,17 @@ class OracleEnv:
         b = OracleBuffers()
         self.L.ppo_buffers_of(self.h, C.byref(b))
         n = self.num_envs = b.num_envs
-        self.obs_buf = _np_view(b.obs_buf, (n, scene.NUM_OBS), np.float32)
-        self.rew_buf = _np_view(b.rew_buf, (n,), np.float32)
-        self.reset_buf = _np_view(b.reset_buf, (n,), np.int64)
-        self.progress_buf = _np_view(b.progress_buf, (n,), np.int64)
-        self.dof_pos = _np_view(b.dof_pos, (scene.NUM_DOF, n), np.float32)
-        self.dof_vel = _np_view(b.dof_vel, (scene.NUM_DOF, n), np.float32)
-        self.dof_force = _np_view(b.dof_force, (scene.NUM_DOF, n), np.float32)
+        A = self.num_agents = b.num_agents            # 2 for the 4-actor variant: agent a of env e owns row A*e + a
+        nd = self.num_dofs = A * scene.NUM_DOF
+        self.obs_buf = _np_view(b.obs_buf, (n * A, scene.NUM_OBS), np.float32)
+        self.rew_buf = _np_view(b.rew_buf, (n * A,), np.float32)
+        self.reset_buf = _np_view(b.reset_buf, (n * A,), np.int64)
+        self.progress_buf = _np_view(b.progress_buf, (n * A,), np.int64)
+        self.dof_pos = _np_view(b.dof_pos, (nd, n), np.float32)
+        self.dof_vel = _np_view(b.dof_vel, (nd, n), np.float32)
+        self.dof_force = _np_view(b.dof_force, (nd, n), np.float32)
         self.ball = _np_view(b.ball, (13, n), np.float32)
-        self.flags = _np_view(b.flags, (n,), np.uint32)
+        self.flags = _np_view(b.flags, (n,) if A == 1 else (A, n), np.uint32)
         self.episode = _np_view(b.episode, (n,), np.uint32)
 
     def close(self):
@@ -125,7 +127,7 @@ class OracleEnv:
 
     def step(self, actions):
         a = _f32(actions)
-        assert a.shape == (self.num_envs, scene.NUM_DOF)
+        assert a.shape == (self.num_envs * self.num_agents, scene.NUM_DOF)
         self.L.ppo_step(self.h, a.ctypes.data)
 
     def reset_all(self):
@@ -147,22 +149,22 @@ class OracleEnv:
                                      dof_force.ctypes.data, pre_ball_vx.ctypes.data)
 
     def refresh_root_states(self):
-        out = np.empty((self.num_envs, scene.NUM_ACTORS, 13), np.float32)
+        out = np.empty((self.num_envs, self.num_agents + 2, 13), np.float32)
         self.L.ppo_refresh_root_states(self.h, out.ctypes.data)
         return out
 
     def refresh_dof_states(self):
-        out = np.empty((self.num_envs, scene.NUM_DOF, 2), np.float32)
+        out = np.empty((self.num_envs, self.num_dofs, 2), np.float32)
         self.L.ppo_refresh_dof_states(self.h, out.ctypes.data)
         return out
 
     def refresh_dof_force(self):
-        out = np.empty((self.num_envs, scene.NUM_DOF), np.float32)
+        out = np.empty((self.num_envs, self.num_dofs), np.float32)
         self.L.ppo_refresh_dof_force(self.h, out.ctypes.data)
         return out
 
     def refresh_rigid_body_states(self):
-        out = np.empty((self.num_envs, scene.NUM_BODIES, 13), np.float32)
+        out = np.empty((self.num_envs, self.num_agents * scene.NUM_HUMANOID_BODIES + 2, 13), np.float32)
         self.L.ppo_refresh_rigid_body_states(self.h, out.ctypes.data)
         return out
 

@@ -15,9 +15,12 @@
  *   - serve velocity       TT:296-323, T3:289-305, TN:301-328
  *   - observations         TT:1640-1708, with calc_heading_quat_inv / my_quat_rotate restated from the
  *                          published isaacgymenvs.utils.torch_jit_utils (un-vendored dependency, unpinned)
+ *   - 4-actor variant      T4 = tasks/humanoid_pingpong_4_actor_tilt.py: rewards T4:1113-1439, reset T4:853-912, serve
+ *                          T4:299-326, poses T4:525-526,555-556; the two-agent wiring the class leaves open (T4:743,786-803)
+ *                          is the build's completion, stated in include/ppenv.h at PPENV_VARIANT_T4
  *
  * PARITY PINNING.  The reward / observation / reset part is pinned against the
- * reference's own torch functions: tests/golden/*.npz hold their outputs on
+ * reference's own torch functions: the npz files under tests/golden hold their outputs on
  * scripted state sequences (tools/gen_golden.py imports the reference in the
  * build container).  The rigid-body part (gym.simulate) is closed-source Isaac
  * Gym / PhysX, absent from the reference and from this pipeline, and no
@@ -45,6 +48,7 @@
 typedef struct ppo_env {
     ppenv_config cfg;
     int n;
+    int A;   /* agents (humanoids) per env: 1, or 2 for PPENV_VARIANT_T4; agent a of env e owns row A*e + a of obs / rew / reset / progress */
     float *obs, *rew;
     int64_t *reset, *progress;
     float *dof_pos, *dof_vel, *dof_force, *ball; /* SoA [k][N] */
@@ -147,7 +151,7 @@ static void serve_velocity(const ppenv_config* c, uint32_t gid, uint32_t episode
     if (c->variant == PPENV_VARIANT_T3) {            /* T3:296-300 */
         double s = -speed;
         out[0] = (float)(s * cos(a)); out[1] = (float)(s * sin(a)); out[2] = 0.0f;
-    } else if (c->variant == PPENV_VARIANT_TT) {     /* TT:307-318 (sic: sin a sin az, then sin a) */
+    } else if (c->variant == PPENV_VARIANT_TT || c->variant == PPENV_VARIANT_T4) {   /* TT:307-318 = T4:310-321 (sic: sin a sin az, then sin a) */
         double s = -speed;
         out[0] = (float)(s * cos(a) * cos(az)); out[1] = (float)(s * sin(a) * sin(az)); out[2] = (float)(s * sin(a));
     } else {                                         /* TN:312-323 */
@@ -165,9 +169,15 @@ typedef struct {
     v3 v[ND];      /* linear velocity of link origin, world */
 } arm_fk;
 
-static void arm_forward_kinematics(const ppenv_config* c, const double* q, const double* qd, arm_fk* k) {
-    m3 Rp = mf(c->base_rot);
-    v3 pp = vf(c->base_pos), wp = V(0, 0, 0), vp = V(0, 0, 0);
+/* the chain base: humanoid 1's torso frame, or humanoid 2's for the 4-actor variant */
+typedef struct { const float* rot; const float* pos; } arm_base;
+static arm_base base_of(const ppenv_config* c, int arm) {
+    arm_base b = {arm == 0 ? c->base_rot : c->base2_rot, arm == 0 ? c->base_pos : c->base2_pos};
+    return b;
+}
+static void arm_forward_kinematics_b(const ppenv_config* c, arm_base base, const double* q, const double* qd, arm_fk* k) {
+    m3 Rp = mf(base.rot);
+    v3 pp = vf(base.pos), wp = V(0, 0, 0), vp = V(0, 0, 0);
     for (int i = 0; i < ND; i++) {
         const ppenv_joint* j = &c->joint[i];
         m3 R0 = mf(j->origin_rot), Rq = axis_rot(j->axis, q[i]);
@@ -183,12 +193,16 @@ static void arm_forward_kinematics(const ppenv_config* c, const double* q, const
     }
 }
 
+static void arm_forward_kinematics(const ppenv_config* c, const double* q, const double* qd, arm_fk* k) {
+    arm_forward_kinematics_b(c, base_of(c, 0), q, qd, k);
+}
+
 /* Recursive Newton-Euler, world coordinates: tau = RNEA(q, qd, qdd) with gravity
  * folded in as a base acceleration of -g when grav != 0. */
-static void arm_rnea(const ppenv_config* c, const arm_fk* k, const double* qd, const double* qdd, double grav,
-                     int use_vel, double* tau) {
+static void arm_rnea_b(const ppenv_config* c, arm_base base, const arm_fk* k, const double* qd, const double* qdd, double grav,
+                       int use_vel, double* tau) {
     v3 alpha[ND], acc[ND], F[ND], N[ND], comw[ND];
-    v3 wp = V(0, 0, 0), alp = V(0, 0, 0), ap = V(0, 0, grav), pp = vf(c->base_pos); /* base accelerates up by |g| */
+    v3 wp = V(0, 0, 0), alp = V(0, 0, 0), ap = V(0, 0, grav), pp = vf(base.pos); /* base accelerates up by |g| */
     for (int i = 0; i < ND; i++) {
         const ppenv_joint* j = &c->joint[i];
         v3 d = vsub(k->p[i], pp);
@@ -216,15 +230,19 @@ static void arm_rnea(const ppenv_config* c, const arm_fk* k, const double* qd, c
     }
 }
 
+static void arm_rnea(const ppenv_config* c, const arm_fk* k, const double* qd, const double* qdd, double grav, int use_vel, double* tau) {
+    arm_rnea_b(c, base_of(c, 0), k, qd, qdd, grav, use_vel, tau);
+}
+
 /* qdd from (M + diag(arm)) qdd = tau - C */
-static void arm_forward_dynamics(const ppenv_config* c, const arm_fk* k, const double* qd, const double* tau,
-                                 const double* arm_eff, double* qdd) {
+static void arm_forward_dynamics_b(const ppenv_config* c, arm_base base, const arm_fk* k, const double* qd, const double* tau,
+                                   const double* arm_eff, double* qdd) {
     double C[ND], zero[ND] = {0}, M[ND][ND + 1], col[ND], unit[ND];
-    arm_rnea(c, k, qd, zero, -(double)c->gravity_z, 1, C);
+    arm_rnea_b(c, base, k, qd, zero, -(double)c->gravity_z, 1, C);
     for (int j = 0; j < ND; j++) {
         memset(unit, 0, sizeof unit);
         unit[j] = 1.0;
-        arm_rnea(c, k, qd, unit, 0.0, 0, col);
+        arm_rnea_b(c, base, k, qd, unit, 0.0, 0, col);
         for (int i = 0; i < ND; i++) M[i][j] = col[i];
     }
     for (int i = 0; i < ND; i++) { M[i][i] += arm_eff[i]; M[i][ND] = tau[i] - C[i]; }
@@ -242,6 +260,10 @@ static void arm_forward_dynamics(const ppenv_config* c, const arm_fk* k, const d
         for (int j = i + 1; j < ND; j++) s -= M[i][j] * qdd[j];
         qdd[i] = s / M[i][i];
     }
+}
+static void arm_forward_dynamics(const ppenv_config* c, const arm_fk* k, const double* qd, const double* tau,
+                                 const double* arm_eff, double* qdd) {
+    arm_forward_dynamics_b(c, base_of(c, 0), k, qd, tau, arm_eff, qdd);
 }
 
 /* world pose / velocity of a frame attached to a chain link (or static) */
@@ -358,20 +380,21 @@ static void link_point_state(const arm_fk* k, int link, const float* local, v3* 
     *p = vadd(k->p[link], off);
     *v = vadd(k->v[link], vcross(k->w[link], off));
 }
-static void arm_geometry(const ppenv_config* c, const arm_fk* k, arm_geom* g) {
+static void arm_geometry_s(const ppenv_config* c, const ppenv_shape* shapes, const arm_fk* k, arm_geom* g) {
     link_point_state(k, c->paddle_link, c->paddle_center, &g->pc, &g->vpc);
     g->pn = mv(&k->R[c->paddle_link], vf(c->paddle_normal));
     g->pnd = vcross(k->w[c->paddle_link], g->pn);
     for (int s = 0; s < c->num_shapes; s++) {
-        link_point_state(k, c->shape[s].link, c->shape[s].a, &g->sa[s], &g->va[s]);
-        link_point_state(k, c->shape[s].link, c->shape[s].b, &g->sb[s], &g->vb[s]);
+        link_point_state(k, shapes[s].link, shapes[s].a, &g->sa[s], &g->va[s]);
+        link_point_state(k, shapes[s].link, shapes[s].b, &g->sb[s], &g->vb[s]);
     }
 }
+static void arm_geometry(const ppenv_config* c, const arm_fk* k, arm_geom* g) { arm_geometry_s(c, c->shape, k, g); }
 
 /* One substep of the ball.  The arm's shapes move linearly from their pose at the START of the substep with
  * the velocities they have there (contacts are generated from start-of-step poses, as PhysX does); within the
  * substep the ball and the arm therefore do not depend on each other. */
-static void ball_substep(const ppenv_config* c, ball_t* b, double quat[4], const arm_geom* g, double h) {
+static void ball_substep_n(const ppenv_config* c, ball_t* b, double quat[4], int narms, const arm_geom* const* garr, double h) {
     int M = c->ball_substeps;
     double hb = h / M;
     for (int m = 0; m < M; m++) {
@@ -384,13 +407,17 @@ static void ball_substep(const ppenv_config* c, ball_t* b, double quat[4], const
                         c->ground_friction, hb);
         contact_box(c, b, &c->table, hb);
         contact_box(c, b, &c->net, hb);
-        if (vnorm(vsub(b->p, vf(c->humanoid_bound_center))) < c->humanoid_bound_radius) {
+        for (int arm = 0; arm < narms; arm++) {   /* humanoid 1's shapes, then humanoid 2's (4-actor variant) */
+            const arm_geom* g = garr[arm];
+            const float* bound = arm == 0 ? c->humanoid_bound_center : c->humanoid2_bound_center;
+            const ppenv_shape* shapes = arm == 0 ? c->shape : c->shape2;
+            if (!(vnorm(vsub(b->p, vf(bound))) < c->humanoid_bound_radius)) continue;
             v3 cc = vadd(g->pc, vscale(g->vpc, t));
             v3 nn = vadd(g->pn, vscale(g->pnd, t));
             nn = vscale(nn, 1.0 / vnorm(nn));
             contact_disc(c, b, cc, nn, g->vpc, g->pnd, hb);
             for (int s = 0; s < c->num_shapes; s++) {
-                const ppenv_shape* sh = &c->shape[s];
+                const ppenv_shape* sh = &shapes[s];
                 v3 a = vadd(g->sa[s], vscale(g->va[s], t)), bb = vadd(g->sb[s], vscale(g->vb[s], t));
                 contact_capsule(c, b, a, bb, g->va[s], g->vb[s], sh->radius, sh->restitution, sh->friction, hb);
             }
@@ -406,6 +433,10 @@ static void ball_substep(const ppenv_config* c, ball_t* b, double quat[4], const
     x += dx; y += dy; z += dz; w += dw;
     double nrm = sqrt(x * x + y * y + z * z + w * w);
     quat[0] = x / nrm; quat[1] = y / nrm; quat[2] = z / nrm; quat[3] = w / nrm;
+}
+
+static void ball_substep(const ppenv_config* c, ball_t* b, double quat[4], const arm_geom* g, double h) {
+    ball_substep_n(c, b, quat, 1, &g, h);
 }
 
 /* ------------------------------------------------------ fp32 reward / obs / reset */
@@ -453,21 +484,20 @@ static void compute_obs(const bodies_t bs, const float* dof_pos, const float* do
     quat_rotate_f(hinv, &ball[7], &obs[6 * NB + 2 * ND + 3]);
 }
 
-static float power_term(const float* dof_force, const float* dof_vel) {
+static float power_term(const float* dof_force, const float* dof_vel, int ndof) {
     float p = 0.0f;
-    for (int d = 0; d < ND; d++) p += fabsf(dof_force[d] * dof_vel[d]);
+    for (int d = 0; d < ndof; d++) p += fabsf(dof_force[d] * dof_vel[d]);
     return p;
 }
 
 /* Reward + reset decision for one env.  Inputs are the post-step, pre-reset
  * state; flags are read-modify-write (sticky).  Returns reward, *reset_out 0/1. */
 static float compute_reward(const ppenv_config* c, float humanoid_x, const float* paddle_pos, float pre_vx,
-                            const float* ball, const float* dof_force, const float* dof_vel, int64_t progress,
-                            uint32_t* flags, int64_t* reset_out) {
+                            const float* ball, float power, int64_t progress, uint32_t* flags, int64_t* reset_out) {
     const float Bx = ball[0], By = ball[1], Bz = ball[2], vx = ball[7];
     const float alpha = c->alpha_velocity_reward, penalty = c->penalty;
     const float threshold = 0.1f;
-    float power_reward = -c->power_coefficient * power_term(dof_force, dof_vel);
+    float power_reward = -c->power_coefficient * power;   /* power = sum_j |dof_force_j * dof_vel_j| (TT:1246) */
     uint32_t f = *flags;
     float reward;
     int64_t die = 0;
@@ -481,7 +511,7 @@ static float compute_reward(const ppenv_config* c, float humanoid_x, const float
         if (missed) reward = reward + penalty;
         if (missed) die = 1;                                                               /* T3:1158 */
         if (Bz < threshold) die = 1;                                                       /* T3:1161 */
-    } else if (c->variant == PPENV_VARIANT_TT) {            /* TT:1105-1270 */
+    } else if (c->variant == PPENV_VARIANT_TT || c->variant == PPENV_VARIANT_T4) {   /* TT:1105-1270 == T4:1113-1278 */
         float dx = paddle_pos[0] - Bx, dy = paddle_pos[1] - By, dz = paddle_pos[2] - Bz;
         float dist = sqrtf(dx * dx + dy * dy + dz * dz);                                   /* TT:1144-1146 */
         float pos_reward = 1.0f / (1.0f + 1.5f * dist * dist);                             /* TT:1147 */
@@ -538,16 +568,18 @@ ppo_env* ppo_create(const ppenv_config* cfg) {
     ppo_env* e = (ppo_env*)calloc(1, sizeof *e);
     e->cfg = *cfg;
     int n = e->n = cfg->num_envs;
+    int A = e->A = cfg->variant == PPENV_VARIANT_T4 ? 2 : 1;
+    if (cfg->num_humanoids != A) { free(e); return NULL; }
     e->threads = 1;
-    e->obs = (float*)calloc((size_t)n * PPENV_NUM_OBS, sizeof(float));
-    e->rew = (float*)calloc(n, sizeof(float));
-    e->reset = (int64_t*)calloc(n, sizeof(int64_t));
-    e->progress = (int64_t*)calloc(n, sizeof(int64_t));
-    e->dof_pos = (float*)calloc((size_t)n * ND, sizeof(float));
-    e->dof_vel = (float*)calloc((size_t)n * ND, sizeof(float));
-    e->dof_force = (float*)calloc((size_t)n * ND, sizeof(float));
+    e->obs = (float*)calloc((size_t)n * A * PPENV_NUM_OBS, sizeof(float));
+    e->rew = (float*)calloc((size_t)n * A, sizeof(float));
+    e->reset = (int64_t*)calloc((size_t)n * A, sizeof(int64_t));
+    e->progress = (int64_t*)calloc((size_t)n * A, sizeof(int64_t));
+    e->dof_pos = (float*)calloc((size_t)n * A * ND, sizeof(float));
+    e->dof_vel = (float*)calloc((size_t)n * A * ND, sizeof(float));
+    e->dof_force = (float*)calloc((size_t)n * A * ND, sizeof(float));
     e->ball = (float*)calloc((size_t)n * 13, sizeof(float));
-    e->flags = (uint32_t*)calloc(n, sizeof(uint32_t));
+    e->flags = (uint32_t*)calloc((size_t)n * A, sizeof(uint32_t));
     e->episode = (uint32_t*)calloc(n, sizeof(uint32_t));
     e->serve = (float*)calloc((size_t)n * 3, sizeof(float));
     return e;
@@ -560,13 +592,13 @@ void ppo_destroy(ppo_env* e) {
 void ppo_set_threads(ppo_env* e, int t) { e->threads = t > 0 ? t : 1; }
 
 typedef struct ppo_buffers {
-    int32_t num_envs;
+    int32_t num_envs, num_agents;
     float* obs_buf; float* rew_buf; int64_t* reset_buf; int64_t* progress_buf;
     float* dof_pos; float* dof_vel; float* dof_force; float* ball;
     uint32_t* flags; uint32_t* episode; float* serve_override;
 } ppo_buffers;
 void ppo_buffers_of(ppo_env* e, ppo_buffers* b) {
-    b->num_envs = e->n; b->obs_buf = e->obs; b->rew_buf = e->rew; b->reset_buf = e->reset;
+    b->num_envs = e->n; b->num_agents = e->A; b->obs_buf = e->obs; b->rew_buf = e->rew; b->reset_buf = e->reset;
     b->progress_buf = e->progress; b->dof_pos = e->dof_pos; b->dof_vel = e->dof_vel; b->dof_force = e->dof_force;
     b->ball = e->ball; b->flags = e->flags; b->episode = e->episode; b->serve_override = e->serve;
 }
@@ -587,22 +619,31 @@ static void reset_env_state(ppo_env* e, int i, int reset_dofs) {
     for (int k = 0; k < 3; k++) e->ball[(size_t)(7 + k) * n + i] = v[k];
     for (int k = 0; k < 3; k++) e->ball[(size_t)(10 + k) * n + i] = 0.0f;
     if (reset_dofs)
-        for (int d = 0; d < ND; d++) {
-            e->dof_pos[(size_t)d * n + i] = c->init_dof_pos[d];
-            e->dof_vel[(size_t)d * n + i] = c->init_dof_vel[d];
+        for (int d = 0; d < e->A * ND; d++) {   /* T4:873: the dof states of both humanoids */
+            e->dof_pos[(size_t)d * n + i] = c->init_dof_pos[d % ND];
+            e->dof_vel[(size_t)d * n + i] = c->init_dof_vel[d % ND];
         }
 }
 
-static void gather_env(const ppo_env* e, int i, float* q, float* qd, float* ball) {
+static void gather_env(const ppo_env* e, int i, float* q, float* qd, float* ball) {   /* q, qd: [A * ND] */
     int n = e->n;
-    for (int d = 0; d < ND; d++) { q[d] = e->dof_pos[(size_t)d * n + i]; qd[d] = e->dof_vel[(size_t)d * n + i]; }
+    for (int d = 0; d < e->A * ND; d++) { q[d] = e->dof_pos[(size_t)d * n + i]; qd[d] = e->dof_vel[(size_t)d * n + i]; }
     for (int k = 0; k < 13; k++) ball[k] = e->ball[(size_t)k * n + i];
 }
 
-static void bodies_from_fk(const ppenv_config* c, const arm_fk* k, bodies_t bs) {
+/* xyzw unit quaternion -> rotation matrix */
+static m3 quat_to_rot_f(const float* q) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    m3 r = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+             2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+    return r;
+}
+/* observed bodies of humanoid `arm` (0: humanoid 1; 1: humanoid 2 of the 4-actor variant, whose pelvis is static at its own root pose) */
+static void bodies_from_fk_arm(const ppenv_config* c, int arm, const arm_fk* k, bodies_t bs) {
     for (int j = 0; j < NB; j++) {
         v3 pos, lin, ang; m3 rot; double qt[4];
         frame_state(c, k, &c->obs_body[j], &pos, &rot, &lin, &ang);
+        if (arm == 1 && c->obs_body[j].link < 0) { pos = vf(c->humanoid2_root_pos); rot = quat_to_rot_f(c->humanoid2_root_quat); }
         rot_to_quat(&rot, qt);
         bs[j][0] = (float)pos.x; bs[j][1] = (float)pos.y; bs[j][2] = (float)pos.z;
         for (int t = 0; t < 4; t++) bs[j][3 + t] = (float)qt[t];
@@ -610,28 +651,33 @@ static void bodies_from_fk(const ppenv_config* c, const arm_fk* k, bodies_t bs) 
         bs[j][10] = (float)ang.x; bs[j][11] = (float)ang.y; bs[j][12] = (float)ang.z;
     }
 }
+static void bodies_from_fk(const ppenv_config* c, const arm_fk* k, bodies_t bs) { bodies_from_fk_arm(c, 0, k, bs); }
 
-/* observations of env i from the current SoA state (used by create / reset_all) */
+/* observations of env i from the current SoA state (used by create / reset_all): one row per agent */
 static void obs_from_state(ppo_env* e, int i) {
     const ppenv_config* c = &e->cfg;
-    float qf[ND], qdf[ND], ball[13];
-    double q[ND], qd[ND];
+    float qf[2 * ND], qdf[2 * ND], ball[13];
     gather_env(e, i, qf, qdf, ball);
-    for (int d = 0; d < ND; d++) { q[d] = qf[d]; qd[d] = qdf[d]; }
-    arm_fk k;
-    arm_forward_kinematics(c, q, qd, &k);
-    bodies_t bs;
-    bodies_from_fk(c, &k, bs);
-    compute_obs(bs, qf, qdf, ball, &e->obs[(size_t)i * PPENV_NUM_OBS]);
+    for (int a = 0; a < e->A; a++) {
+        double q[ND], qd[ND];
+        for (int d = 0; d < ND; d++) { q[d] = qf[a * ND + d]; qd[d] = qdf[a * ND + d]; }
+        arm_fk k;
+        arm_forward_kinematics_b(c, base_of(c, a), q, qd, &k);
+        bodies_t bs;
+        bodies_from_fk_arm(c, a, &k, bs);
+        compute_obs(bs, &qf[a * ND], &qdf[a * ND], ball, &e->obs[((size_t)i * e->A + a) * PPENV_NUM_OBS]);
+    }
 }
 
 static void init_env(ppo_env* e, int i) {
     reset_env_state(e, i, 1);
-    for (int d = 0; d < ND; d++) e->dof_force[(size_t)d * e->n + i] = 0.0f;
-    e->flags[i] = initial_flags(&e->cfg);
-    e->progress[i] = 0;
-    e->reset[i] = 1;  /* upstream VecTask.allocate_buffers: reset_buf = ones; overwritten by the first step (TT:740) */
-    e->rew[i] = 0.0f;
+    for (int d = 0; d < e->A * ND; d++) e->dof_force[(size_t)d * e->n + i] = 0.0f;
+    for (int a = 0; a < e->A; a++) {
+        e->flags[(size_t)a * e->n + i] = initial_flags(&e->cfg);
+        e->progress[(size_t)i * e->A + a] = 0;
+        e->reset[(size_t)i * e->A + a] = 1;  /* upstream VecTask.allocate_buffers: reset_buf = ones; overwritten by the first step (TT:740) */
+        e->rew[(size_t)i * e->A + a] = 0.0f;
+    }
     obs_from_state(e, i);
 }
 /* state as after _create_envs (TT:512-643): creation is episode 0 of every env */
@@ -719,7 +765,7 @@ static void step_env(ppo_env* e, int i, const float* actions) {
     int64_t progress = e->progress[i] + 1;                          /* TT:1023 */
     uint32_t flags = e->flags[i];
     int64_t reset;
-    float rew = compute_reward(c, c->humanoid_root_pos[0], bs[c->paddle_obs_index], pre_vx, ballf, dof_force, qdf,
+    float rew = compute_reward(c, c->humanoid_root_pos[0], bs[c->paddle_obs_index], pre_vx, ballf, power_term(dof_force, qdf, ND),
                                progress, &flags, &reset);
     for (int d = 0; d < ND; d++) {
         e->dof_pos[(size_t)d * n + i] = qf[d]; e->dof_vel[(size_t)d * n + i] = qdf[d];
@@ -738,12 +784,17 @@ static void step_env(ppo_env* e, int i, const float* actions) {
     compute_obs(bs, qf, qdf, ballf, &e->obs[(size_t)i * PPENV_NUM_OBS]);
 }
 
+static void step_env_t4(ppo_env* e, int i, const float* actions);
+
 void ppo_step(ppo_env* e, const float* actions) {
     int n = e->n;
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(e->threads) schedule(static)
 #endif
-    for (int i = 0; i < n; i++) step_env(e, i, actions);
+    for (int i = 0; i < n; i++) {
+        if (e->A == 2) step_env_t4(e, i, actions);
+        else step_env(e, i, actions);
+    }
 }
 
 /* ---------------------------------------------- Isaac-Gym tensor-API mode (TT:1022-1039) */
@@ -764,7 +815,7 @@ void ppo_post_physics_step(ppo_env* e, const float* rb_states /* [N,42,13] */, f
         int64_t progress = e->progress[i] + 1;
         uint32_t flags = e->flags[i];
         int64_t reset;
-        float rew = compute_reward(c, root[0], &rb[39 * 13], pre_ball_vx[i], ball, &dof_force[(size_t)i * ND], qdf,
+        float rew = compute_reward(c, root[0], &rb[39 * 13], pre_ball_vx[i], ball, power_term(&dof_force[(size_t)i * ND], qdf, ND),
                                    progress, &flags, &reset);
         if (reset) {
             e->episode[i] += 1;
@@ -788,68 +839,84 @@ void ppo_post_physics_step(ppo_env* e, const float* rb_states /* [N,42,13] */, f
     }
 }
 
-/* ------------------------------------------------------------ refresh (gym.refresh_*) */
-void ppo_refresh_root_states(ppo_env* e, float* out /* [N,3,13] */) {
+/* ------------------------------------------------------------ refresh (gym.refresh_*)
+ * 3-actor layouts [N,3,13] / [N,7,2] / [N,7] / [N,42,13]; 4-actor [N,4,13] (humanoid1, humanoid2, table, ball: T4:181-185) /
+ * [N,14,2] / [N,14] / [N,82,13] (humanoid1 0-39, humanoid2 40-79, table 80, ball 81: T4:169-172). */
+void ppo_refresh_root_states(ppo_env* e, float* out) {
     const ppenv_config* c = &e->cfg;
+    const int A = e->A, rows = A + 2;
     for (int i = 0; i < e->n; i++) {
-        float* r = &out[(size_t)i * 39];
-        memset(r, 0, 39 * sizeof(float));
+        float* r = &out[(size_t)i * rows * 13];
+        memset(r, 0, rows * 13 * sizeof(float));
         memcpy(r, c->humanoid_root_pos, 12); memcpy(r + 3, c->humanoid_root_quat, 16);
-        memcpy(r + 13, c->table_root_pos, 12); memcpy(r + 16, c->table_root_quat, 16);
-        for (int k = 0; k < 13; k++) r[26 + k] = e->ball[(size_t)k * e->n + i];
+        if (A == 2) { memcpy(r + 13, c->humanoid2_root_pos, 12); memcpy(r + 16, c->humanoid2_root_quat, 16); }
+        memcpy(r + A * 13, c->table_root_pos, 12); memcpy(r + A * 13 + 3, c->table_root_quat, 16);
+        for (int k = 0; k < 13; k++) r[(A + 1) * 13 + k] = e->ball[(size_t)k * e->n + i];
     }
 }
-void ppo_refresh_dof_states(ppo_env* e, float* out /* [N,7,2] */) {
+void ppo_refresh_dof_states(ppo_env* e, float* out) {
+    const int D = e->A * ND;
     for (int i = 0; i < e->n; i++)
-        for (int d = 0; d < ND; d++) {
-            out[((size_t)i * ND + d) * 2] = e->dof_pos[(size_t)d * e->n + i];
-            out[((size_t)i * ND + d) * 2 + 1] = e->dof_vel[(size_t)d * e->n + i];
+        for (int d = 0; d < D; d++) {
+            out[((size_t)i * D + d) * 2] = e->dof_pos[(size_t)d * e->n + i];
+            out[((size_t)i * D + d) * 2 + 1] = e->dof_vel[(size_t)d * e->n + i];
         }
 }
-void ppo_refresh_dof_force(ppo_env* e, float* out /* [N,7] */) {
+void ppo_refresh_dof_force(ppo_env* e, float* out) {
+    const int D = e->A * ND;
     for (int i = 0; i < e->n; i++)
-        for (int d = 0; d < ND; d++) out[(size_t)i * ND + d] = e->dof_force[(size_t)d * e->n + i];
+        for (int d = 0; d < D; d++) out[(size_t)i * D + d] = e->dof_force[(size_t)d * e->n + i];
 }
-void ppo_refresh_rigid_body_states(ppo_env* e, float* out /* [N,42,13] */) {
+void ppo_refresh_rigid_body_states(ppo_env* e, float* out) {
     const ppenv_config* c = &e->cfg;
     static const int body_ids[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};
+    const int A = e->A, HB = PPENV_NUM_HUMANOID_BODIES;
     for (int i = 0; i < e->n; i++) {
-        float qf[ND], qdf[ND], ball[13];
-        double q[ND], qd[ND];
+        float qf[2 * ND], qdf[2 * ND], ball[13];
         gather_env(e, i, qf, qdf, ball);
-        for (int d = 0; d < ND; d++) { q[d] = qf[d]; qd[d] = qdf[d]; }
-        arm_fk k;
-        arm_forward_kinematics(c, q, qd, &k);
-        bodies_t bs;
-        bodies_from_fk(c, &k, bs);
-        float* rb = &out[(size_t)i * PPENV_NUM_BODIES * 13];
-        for (int b = 0; b < PPENV_NUM_HUMANOID_BODIES; b++) {
-            memset(&rb[b * 13], 0, 13 * sizeof(float));
-            memcpy(&rb[b * 13], c->humanoid_root_pos, 12); memcpy(&rb[b * 13 + 3], c->humanoid_root_quat, 16);
+        float* rb = &out[(size_t)i * (A * HB + 2) * 13];
+        for (int a = 0; a < A; a++) {
+            double q[ND], qd[ND];
+            for (int d = 0; d < ND; d++) { q[d] = qf[a * ND + d]; qd[d] = qdf[a * ND + d]; }
+            arm_fk k;
+            arm_forward_kinematics_b(c, base_of(c, a), q, qd, &k);
+            bodies_t bs;
+            bodies_from_fk_arm(c, a, &k, bs);
+            float* rba = &rb[a * HB * 13];
+            const float* rp = a == 0 ? c->humanoid_root_pos : c->humanoid2_root_pos;
+            const float* rq = a == 0 ? c->humanoid_root_quat : c->humanoid2_root_quat;
+            for (int b = 0; b < HB; b++) {
+                memset(&rba[b * 13], 0, 13 * sizeof(float));
+                memcpy(&rba[b * 13], rp, 12); memcpy(&rba[b * 13 + 3], rq, 16);
+            }
+            for (int j = 0; j < NB; j++) memcpy(&rba[body_ids[j] * 13], bs[j], 13 * sizeof(float));
         }
-        for (int j = 0; j < NB; j++) memcpy(&rb[body_ids[j] * 13], bs[j], 13 * sizeof(float));
-        memset(&rb[40 * 13], 0, 13 * sizeof(float));
-        memcpy(&rb[40 * 13], c->table_root_pos, 12); memcpy(&rb[40 * 13 + 3], c->table_root_quat, 16);
-        memcpy(&rb[41 * 13], ball, 13 * sizeof(float));
+        float* t = &rb[A * HB * 13];
+        memset(t, 0, 13 * sizeof(float));
+        memcpy(t, c->table_root_pos, 12); memcpy(t + 3, c->table_root_quat, 16);
+        memcpy(t + 13, ball, 13 * sizeof(float));
     }
 }
 
 /* ---------------------------------------------------------------- state blob I/O */
-size_t ppo_state_bytes(ppo_env* e) { return (size_t)e->n * ((ND * 3 + 13) * 4 + 4 + 4 + 8 + 8); }
+size_t ppo_state_bytes(ppo_env* e) {
+    size_t A = (size_t)e->A;
+    return (size_t)e->n * ((A * ND * 3 + 13) * 4 + A * 4 + 4 + A * 8 + A * 8);
+}
 static unsigned char* blob_copy(unsigned char* p, void* arr, size_t bytes, int to_blob) {
     if (to_blob) memcpy(p, arr, bytes); else memcpy(arr, p, bytes);
     return p + bytes;
 }
 static void blob_io(ppo_env* e, unsigned char* p, int to_blob) {
-    size_t n = e->n;
-    p = blob_copy(p, e->dof_pos, n * ND * 4, to_blob);
-    p = blob_copy(p, e->dof_vel, n * ND * 4, to_blob);
-    p = blob_copy(p, e->dof_force, n * ND * 4, to_blob);
+    size_t n = e->n, A = (size_t)e->A;
+    p = blob_copy(p, e->dof_pos, n * A * ND * 4, to_blob);
+    p = blob_copy(p, e->dof_vel, n * A * ND * 4, to_blob);
+    p = blob_copy(p, e->dof_force, n * A * ND * 4, to_blob);
     p = blob_copy(p, e->ball, n * 13 * 4, to_blob);
-    p = blob_copy(p, e->flags, n * 4, to_blob);
+    p = blob_copy(p, e->flags, n * A * 4, to_blob);
     p = blob_copy(p, e->episode, n * 4, to_blob);
-    p = blob_copy(p, e->progress, n * 8, to_blob);
-    p = blob_copy(p, e->reset, n * 8, to_blob);
+    p = blob_copy(p, e->progress, n * A * 8, to_blob);
+    p = blob_copy(p, e->reset, n * A * 8, to_blob);
 }
 int ppo_get_state(ppo_env* e, void* dst, size_t nbytes) {
     if (nbytes != ppo_state_bytes(e)) return PPENV_ESTATE;
@@ -1128,10 +1195,114 @@ void ppo_t4_rewards(const ppenv_t4_params* p, const float* rb_states, const floa
         float power = 0.f;
         for (int d = 0; d < PPENV_T4_NUM_DOF; d++)       /* the class hands the whole 14-dof tensors to the reward (T4:746-747) */
             power += fabsf(dof_force[(size_t)i * PPENV_T4_NUM_DOF + d] * dof_states[((size_t)i * PPENV_T4_NUM_DOF + d) * 2 + 1]);
-        /* side 1 through compute_reward(): its power term is -c * sum|tau qd| over 7 dofs, so feed the 14-dof sum in one slot */
-        float tau7[ND] = {power, 0, 0, 0, 0, 0, 0}, qd7[ND] = {1.0f, 0, 0, 0, 0, 0, 0};
         flags1[i] = flags1_in[i]; flags2[i] = flags2_in[i];
-        rew1[i] = compute_reward(&c, root[0], &rb[39 * 13], pre_ball_vx[i], ball, tau7, qd7, progress[i], &flags1[i], &reset1[i]);
+        rew1[i] = compute_reward(&c, root[0], &rb[39 * 13], pre_ball_vx[i], ball, power, progress[i], &flags1[i], &reset1[i]);
         rew2[i] = t4_reward_side2(p, root[13], &rb[79 * 13], pre_ball_vx[i], ball, power, progress[i], &flags2[i], &reset2[i]);
     }
+}
+
+/* ------------------------------------------------ the fused step of the 4-actor variant (PPENV_VARIANT_T4)
+ * Two humanoids (the same arm model on two bases), one ball.  Reference pieces: pre_physics_step T4:1008-1026, the two
+ * reward functions T4:1113-1439, _reset_idx T4:853-912 (both humanoids' dof states, all four actors' root states),
+ * observations per humanoid T4:770-803.  The class itself is unfinished (T4:743 calls a missing name, T4:786 "TODO");
+ * the wiring — agent a of env e owns row 2e + a, each agent observes its own seven dofs, one shared reset — is the
+ * build's completion (include/ppenv.h, PPENV_VARIANT_T4).  Like the class's call site (T4:746-747), both reward
+ * functions receive the whole 14-dof force / velocity tensors. */
+static void step_env_t4(ppo_env* e, int i, const float* actions) {
+    const ppenv_config* c = &e->cfg;
+    const int n = e->n;
+    float qf[2 * ND], qdf[2 * ND], ballf[13];
+    gather_env(e, i, qf, qdf, ballf);
+
+    double target[2][ND], q[2][ND], qd[2][ND], tau_drive[2][ND] = {{0}};
+    for (int a = 0; a < 2; a++)
+        for (int d = 0; d < ND; d++) {
+            float act = actions[((size_t)i * 2 + a) * ND + d];
+            act = fminf(fmaxf(act, -c->clip_actions), c->clip_actions);
+            float lo = c->joint[d].lower, hi = c->joint[d].upper;
+            float off = 0.5f * (hi + lo), scale = 0.5f * (hi - lo);
+            target[a][d] = off + scale * act;                      /* T4:1014 */
+            q[a][d] = qf[a * ND + d]; qd[a][d] = qdf[a * ND + d];
+        }
+    float pre_vx = ballf[7];                                        /* T4:1026 */
+
+    ball_t b = {vf(&ballf[0]), vf(&ballf[7]), vf(&ballf[10])};
+    double bq[4] = {ballf[3], ballf[4], ballf[5], ballf[6]};
+    double h = (double)c->dt / c->substeps;
+    arm_fk k0[2];
+    for (int a = 0; a < 2; a++) arm_forward_kinematics_b(c, base_of(c, a), q[a], qd[a], &k0[a]);
+    for (int s = 0; s < c->substeps; s++) {
+        arm_geom g[2];
+        for (int a = 0; a < 2; a++) {
+            double tau[ND], arm_eff[ND], qdd[ND];
+            int sat[ND];
+            arm_geometry_s(c, a == 0 ? c->shape : c->shape2, &k0[a], &g[a]);   /* pose and velocities at the start of the substep */
+            for (int d = 0; d < ND; d++) {
+                const ppenv_joint* j = &c->joint[d];
+                double err = target[a][d] - q[a][d];
+                double t_exp = j->kp * err - j->kd * qd[a][d];
+                sat[d] = fabs(t_exp) > j->effort;
+                if (sat[d]) { tau[d] = t_exp > 0 ? j->effort : -j->effort; arm_eff[d] = j->armature; }
+                else { tau[d] = j->kp * (err - h * qd[a][d]) - j->kd * qd[a][d]; arm_eff[d] = j->armature + h * j->kd + h * h * j->kp; }
+            }
+            arm_forward_dynamics_b(c, base_of(c, a), &k0[a], qd[a], tau, arm_eff, qdd);
+            for (int d = 0; d < ND; d++) {
+                const ppenv_joint* j = &c->joint[d];
+                double err = target[a][d] - q[a][d];
+                double v_new = qd[a][d] + h * qdd[d];
+                tau_drive[a][d] = sat[d] ? tau[d] : j->kp * (err - h * v_new) - j->kd * v_new;
+                v_new = clampd(v_new, -j->vel_limit, j->vel_limit);
+                double q_new = q[a][d] + h * v_new;
+                if (q_new > j->upper) { q_new = j->upper; if (v_new > 0) v_new = 0; }
+                if (q_new < j->lower) { q_new = j->lower; if (v_new < 0) v_new = 0; }
+                q[a][d] = q_new; qd[a][d] = v_new;
+            }
+        }
+        const arm_geom* garr[2] = {&g[0], &g[1]};
+        ball_substep_n(c, &b, bq, 2, garr, h);
+        for (int a = 0; a < 2; a++) arm_forward_kinematics_b(c, base_of(c, a), q[a], qd[a], &k0[a]);
+    }
+
+    /* refresh_sim_tensors: round the state to the fp32 tensors */
+    float dof_force[2 * ND];
+    for (int a = 0; a < 2; a++)
+        for (int d = 0; d < ND; d++) {
+            qf[a * ND + d] = (float)q[a][d]; qdf[a * ND + d] = (float)qd[a][d]; dof_force[a * ND + d] = (float)tau_drive[a][d];
+        }
+    ballf[0] = (float)b.p.x; ballf[1] = (float)b.p.y; ballf[2] = (float)b.p.z;
+    for (int t = 0; t < 4; t++) ballf[3 + t] = (float)bq[t];
+    ballf[7] = (float)b.v.x; ballf[8] = (float)b.v.y; ballf[9] = (float)b.v.z;
+    ballf[10] = (float)b.w.x; ballf[11] = (float)b.w.y; ballf[12] = (float)b.w.z;
+    bodies_t bs[2];
+    for (int a = 0; a < 2; a++) bodies_from_fk_arm(c, a, &k0[a], bs[a]);
+
+    /* post_physics_step: T4:1028-1046 */
+    int64_t progress = e->progress[(size_t)i * 2] + 1;
+    uint32_t flags[2] = {e->flags[i], e->flags[(size_t)n + i]};
+    int64_t reset1, reset2;
+    float power = power_term(dof_force, qdf, 2 * ND);               /* T4:746-747: the whole dof tensors */
+    ppenv_t4_params p;
+    memset(&p, 0, sizeof p);
+    p.max_episode_length = c->max_episode_length;
+    p.alpha_velocity_reward = c->alpha_velocity_reward; p.power_coefficient = c->power_coefficient; p.penalty = c->penalty;
+    p.hit_table_reward = c->hit_table_reward; p.not_hit_table_penalty = c->not_hit_table_penalty;
+    float rew1 = compute_reward(c, c->humanoid_root_pos[0], bs[0][c->paddle_obs_index], pre_vx, ballf, power, progress, &flags[0], &reset1);
+    float rew2 = t4_reward_side2(&p, c->humanoid2_root_pos[0], bs[1][c->paddle_obs_index], pre_vx, ballf, power, progress, &flags[1], &reset2);
+    int64_t reset = (reset1 | reset2) ? 1 : 0;                      /* same rule on both sides (T4:1270-1276, 1431-1437) */
+    for (int d = 0; d < 2 * ND; d++) {
+        e->dof_pos[(size_t)d * n + i] = qf[d]; e->dof_vel[(size_t)d * n + i] = qdf[d]; e->dof_force[(size_t)d * n + i] = dof_force[d];
+    }
+    for (int t = 0; t < 13; t++) e->ball[(size_t)t * n + i] = ballf[t];
+    if (reset) {                                                    /* T4:853-912 */
+        e->episode[i] += 1;
+        reset_env_state(e, i, 1);
+        progress = 0;
+        flags[0] = flags[1] = initial_flags(c);
+        gather_env(e, i, qf, qdf, ballf);
+    }
+    for (int a = 0; a < 2; a++) {
+        e->progress[(size_t)i * 2 + a] = progress; e->flags[(size_t)a * n + i] = flags[a]; e->reset[(size_t)i * 2 + a] = reset;
+        compute_obs(bs[a], &qf[a * ND], &qdf[a * ND], ballf, &e->obs[((size_t)i * 2 + a) * PPENV_NUM_OBS]);
+    }
+    e->rew[(size_t)i * 2] = rew1; e->rew[(size_t)i * 2 + 1] = rew2;
 }

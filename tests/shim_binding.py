@@ -37,18 +37,20 @@ class ShimEnv:
         self.config = config
         assert self.L.shim_model_matches(C.byref(config)) == 1
         n = self.num_envs = config.num_envs
-        self.obs_buf = np.zeros((n, scene.NUM_OBS), np.float32)
-        self.rew_buf = np.zeros(n, np.float32)
-        self.reset_buf = np.zeros(n, np.int64)
-        self.progress_buf = np.zeros(n, np.int64)
-        self.dof_pos = np.zeros((scene.NUM_DOF, n), np.float32)
-        self.dof_vel = np.zeros((scene.NUM_DOF, n), np.float32)
-        self.dof_force = np.zeros((scene.NUM_DOF, n), np.float32)
+        A = self.num_agents = config.num_humanoids
+        nd = A * scene.NUM_DOF
+        self.obs_buf = np.zeros((n * A, scene.NUM_OBS), np.float32)
+        self.rew_buf = np.zeros(n * A, np.float32)
+        self.reset_buf = np.zeros(n * A, np.int64)
+        self.progress_buf = np.zeros(n * A, np.int64)
+        self.dof_pos = np.zeros((nd, n), np.float32)
+        self.dof_vel = np.zeros((nd, n), np.float32)
+        self.dof_force = np.zeros((nd, n), np.float32)
         self.ball = np.zeros((13, n), np.float32)
-        self.flags = np.zeros(n, np.uint32)
+        self.flags = np.zeros(n if A == 1 else (A, n), np.uint32)
         self.episode = np.zeros(n, np.uint32)
         self.serve = None
-        self.bodies = np.zeros((n, scene.NUM_OBS_BODIES, 13), np.float32)
+        self.bodies = np.zeros((n, A * scene.NUM_OBS_BODIES, 13), np.float32)
 
     def copy_state_from(self, other):
         for name in ("dof_pos", "dof_vel", "dof_force", "ball", "flags", "episode", "progress_buf", "reset_buf"):
