@@ -49,6 +49,23 @@ struct DevBuffers {
     float* serve;
 };
 
+// State stores of the step kernels.  PP_STORE_MODE (profiling builds) selects how they leave the CU:
+// 0 plain, 1 non-temporal (default), 2 system-scope (write-through).  Measured at N = 16384 / 65536 (tools/gpu_storemode.sh):
+// 13.03 / 19.50 us, 12.92 / 19.18 us, 13.13 / 20.28 us — nothing in the launch reads the state again, so it may stream out.
+#ifndef PP_STORE_MODE
+#define PP_STORE_MODE 1
+#endif
+template <class V>
+__device__ __forceinline__ void st_state(V* p, V v) {
+#if PP_STORE_MODE == 1
+    __builtin_nontemporal_store(v, p);
+#elif PP_STORE_MODE == 2
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    *p = v;
+#endif
+}
+
 // ------------------------------------------------------------- SoA state <-> registers
 template <int A>
 __device__ __forceinline__ void load_state(const DevBuffers& b, int n, int i, EnvStateT<A>& st) {
@@ -74,19 +91,19 @@ __device__ __forceinline__ void store_ball(const DevBuffers& b, int n, int i, co
     const float bl[13] = {ball.p.x, ball.p.y, ball.p.z, ball.quat[0], ball.quat[1], ball.quat[2], ball.quat[3],
                           ball.v.x, ball.v.y, ball.v.z, ball.w.x, ball.w.y, ball.w.z};
 #pragma unroll
-    for (int k = 0; k < 13; k++) b.ball[(size_t)k * n + i] = bl[k];
+    for (int k = 0; k < 13; k++) st_state(&b.ball[(size_t)k * n + i], bl[k]);
 }
 // progress / flags / episode and the per-agent rows of rew / reset
 template <int A>
 __device__ __forceinline__ void store_task(const DevBuffers& b, int n, int i, const EnvStateT<A>& st, const float* rew, long long reset) {
 #pragma unroll
     for (int a = 0; a < A; a++) {
-        b.progress[(size_t)i * A + a] = st.progress;
-        b.flags[(size_t)a * n + i] = st.flags[a];
-        b.rew[(size_t)i * A + a] = rew[a];
-        b.reset[(size_t)i * A + a] = reset;
+        st_state(&b.progress[(size_t)i * A + a], st.progress);
+        st_state(&b.flags[(size_t)a * n + i], st.flags[a]);
+        st_state(&b.rew[(size_t)i * A + a], rew[a]);
+        st_state(&b.reset[(size_t)i * A + a], reset);
     }
-    b.episode[i] = st.episode;
+    st_state(&b.episode[i], st.episode);
 }
 template <int A>
 __device__ __forceinline__ void store_state(const DevBuffers& b, int n, int i, const EnvStateT<A>& st, const float* rew, long long reset) {
@@ -196,6 +213,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
 struct NullVisitor {
     __device__ __forceinline__ void operator()(int, const M3&, V3, V3, V3) {}
 };
+// position of the last observed body (the paddle) only: a sweep with this visitor is the bare pose chain
+template <class T>
+struct PaddlePosVisitor {
+    V3 pos;
+    __device__ __forceinline__ void operator()(int i, const M3& Rw, V3 pw, V3, V3) {
+        if (i == ND - 1) pos = pw + mul(Rw, ld3(T::tip_frame(NB - 1).origin_xyz));
+    }
+};
 
 // obs tile -> obs_buf for the columns [C0, C1) (both multiples of 4) of `nrows` tile rows starting at tile row
 // `t0`, as float4.  Tile row t0 + r goes to obs_buf row `g0 + r * gstep` (the tile is [agent][lane], obs_buf rows
@@ -284,17 +309,21 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         }
         // FK of the final state: paddle position for the reward, then the body block of the observation row,
         // obs[0:60] (TT:1696-1697) — it depends on the pre-reset body states only (TT:1039)
-        BodyState bodies[NB];
+        // The ball wave's task tail waits for the paddle position only: a bare pose-chain sweep publishes it first
+        // (~1k cycles earlier than the full sweep would), then the full sweep produces the ten observed bodies.
         if (active) {
-            ArmGeom<T::kShapes> g;
-            BodyVisitor<T, false> bv(g, bodies);
-            fk_sweep<T>(S, q, qd, js, bv);
-            static_body<false>(S, bodies[0]);
-            s_paddle[arm * 3 + 0][lane] = bodies[NB - 1].pos.x; s_paddle[arm * 3 + 1][lane] = bodies[NB - 1].pos.y; s_paddle[arm * 3 + 2][lane] = bodies[NB - 1].pos.z;
+            PaddlePosVisitor<T> pv;
+            fk_sweep<T>(S, q, qd, js, pv);
+            s_paddle[arm * 3 + 0][lane] = pv.pos.x; s_paddle[arm * 3 + 1][lane] = pv.pos.y; s_paddle[arm * 3 + 2][lane] = pv.pos.z;
         }
         publish(&s_flag[arm], substeps + 1);
         PP_STAMP_AT(5);
         if (active) {
+            BodyState bodies[NB];
+            ArmGeom<T::kShapes> g;
+            BodyVisitor<T, false> bv(g, bodies);
+            fk_sweep<T>(S, q, qd, js, bv);
+            static_body<false>(S, bodies[0]);
             V3 bpos[NB], bvel[NB];
 #pragma unroll
             for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
@@ -310,9 +339,9 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
             const bool rst = s_reset[lane] != 0 && K.rc.variant != PPENV_VARIANT_TN;   // TN:888-901 keeps the dof state
 #pragma unroll
             for (int d = 0; d < ND; d++) {
-                b.dof_pos[(size_t)(arm * ND + d) * n + i] = rst ? K.init_dof_pos[d] : q[d];
-                b.dof_vel[(size_t)(arm * ND + d) * n + i] = rst ? K.init_dof_vel[d] : qd[d];
-                b.dof_force[(size_t)(arm * ND + d) * n + i] = tau[d];
+                st_state(&b.dof_pos[(size_t)(arm * ND + d) * n + i], rst ? K.init_dof_pos[d] : q[d]);
+                st_state(&b.dof_vel[(size_t)(arm * ND + d) * n + i], rst ? K.init_dof_vel[d] : qd[d]);
+                st_state(&b.dof_force[(size_t)(arm * ND + d) * n + i], tau[d]);
             }
         }
         return;

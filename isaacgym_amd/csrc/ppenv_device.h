@@ -225,16 +225,26 @@ PP_HD void rot_to_quat(const M3& r, float q[4]) {
 // Counter-based: (seed, global env id, episode, draw) -> U[0,1).  Same function
 // as the oracle's (oracle/ppenv_oracle.c rng_uniform); the reference's host-side
 // Python `random` stream (TT:307-312) cannot be reproduced by a vectorised env.
+// (mix64 is the SplitMix64 finaliser, used by the 27-DoF tensor-API kernel's draws.)
 PP_HD uint64_t mix64(uint64_t z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
     z ^= z >> 27; z *= 0x94D049BB133111EBull;
     z ^= z >> 31;
     return z;
 }
+// 32-bit avalanche hash ("lowbias32"): two multiplies per call.  64-bit multiplies cost four quarter-rate 32-bit
+// multiplies each on CDNA; the serve draw sits on every step's path (drawn speculatively), so the keyed counter is 32-bit.
+PP_HD uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
 PP_HD float rng_uniform(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t k) {
-    uint64_t s = mix64(seed + 0x9E3779B97F4A7C15ull * ((uint64_t)gid + 1));
-    uint64_t x = mix64(s + 0x9E3779B97F4A7C15ull * ((uint64_t)episode * 4 + k + 1));
-    return (float)(x >> 40) * (1.0f / 16777216.0f);
+    uint32_t h = hash32(gid ^ (uint32_t)seed);
+    h = hash32(h + episode * 0x9E3779B9u + (uint32_t)(seed >> 32));
+    h = hash32(h + (k + 1u) * 0x85EBCA6Bu);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 // sin / cos of a serve angle (|x| <= ~0.5 rad): Taylor to x^9 / x^8, exact to fp32 there
 PP_HD void sincos_small(float x, float& s, float& c) {
@@ -496,7 +506,9 @@ PP_HD void arm_substep(const ArmSite& S, JointSave* js, float* q, float* qd, con
         const JointDrive J = T::drive(d);
         float err = target[d] - q[d];
         float vn = qd[d] + h * qdd[d];
-        tau_drive[d] = sat[d] ? tau[d] : J.kp * (err - h * vn) - J.kd * vn;
+        // dof_force reports the drive torque within the actuator's limit: the implicit branch's end-of-substep value
+        // Kp(e - h qd+) - Kd qd+ can overshoot it when inertial coupling swings qd+ far from qd
+        tau_drive[d] = sat[d] ? tau[d] : fminf(fmaxf(J.kp * (err - h * vn) - J.kd * vn, -J.effort), J.effort);
         vn = fminf(fmaxf(vn, -J.vel_limit), J.vel_limit);
         float qn = q[d] + h * vn;
         if (qn > J.upper) { qn = J.upper; vn = fminf(vn, 0.f); }
@@ -716,6 +728,18 @@ PP_HD void heading_quat_inv(const float q[4], float out[4]) {
     out[0] = 0.f; out[1] = 0.f; out[2] = sz / nrm; out[3] = w / nrm;
 }
 
+// my_quat_rotate by a heading quaternion.  calc_heading_quat_inv always returns a rotation about z, q = (0, 0, sz, w), for
+// which my_quat_rotate's three terms a = v(2w^2-1), b = 2w(q x v), c = 2q(q.v) collapse to
+//   x' = x(2w^2-1) - 2 w sz y,   y' = y(2w^2-1) + 2 w sz x,   z' = z((2w^2-1) + 2 sz^2) = z
+// — the same fp32 products as quat_rotate's x and y (its cross-product terms with q.x = q.y = 0 are exact zeros), 6 flops
+// instead of ~30 per vector; 24 vectors per observation row (TT:1657-1660,1696-1697).
+PP_HD V3 heading_rotate(const float hinv[4], V3 v) {
+    float qw = hinv[3], sz = hinv[2];
+    float s = 2.0f * (qw * qw) - 1.0f;
+    float k = sz * qw * 2.0f;
+    return mk(v.x * s - v.y * k, v.y * s + v.x * k, v.z);
+}
+
 struct RewardIn {
     float humanoid_x;   // humanoid1_root_states[..., 0]
     V3 paddle;          // humanoid1_paddle_rb_states[..., 0:3]
@@ -911,8 +935,8 @@ PP_HD void write_obs_bodies(const V3* body_pos, const V3* body_vel, const float 
     V3 root = body_pos[0];
 #pragma unroll
     for (int j = J0; j < J1; j++) {
-        V3 lp = quat_rotate(hinv, body_pos[j] - root);   // TT:1696
-        V3 lv = quat_rotate(hinv, body_vel[j]);          // TT:1697
+        V3 lp = heading_rotate(hinv, body_pos[j] - root);   // TT:1696
+        V3 lv = heading_rotate(hinv, body_vel[j]);          // TT:1697
         store(3 * j, lp.x); store(3 * j + 1, lp.y); store(3 * j + 2, lp.z);
         store(3 * NB + 3 * j, lv.x); store(3 * NB + 3 * j + 1, lv.y); store(3 * NB + 3 * j + 2, lv.z);
     }
@@ -925,8 +949,8 @@ PP_HD void write_obs_tail(V3 root, const float hinv[4], const float* q, const fl
         store(6 * NB + d, q[d]);
         store(6 * NB + ND + d, qd[d] * 0.1f);
     }
-    V3 lb = quat_rotate(hinv, ball_p - root);            // TT:1657-1659
-    V3 lbv = quat_rotate(hinv, ball_v);                  // TT:1660
+    V3 lb = heading_rotate(hinv, ball_p - root);            // TT:1657-1659
+    V3 lbv = heading_rotate(hinv, ball_v);                  // TT:1660
     store(6 * NB + 2 * ND, lb.x); store(6 * NB + 2 * ND + 1, lb.y); store(6 * NB + 2 * ND + 2, lb.z);
     store(6 * NB + 2 * ND + 3, lbv.x); store(6 * NB + 2 * ND + 4, lbv.y); store(6 * NB + 2 * ND + 5, lbv.z);
 }

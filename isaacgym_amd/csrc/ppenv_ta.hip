@@ -169,22 +169,22 @@ __global__ __launch_bounds__(kTaBlock) void ta_post_physics_kernel(const ppenv_t
     const V3 rootp = mk(rb[0], rb[1], rb[2]);
     for (int j = 0; j < NB; j++) {
         const float* b = rb + kTaObsIds[j] * 13;
-        V3 lp = quat_rotate(hinv, mk(b[0], b[1], b[2]) - rootp);
-        V3 lv = quat_rotate(hinv, mk(b[7], b[8], b[9]));
+        V3 lp = heading_rotate(hinv, mk(b[0], b[1], b[2]) - rootp);
+        V3 lv = heading_rotate(hinv, mk(b[7], b[8], b[9]));
         o[3 * j] = lp.x; o[3 * j + 1] = lp.y; o[3 * j + 2] = lp.z;
         o[30 + 3 * j] = lv.x; o[30 + 3 * j + 1] = lv.y; o[30 + 3 * j + 2] = lv.z;
     }
 #pragma unroll
     for (int d = 0; d < TA_ND; d++) { o[60 + d] = q[d]; o[60 + TA_ND + d] = qd[d] * 0.1f; }
-    V3 lb = quat_rotate(hinv, mk(ball[0], ball[1], ball[2]) - rootp);
-    V3 lv = quat_rotate(hinv, mk(ball[7], ball[8], ball[9]));
+    V3 lb = heading_rotate(hinv, mk(ball[0], ball[1], ball[2]) - rootp);
+    V3 lv = heading_rotate(hinv, mk(ball[7], ball[8], ball[9]));
     o[114] = lb.x; o[115] = lb.y; o[116] = lb.z; o[117] = lv.x; o[118] = lv.y; o[119] = lv.z;
     o[120] = lb.y + (lv.y / (-lv.x + 1e-6f)) * lb.x;                            // TA:1839
     for (int j = 0; j < TA_NBAL; j++) {                                         // TA:1891-1927
         const float* b = rb + kTaBalIds[j] * 13;
         const float* r = irb + kTaBalIds[j] * 13;
-        V3 t = quat_rotate(hinv, mk(r[0] - b[0], r[1] - b[1], r[2] - b[2]));
-        V3 tv = quat_rotate(hinv, mk(r[7] - b[7], r[8] - b[8], r[9] - b[9]));
+        V3 t = heading_rotate(hinv, mk(r[0] - b[0], r[1] - b[1], r[2] - b[2]));
+        V3 tv = heading_rotate(hinv, mk(r[7] - b[7], r[8] - b[8], r[9] - b[9]));
         o[121 + 3 * j] = t.x * 10.f; o[122 + 3 * j] = t.y * 10.f; o[123 + 3 * j] = t.z * 10.f;
         o[121 + 3 * TA_NBAL + 3 * j] = tv.x; o[122 + 3 * TA_NBAL + 3 * j] = tv.y; o[123 + 3 * TA_NBAL + 3 * j] = tv.z;
     }

@@ -135,10 +135,17 @@ static uint64_t mix64(uint64_t z) {
     z ^= z >> 31;
     return z;
 }
+static uint32_t hash32(uint32_t x) {   /* "lowbias32" avalanche hash */
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
 static float rng_uniform(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t k) {
-    uint64_t s = mix64(seed + 0x9E3779B97F4A7C15ull * ((uint64_t)gid + 1));
-    uint64_t x = mix64(s + 0x9E3779B97F4A7C15ull * ((uint64_t)episode * 4 + k + 1));
-    return (float)(x >> 40) * (1.0f / 16777216.0f);
+    uint32_t h = hash32(gid ^ (uint32_t)seed);
+    h = hash32(h + episode * 0x9E3779B9u + (uint32_t)(seed >> 32));
+    h = hash32(h + (k + 1u) * 0x85EBCA6Bu);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 /* generate_random_speed_for_ball: TT:296-323 / T3:289-305 / TN:301-328 */
 static void serve_velocity(const ppenv_config* c, uint32_t gid, uint32_t episode, float out[3]) {
@@ -737,7 +744,7 @@ static void step_env(ppo_env* e, int i, const float* actions) {
             const ppenv_joint* j = &c->joint[d];
             double err = target[d] - q[d];
             double v_new = qd[d] + h * qdd[d];
-            tau_drive[d] = sat[d] ? tau[d] : j->kp * (err - h * v_new) - j->kd * v_new;
+            tau_drive[d] = sat[d] ? tau[d] : clampd(j->kp * (err - h * v_new) - j->kd * v_new, -j->effort, j->effort);   /* reported within the limit */
             v_new = clampd(v_new, -j->vel_limit, j->vel_limit);
             double q_new = q[d] + h * v_new;
             if (q_new > j->upper) { q_new = j->upper; if (v_new > 0) v_new = 0; }
@@ -1250,7 +1257,7 @@ static void step_env_t4(ppo_env* e, int i, const float* actions) {
                 const ppenv_joint* j = &c->joint[d];
                 double err = target[a][d] - q[a][d];
                 double v_new = qd[a][d] + h * qdd[d];
-                tau_drive[a][d] = sat[d] ? tau[d] : j->kp * (err - h * v_new) - j->kd * v_new;
+                tau_drive[a][d] = sat[d] ? tau[d] : clampd(j->kp * (err - h * v_new) - j->kd * v_new, -j->effort, j->effort);
                 v_new = clampd(v_new, -j->vel_limit, j->vel_limit);
                 double q_new = q[a][d] + h * v_new;
                 if (q_new > j->upper) { q_new = j->upper; if (v_new > 0) v_new = 0; }

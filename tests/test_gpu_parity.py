@@ -137,7 +137,8 @@ def test_schedules_agree_step_by_step(torch_cuda, monkeypatch):
             e.step(a)
         for name in ("reset_buf", "progress_buf", "flags", "episode"):
             assert torch.equal(getattr(envs["split"], name), getattr(envs["fused"], name)), (name, t)
-        for name, atol in (("obs_buf", 2e-4), ("rew_buf", 2e-2), ("dof_pos", 1e-5), ("dof_vel", 1e-3), ("ball", 5e-3)):
+        # rew: alpha = 1000 (TN) times the ball-velocity agreement of ~1e-4 m/s right after a paddle hit
+        for name, atol in (("obs_buf", 2e-4), ("rew_buf", 1e-1), ("dof_pos", 1e-5), ("dof_vel", 1e-3), ("ball", 5e-3)):
             x, y = getattr(envs["split"], name), getattr(envs["fused"], name)
             assert torch.allclose(x, y, rtol=1e-5, atol=atol), (name, t, float((x - y).abs().max()))
     for e in envs.values():
@@ -290,10 +291,9 @@ def test_long_run_stays_physical(torch_cuda, variant):
     assert bool(torch.isfinite(env.obs_buf).all()) and bool(torch.isfinite(rew_sum).all()) and bool(torch.isfinite(env.ball).all())
     assert bool((env.dof_pos >= lo - 1e-6).all()) and bool((env.dof_pos <= hi + 1e-6).all())
     assert bool((env.dof_vel.abs() <= vmax + 1e-4).all())
-    # the effort limit is tested on the explicit PD estimate; the torque the implicit branch ends up
-    # applying, Kp(e - h qd+) - Kd qd+, is not re-clamped and exceeds it when inertial coupling swings qd+ far from qd
+    # dof_force is reported within the actuator's effort limit
     effort = torch.tensor([env.config.joint[j].effort for j in range(7)], device="cuda")[:, None]
-    assert bool((env.dof_force.abs() <= 4.0 * effort).all()), float((env.dof_force.abs() / effort).max())
+    assert bool((env.dof_force.abs() <= effort * (1 + 1e-6)).all()), float((env.dof_force.abs() / effort).max())
     assert float((env.ball[3:7].pow(2).sum(0) - 1).abs().max()) < 1e-4
     assert float(env.ball[2].min()) > -0.05 and float(env.ball[0:3].abs().max()) < 50.0
     assert float(max_speed) < 60.0                           # restitution <= 1: the ball cannot keep gaining energy
