@@ -281,8 +281,8 @@ int ppenv_refresh_rigid_body_states(struct ppenv* env, float* rb_states_dev /* [
  * tasks/humanoid_pingpong_3_actor_all_dof.py ("TA"): post_physics_step TA:1145-1192 on caller-supplied
  * simulator tensors — compute_pingpong_reward_nv TA:1440-1690 (+ compute_gradient_penalty TA:1245-1301,
  * compute_imitation_reward TA:1313-1418), _reset_idx TA:965-1028, compute_observations TA:867-904
- * (-> TA:1811-1927, 313 values).  The rigid-body step of this variant (free-floating 27-DoF humanoid
- * with ground contact) is not built yet; this entry is stateless: every buffer is the caller's. */
+ * (-> TA:1811-1927, 313 values).  Stateless: every buffer is the caller's (a real Isaac Gym's tensors, or the ones
+ * ppenv_ta_simulate below steps). */
 #define PPENV_TA_NUM_DOF 27
 #define PPENV_TA_NUM_OBS 313          /* TA:106: 60 + 54 + 7 + 138 + 54 */
 #define PPENV_TA_NUM_BALANCE_BODIES 23 /* bodyStatesIdBalance, HumanoidPingpongTiltNESSparse27DOFG1.yaml:57 */
@@ -333,6 +333,81 @@ int ppenv_ta_post_physics_step(const ppenv_ta_params* params, const float* rb_st
                                const float* pre_ball_vx_dev, const float* reset_override_dev, uint32_t* flags_dev,
                                uint32_t* episode_dev, int64_t* progress_dev, float* obs_dev, float* rew_dev, int64_t* reset_dev,
                                uint32_t* scratch_any_reset_dev /* 1 word */, void* stream);
+
+/* ---- 27-DoF variant: the rigid-body step -------------------------------------------------------
+ * Replaces, for tasks/humanoid_pingpong_3_actor_all_dof.py ("TA"), pre_physics_step TA:1124-1143 (action -> PD target,
+ * snapshot of the ball's vx), gym.simulate (external, closed: a free-floating 27-DoF humanoid — fix_base_link = False,
+ * TA:462 — standing on the ground plane TA:400-407, DOF_MODE_POS drives with the 27 gains TA:757-774, one ball) and the
+ * gym.refresh_* calls TA:1150.  PARITY UNPINNED like every rigid-body step here: the specification is the build's own
+ * (DESIGN.md "TA physics").  Stateless like ppenv_ta_post_physics_step: the simulation state IS the caller's Isaac-Gym
+ * layout tensors (root_states [N,3,13], dof_states [N,27,2]), which _reset_idx (TA:965-1028, inside
+ * ppenv_ta_post_physics_step) rewrites in place for reset envs exactly as the reference does. */
+#define PPENV_TA_NUM_LINKS 28   /* pelvis (floating) + one link per dof; link k >= 1 is moved by dof k-1 (dof order TA:1303-1311) */
+#define PPENV_TA_NUM_FIXED 12   /* rigid bodies welded to a link: imu, contour, d435, head, logo, ..., hands, paddle */
+#define PPENV_TA_MAX_CONTACTS 24 /* points of the humanoid tested against the ground plane */
+
+typedef struct ppenv_ta_link {
+    int32_t parent;            /* link index, parents before children; -1 for the pelvis */
+    int32_t axis;              /* 0/1/2: joint rotates about x/y/z of the child frame */
+    int32_t body;              /* Isaac Gym rigid-body index of this link (pingpong_note.txt:33) */
+    float origin_xyz[3];       /* child frame in the parent frame at q = 0 */
+    float origin_rot[9];
+    float mass;                /* link + everything welded to it */
+    float com[3];
+    float inertia[6];          /* about the com, link axes: xx yy zz xy xz yz */
+    float lower, upper;        /* joint limits -> action offset / scale (TA:729-733) */
+    float kp, kd;              /* TA:757-774 */
+    float effort, vel_limit, armature;
+} ppenv_ta_link;
+
+typedef struct ppenv_ta_fixed {
+    int32_t body;              /* Isaac Gym rigid-body index */
+    int32_t link;              /* the link it is welded to */
+    float xyz[3], rot[9];      /* pose in that link's frame */
+} ppenv_ta_fixed;
+
+typedef struct ppenv_ta_model {
+    ppenv_ta_link link[PPENV_TA_NUM_LINKS];
+    ppenv_ta_fixed fixed[PPENV_TA_NUM_FIXED];
+    /* humanoid-vs-ground (plane TA:400-407): points fixed in links — the eight sole corners of the two ankle-roll links,
+     * then knees, pelvis, torso, head, elbows, hands — each a penalty contact */
+    int32_t num_contacts;
+    int32_t contact_link[PPENV_TA_MAX_CONTACTS];
+    float contact_point[PPENV_TA_MAX_CONTACTS][3];
+    float ground_z;            /* plane height for the humanoid AND the ball (see scene.py: PlaneParams.distance = -0.21) */
+    float foot_stiffness;      /* N/m per point, penalty contact integrated implicitly */
+    float foot_damping;        /* N s/m per point, normal */
+    float foot_tangent_damping;/* N s/m per point: regularised Coulomb friction */
+    float foot_friction;       /* combined mu (plane 1.0, TA yaml:78-79; humanoid shapes 0.5, TA:588) */
+    float contact_fade_depth;  /* m: the contact damper fades in over this much overlap ... */
+    float contact_fade_force;  /* N: ... and the implicit terms with the normal force, so the law has no jump at touch-down / lift-off */
+    float contact_max_penetration; /* the spring saturates here: deeper overlap is pushed out at <= k pen_max / c_n (what
+                                      max_depenetration_velocity does in PhysX) instead of storing 1/2 k pen^2 */
+    /* Joint limits as joint-space torques (a clamp of q or qd after the solve would stop a link without any reaction on
+     * its parent: harmless on a bolted base, a momentum source on a floating one): beyond a position limit a spring-damper
+     * limit_stiffness / limit_damping, above the velocity limit a damper vel_limit_damping, all integrated implicitly
+     * (they only add to the joint's diagonal inertia term, like the PD drive). */
+    float limit_stiffness, limit_damping, vel_limit_damping;
+    /* ball-vs-humanoid collision: `scene.shape[s].link` and `scene.paddle_link` index ppenv_ta_model.link;
+     * the broad-phase sphere (scene.humanoid_bound_radius) is centred on this point of this link */
+    int32_t bound_link;
+    float bound_center[3];
+} ppenv_ta_model;
+
+struct ppenv_ta_sim;   /* opaque: device copy of the constants */
+typedef struct ppenv_ta_sim ppenv_ta_sim;
+
+/* `scene` supplies what the 27-DoF scene shares with the 3-actor ones: dt, substeps, ball_substeps, gravity_z, clip_actions,
+ * contact scalars, ball, table, net, paddle blade and the humanoid's ball-collision shapes (its 7-DoF arm tables are ignored). */
+int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, void* stream, ppenv_ta_sim** out);
+void ppenv_ta_sim_destroy(ppenv_ta_sim* sim);
+/* One pre_physics_step + gym.simulate + refresh.  actions [N,27]; root_states [N,3,13] (humanoid, table, ball) and
+ * dof_states [N,27,2] are read and updated in place; rb_states [N,42,13], dof_force [N,27], pre_ball_vx [N] are written. */
+int ppenv_ta_simulate(ppenv_ta_sim* sim, int32_t num_envs, const float* actions_dev, float* root_states_dev, float* dof_states_dev,
+                      float* rb_states_dev, float* dof_force_dev, float* pre_ball_vx_dev, void* stream);
+/* rigid-body states of the current root / dof states without stepping (initial_rb_states of TA:1152; tests) */
+int ppenv_ta_forward_kinematics(ppenv_ta_sim* sim, int32_t num_envs, const float* root_states_dev, const float* dof_states_dev,
+                                float* rb_states_dev, void* stream);
 
 /* ---- 4-actor variant (Humanoid12PingpongTiltG1), reward functions only ------------------------------
  * tasks/humanoid_pingpong_4_actor_tilt.py ("T4") defines compute_humanoid1_pingpong_reward T4:1113-1278

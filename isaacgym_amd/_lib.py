@@ -13,8 +13,9 @@ from . import scene
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("PPENV_LIB", os.path.join(_PKG, "lib", "libppenv.so"))   # PPENV_LIB: profiling builds only
-SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip"), os.path.join(_PKG, "csrc", "ppenv_ta.hip")]
-HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1.h"), os.path.join(ROOT, "include", "ppenv.h")]
+SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip"), os.path.join(_PKG, "csrc", "ppenv_ta.hip"), os.path.join(_PKG, "csrc", "ppenv_ta_sim.hip")]
+HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1.h"), os.path.join(_PKG, "csrc", "ppenv_ta_device.h"),
+           os.path.join(ROOT, "include", "ppenv.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only", "-fPIC", "-shared"]
 
 _lib = None
@@ -81,6 +82,11 @@ def lib():
     L.ppenv_set_serve_override.argtypes = [vp, vp, C.c_int, vp]
     L.ppenv_ta_post_physics_step.argtypes = [C.POINTER(scene.TAParams)] + [vp] * 15
     L.ppenv_t4_rewards.argtypes = [C.POINTER(scene.T4Params)] + [vp] * 15
+    L.ppenv_ta_sim_create.argtypes = [cfgp, C.POINTER(scene.TAModel), vp, C.POINTER(vp)]
+    L.ppenv_ta_sim_destroy.restype = None
+    L.ppenv_ta_sim_destroy.argtypes = [vp]
+    L.ppenv_ta_simulate.argtypes = [vp, C.c_int32] + [vp] * 7
+    L.ppenv_ta_forward_kinematics.argtypes = [vp, C.c_int32] + [vp] * 4
     L.ppenv_state_bytes.restype = sz
     L.ppenv_state_bytes.argtypes = [vp]
     L.ppenv_get_state.argtypes = [vp, vp, sz]

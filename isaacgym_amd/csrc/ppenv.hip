@@ -354,6 +354,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     long long reset = 0;
     V3 next_serve = mk(0, 0, 0);
     ArmGeom<T::kShapes> g[A];
+    V3 bound[A];
     float qs[A * ND], qds[A * ND];
 #pragma unroll
     for (int a = 0; a < A; a++) rew[a] = 0.f;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         st.episode = b.episode[i];
         pre_vx = st.ball.v.x;   // TT:1020
 #pragma unroll
-        for (int a = 0; a < A; a++) static_geometry<T>(K.site[a], g[a]);
+        for (int a = 0; a < A; a++) { static_geometry<T>(K.site[a], g[a]); bound[a] = ld3(K.site[a].bound_center); }
         // the serve this env gets if it resets at the end of the step: the counter RNG is a pure function of
         // (seed, env id, episode + 1), so it can be drawn now, off the tail of the step
         next_serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
@@ -400,7 +401,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
                 GeomVisitor<T> gv(g[a]);
                 fk_sweep<T>(K.site[a], &qs[a * ND], &qds[a * ND], js, gv);
             }
-            ball_substep<T, A>(K, st.ball, g);
+            ball_substep<T, A>(K, st.ball, g, bound);
         }
         PP_STAMP_AT(19 + 2 * s);
     }

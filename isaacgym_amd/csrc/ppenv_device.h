@@ -621,8 +621,10 @@ PP_HD V3 lerp(V3 a, V3 b, float f) { return madd(a, b - a, f); }
 // (contacts are generated from start-of-step poses, as PhysX does).  Within a substep the ball and the arm
 // therefore do not depend on each other — which is what lets the two-wave kernel run them concurrently.
 // A = number of humanoids (2 for the 4-actor variant: humanoid 1's shapes are visited first, then humanoid 2's).
+// bound[arm]: centre of the humanoid's broad-phase sphere (fixed with the base here; it follows the torso of the
+// free-floating 27-DoF humanoid).
 template <class T, int A>
-PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> (&g)[A]) {
+PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> (&g)[A], const V3 (&bound)[A]) {
     const int M = K.ball_substeps;
     const float hb = K.hb, h = K.h;
     BallConsts k;
@@ -664,7 +666,7 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> 
 #pragma unroll
         for (int arm = 0; arm < A; arm++) {
             const ArmGeom<T::kShapes>& ga = g[arm];
-            V3 db = b.p - ld3(K.site[arm].bound_center);
+            V3 db = b.p - bound[arm];
 #if defined(PP_ABLATE) && PP_ABLATE == 1   // profiling build: no humanoid shapes
             if (false) {
 #else
@@ -871,15 +873,17 @@ PP_HD void simulate_env(const StepConsts& K, const float* actions, EnvStateT<A>&
     const float h = K.h;
     JointSave js[A][ND];
     ArmGeom<T::kShapes> g[A];
+    V3 bound[A];
 #pragma unroll
     for (int a = 0; a < A; a++) {
+        bound[a] = ld3(K.site[a].bound_center);
         static_geometry<T>(K.site[a], g[a]);
         GeomVisitor<T> gv(g[a]);
         fk_sweep<T>(K.site[a], &st.q[a * ND], &st.qd[a * ND], js[a], gv);
     }
     PP_STAMP_AT(2);
     for (int s = 0; s < substeps; s++) {
-        ball_substep<T, A>(K, st.ball, g);                                // against the arms as they are at the substep's start
+        ball_substep<T, A>(K, st.ball, g, bound);                         // against the arms as they are at the substep's start
         PP_STAMP_AT(3 + 3 * s);
 #pragma unroll
         for (int a = 0; a < A; a++)

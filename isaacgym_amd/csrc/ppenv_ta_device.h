@@ -1,0 +1,442 @@
+// ppenv_ta_device.h — per-env arithmetic of the 27-DoF variant's rigid-body step (fp32).
+//
+// The free-floating 28-link humanoid of tasks/humanoid_pingpong_3_actor_all_dof.py ("TA": fix_base_link = False TA:462,
+// 27 position-driven dofs TA:757-774, ground plane TA:400-407) stepped with the floating-base articulated-body algorithm
+// (Featherstone, RBDA table 9.4) in link coordinates.  Specification: DESIGN.md "TA physics"; the oracle restates it with
+// Newton-Euler sweeps + a dense 33x33 solve in fp64 (oracle/ppenv_oracle.c, ta_simulate_env).
+//
+// One lane owns one env.  Unlike the 7-DoF arm (compiled-in chain, everything in registers) the tree does not fit a
+// lane's registers: per-link quantities live in a lane-private column of an LDS array, addressed through the `Store`
+// accessor (st(slot) -> float&), and the link loops are real loops over constant tables (all lanes of a wave visit the
+// same link, so every table read is a scalar load).  tests/csrc/host_shim.cpp runs the same code over a plain array.
+#pragma once
+
+#include "ppenv_device.h"
+
+namespace pp {
+namespace ta {
+
+constexpr int NL = PPENV_TA_NUM_LINKS;
+constexpr int NDOF = PPENV_TA_NUM_DOF;
+
+// ---- constants of the tree, derived once on the host (make_ta_consts) and read from global memory by the kernels
+struct LinkC {
+    int32_t parent, axis, body, cfirst, ccount, pad_[3];   // contacts [cfirst, cfirst + ccount) sit on this link
+    float r[3], R0[9];                                      // child frame in the parent frame at q = 0
+    float mass, mc[3], Io[6];                               // m, m * com, inertia about the link ORIGIN (xx yy zz xy xz yz)
+    float lo, hi, kp, kd, effort, vlim, armature;
+};
+struct FixedC { int32_t body, link, pad_[2]; float xyz[3], rot[9]; };
+struct TAConsts {
+    LinkC link[NL];
+    FixedC fixed[PPENV_TA_NUM_FIXED];
+    int32_t num_contacts, paddle_link, bound_link, num_shapes;
+    float cpoint[PPENV_TA_MAX_CONTACTS][3];                 // sorted by link
+    int32_t shape_link[PPENV_MAX_SHAPES];
+    float shape_a[PPENV_MAX_SHAPES][3], shape_b[PPENV_MAX_SHAPES][3];
+    float paddle_center[3], paddle_normal[3], bound_center[3];
+    float ground_z, k_n, c_n, c_t, mu, pen_max, fade_depth, fade_force;
+    float k_lim, c_lim, c_vlim;
+    float gravity_z, h, clip_actions;
+    int32_t substeps;
+};
+
+// ---- per-lane storage layout: NL link records, then NDOF dof records
+constexpr int F_C = 0, F_S = 1, F_W = 2, F_V = 5, F_RW = 8, F_PW = 17;
+constexpr int F_A = 20, F_B = 26, F_D = 35, F_PN = 41, F_PF = 44;    // articulated inertia blocks A (sym) B D (sym), bias force
+constexpr int F_UA = 20, F_UB = 23, F_DINV = 26, F_U = 27, F_AW = 28, F_AV = 31;   // overlay A..: written once the link's inertia is consumed
+constexpr int LINK_STRIDE = 47;
+constexpr int DOF_BASE = NL * LINK_STRIDE;
+constexpr int G_Q = 0, G_QD = 1, G_TARGET = 2, G_FORCE = 3;
+constexpr int DOF_STRIDE = 4;
+constexpr int NUM_SLOTS = DOF_BASE + NDOF * DOF_STRIDE;
+
+template <class Store> PP_HD V3 ldv(Store& st, int slot) { return mk(st(slot), st(slot + 1), st(slot + 2)); }
+template <class Store> PP_HD void stv(Store& st, int slot, V3 v) { st(slot) = v.x; st(slot + 1) = v.y; st(slot + 2) = v.z; }
+template <class Store> PP_HD M3 ldm3(Store& st, int slot) { M3 r; for (int k = 0; k < 9; k++) r.m[k] = st(slot + k); return r; }
+template <class Store> PP_HD void stm3(Store& st, int slot, const M3& a) { for (int k = 0; k < 9; k++) st(slot + k) = a.m[k]; }
+template <class Store> PP_HD S3 lds3(Store& st, int slot) { S3 r = {st(slot), st(slot + 1), st(slot + 2), st(slot + 3), st(slot + 4), st(slot + 5)}; return r; }
+template <class Store> PP_HD void sts3(Store& st, int slot, const S3& a) { st(slot) = a.xx; st(slot + 1) = a.yy; st(slot + 2) = a.zz; st(slot + 3) = a.xy; st(slot + 4) = a.xz; st(slot + 5) = a.yz; }
+
+PP_HD M3 joint_rot_rt(const float* r0, int ax, float c, float s) {   // joint_rot with a run-time axis
+    return ax == 0 ? joint_rot<0>(r0, c, s) : (ax == 1 ? joint_rot<1>(r0, c, s) : joint_rot<2>(r0, c, s));
+}
+PP_HD M3 quat_to_m3(const float q[4]) { M3 r; quat_to_rot(q, r.m); return r; }
+PP_HD S3 sym_from(const float* p) { S3 r = {p[0], p[1], p[2], p[3], p[4], p[5]}; return r; }
+PP_HD M3 cross_mat_scaled(V3 a) { M3 r = {{0.f, -a.z, a.y, a.z, 0.f, -a.x, -a.y, a.x, 0.f}}; return r; }   // a^
+// r^ S r^T for symmetric S (the angular block a point inertia S at offset r adds)
+PP_HD S3 rsr(V3 r, const S3& s) {
+    M3 sm = from_sym(s);
+    // T = r^ S : rows are r x cols... (r^ S)_ij = (r x col_j(S))_i
+    V3 t0 = cross(r, col(sm, 0)), t1 = cross(r, col(sm, 1)), t2 = cross(r, col(sm, 2));
+    M3 t = {{t0.x, t1.x, t2.x, t0.y, t1.y, t2.y, t0.z, t1.z, t2.z}};
+    // (T r^T)_ij = -(T r^)_ij = (r x row_i(T))_j  [row_i(T) r^T = r x row_i(T)]
+    V3 u0 = cross(r, row(t, 0)), u1 = cross(r, row(t, 1)), u2 = cross(r, row(t, 2));
+    S3 o = {u0.x, u1.y, u2.z, u0.y, u0.z, u1.z};
+    return o;
+}
+
+// world pose + link-frame twist of the pelvis from its root_states row (pos3 quat4 linvel3 angvel3, world)
+struct BaseState { V3 p; float quat[4]; V3 vw, ww; };
+
+// Rigid-body inertia, velocity-product and gravity bias, ground contacts of one link -> its record (A B D pn pf).
+template <class Store>
+PP_HD void init_link_dynamics(const TAConsts& C, Store& st, int i, const M3& Rw, V3 pw, V3 w, V3 v) {
+    const LinkC& L = C.link[i];
+    const int o = i * LINK_STRIDE;
+    S3 A = sym_from(L.Io);
+    V3 mc = ld3(L.mc);
+    const float m = L.mass;
+    V3 h_ang = mul(A, w) + cross(mc, v);
+    V3 h_lin = v * m - cross(mc, w);
+    V3 pn = cross(w, h_ang) + cross(v, h_lin);
+    V3 pf = cross(w, h_lin);
+    V3 gb = mk(Rw.m[6], Rw.m[7], Rw.m[8]) * C.gravity_z;   // R^T (0, 0, g)
+    pn = pn - cross(mc, gb);
+    pf = pf - gb * m;
+    M3 B = cross_mat_scaled(mc);
+    S3 D = {m, m, m, 0.f, 0.f, 0.f};
+    const V3 zb = mk(Rw.m[6], Rw.m[7], Rw.m[8]);           // world z axis in link coordinates
+    for (int k = L.cfirst; k < L.cfirst + L.ccount; k++) {
+        V3 r = ld3(C.cpoint[k]);
+        V3 pc = pw + mul(Rw, r);
+        float pen = C.ground_z - pc.z;
+        if (!(pen > 0.f)) continue;
+        V3 vloc = v + cross(w, r);
+        V3 vw = mul(Rw, vloc);
+        // every switch of the contact law is a ramp (see the oracle): damper fades in with depth, implicit terms with force
+        float wfade = pen < C.fade_depth ? pen / C.fade_depth : 1.f;
+        float fn0 = C.k_n * fminf(pen, C.pen_max) - wfade * C.c_n * vw.z;
+        if (!(fn0 > 0.f)) continue;
+        float gfade = fn0 < C.fade_force ? fn0 / C.fade_force : 1.f;
+        float vt = sqrtf(vw.x * vw.x + vw.y * vw.y);
+        float dt = gfade * C.c_t;
+        if (dt * vt > C.mu * fn0) dt = C.mu * fn0 / vt;
+        V3 fb = tmul(Rw, mk(-dt * vw.x, -dt * vw.y, fn0));
+        pn = pn - cross(r, fb);
+        pf = pf - fb;
+        // h D_b = h (dt 1 + (dn - dt) z z^T), J = [-r^, 1]
+        float dn = gfade * (wfade * C.c_n + C.h * C.k_n);
+        float hd = C.h * dt, hz = C.h * (dn - dt);
+        S3 Dp = {hd + hz * zb.x * zb.x, hd + hz * zb.y * zb.y, hd + hz * zb.z * zb.z, hz * zb.x * zb.y, hz * zb.x * zb.z, hz * zb.y * zb.z};
+        add_sym(D, Dp);
+        add_sym(A, rsr(r, Dp));
+        M3 dm = from_sym(Dp);   // B += r^ Dp
+        V3 b0 = cross(r, col(dm, 0)), b1 = cross(r, col(dm, 1)), b2 = cross(r, col(dm, 2));
+        B.m[0] += b0.x; B.m[1] += b1.x; B.m[2] += b2.x;
+        B.m[3] += b0.y; B.m[4] += b1.y; B.m[5] += b2.y;
+        B.m[6] += b0.z; B.m[7] += b1.z; B.m[8] += b2.z;
+    }
+    sts3(st, o + F_A, A); stm3(st, o + F_B, B); sts3(st, o + F_D, D);
+    stv(st, o + F_PN, pn); stv(st, o + F_PF, pf);
+}
+
+// Pass 1: kinematics base -> tips.  Fills c s w v Rw pw of every link; with DYN also the link's inertia / bias record.
+template <bool DYN, class Store>
+PP_HD void pass_kinematics(const TAConsts& C, Store& st, const BaseState& b) {
+    {
+        M3 Rw = quat_to_m3(b.quat);
+        V3 w = tmul(Rw, b.ww), v = tmul(Rw, b.vw);
+        stv(st, F_W, w); stv(st, F_V, v); stm3(st, F_RW, Rw); stv(st, F_PW, b.p);
+        if (DYN) init_link_dynamics(C, st, 0, Rw, b.p, w, v);
+    }
+    for (int i = 1; i < NL; i++) {
+        const LinkC& L = C.link[i];
+        const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, ax = L.axis;
+        float q = st(DOF_BASE + (i - 1) * DOF_STRIDE + G_Q), qd = st(DOF_BASE + (i - 1) * DOF_STRIDE + G_QD);
+        float s, c;
+        sincos_joint(q, s, c);
+        M3 E = joint_rot_rt(L.R0, ax, c, s);
+        V3 r = ld3(L.r);
+        M3 Rp = ldm3(st, po + F_RW);
+        V3 pp = ldv(st, po + F_PW), wp = ldv(st, po + F_W), vp = ldv(st, po + F_V);
+        M3 Rw = mul(Rp, E);
+        V3 pw = pp + mul(Rp, r);
+        V3 w = tmul(E, wp), v = tmul(E, vp + cross(wp, r));
+        if (ax == 0) w.x += qd; else if (ax == 1) w.y += qd; else w.z += qd;
+        st(o + F_C) = c; st(o + F_S) = s;
+        stv(st, o + F_W, w); stv(st, o + F_V, v); stm3(st, o + F_RW, Rw); stv(st, o + F_PW, pw);
+        if (DYN) init_link_dynamics(C, st, i, Rw, pw, w, v);
+    }
+}
+
+// drive + limit torques of dof d at the start of a substep (implicit PD with its explicit part clamped to the effort
+// limit; limit spring-damper and velocity-cap damper implicit): torque and the joint-space inertia they add
+PP_HD void joint_torque(const TAConsts& C, const LinkC& L, float q, float qd, float target, float& tau, float& arm) {
+    const float h = C.h;
+    float err = target - q;
+    tau = fminf(fmaxf(L.kp * (err - h * qd) - L.kd * qd, -L.effort), L.effort);   // implicit PD, explicit part within the effort limit
+    arm = L.armature + h * L.kd + h * h * L.kp;
+    float over = q > L.hi ? q - L.hi : (q < L.lo ? q - L.lo : 0.f);
+    if (over != 0.f) {
+        // quadratic toe over the first 0.01 rad, tangent stiffness in the implicit term (see the oracle)
+        float x = fabsf(over), ramp = fminf(x * 100.f, 1.f);
+        float phi = x < 0.01f ? x * x * 50.f : x - 0.005f;
+        float kt = C.k_lim * ramp;
+        tau += -copysignf(C.k_lim * phi, over) - kt * h * qd - ramp * C.c_lim * qd;
+        arm += h * (ramp * C.c_lim + h * kt);
+    }
+    if (fabsf(qd) > L.vlim) {
+        float ex = fabsf(qd) - L.vlim;
+        tau += -C.c_vlim * copysignf(ex, qd);
+        arm += h * C.c_vlim * fminf(ex, 1.f);                  // fades in over 1 rad/s
+    }
+}
+
+// Pass 2: articulated inertias tips -> base (RBDA 9.4 with the drive's implicit terms on the joint diagonal)
+template <class Store>
+PP_HD void pass_inertia(const TAConsts& C, Store& st) {
+    for (int i = NL - 1; i >= 1; i--) {
+        const LinkC& L = C.link[i];
+        const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, ax = L.axis, dofo = DOF_BASE + (i - 1) * DOF_STRIDE;
+        S3 A = lds3(st, o + F_A), D = lds3(st, o + F_D);
+        M3 B = ldm3(st, o + F_B);
+        V3 pn = ldv(st, o + F_PN), pf = ldv(st, o + F_PF), w = ldv(st, o + F_W), v = ldv(st, o + F_V);
+        const float qd = st(dofo + G_QD);
+        float tau, arm;
+        joint_torque(C, L, st(dofo + G_Q), qd, st(dofo + G_TARGET), tau, arm);
+        V3 ua = symcol(A, ax), ub = row(B, ax);
+        float dinv = rcp_fast(symdiag(A, ax) + arm);
+        float u = tau - comp(pn, ax);
+        sym_rank1_sub(A, ua, dinv);
+        sym_rank1_sub(D, ub, dinv);
+        V3 uad = ua * dinv;
+        for (int r = 0; r < 3; r++) {
+            float k = comp(uad, r);
+            B.m[3 * r] -= k * ub.x; B.m[3 * r + 1] -= k * ub.y; B.m[3 * r + 2] -= k * ub.z;
+        }
+        V3 e = unit(ax);
+        V3 cw = cross(w, e) * qd, cv = cross(v, e) * qd;
+        float ud = u * dinv;
+        V3 pan = pn + mul(A, cw) + mul(B, cv) + ua * ud;
+        V3 paf = pf + tmul(B, cw) + mul(D, cv) + ub * ud;
+        // the link's own record is consumed: keep what pass 3 needs in its place
+        stv(st, o + F_UA, ua); stv(st, o + F_UB, ub); st(o + F_DINV) = dinv; st(o + F_U) = u;
+        // to the parent's coordinates
+        M3 E = joint_rot_rt(L.R0, ax, st(o + F_C), st(o + F_S));
+        V3 r = ld3(L.r);
+        S3 Ar = rot_sym(E, A), Dr = rot_sym(E, D);
+        M3 Br = mul_t(mul(E, B), E);
+        V3 nr = mul(E, pan), fr = mul(E, paf);
+        M3 Dm = from_sym(Dr);
+        M3 Bp;
+        for (int j = 0; j < 3; j++) {
+            V3 x = cross(r, col(Dm, j));
+            Bp.m[j] = Br.m[j] + x.x; Bp.m[3 + j] = Br.m[3 + j] + x.y; Bp.m[6 + j] = Br.m[6 + j] + x.z;
+        }
+        V3 wp0 = cross(r, row(Bp, 0)), wp1 = cross(r, row(Bp, 1)), wp2 = cross(r, row(Bp, 2));
+        V3 wb0 = cross(r, row(Br, 0)), wb1 = cross(r, row(Br, 1)), wb2 = cross(r, row(Br, 2));
+        S3 Ap = {Ar.xx + wp0.x + wb0.x, Ar.yy + wp1.y + wb1.y, Ar.zz + wp2.z + wb2.z,
+                 Ar.xy + wp1.x + wb0.y, Ar.xz + wp2.x + wb0.z, Ar.yz + wp2.y + wb1.z};
+        V3 np = nr + cross(r, fr);
+        // accumulate into the parent's record
+        S3 PA = lds3(st, po + F_A), PD = lds3(st, po + F_D);
+        M3 PB = ldm3(st, po + F_B);
+        add_sym(PA, Ap); add_sym(PD, Dr);
+        for (int k = 0; k < 9; k++) PB.m[k] += Bp.m[k];
+        sts3(st, po + F_A, PA); sts3(st, po + F_D, PD); stm3(st, po + F_B, PB);
+        stv(st, po + F_PN, ldv(st, po + F_PN) + np);
+        stv(st, po + F_PF, ldv(st, po + F_PF) + fr);
+    }
+}
+
+PP_HD M3 inv_sym(const S3& s) {   // inverse of a symmetric positive-definite 3x3
+    float c00 = s.yy * s.zz - s.yz * s.yz, c01 = s.xz * s.yz - s.xy * s.zz, c02 = s.xy * s.yz - s.xz * s.yy;
+    float c11 = s.xx * s.zz - s.xz * s.xz, c12 = s.xy * s.xz - s.xx * s.yz, c22 = s.xx * s.yy - s.xy * s.xy;
+    float idet = 1.0f / (s.xx * c00 + s.xy * c01 + s.xz * c02);
+    M3 r = {{c00 * idet, c01 * idet, c02 * idet, c01 * idet, c11 * idet, c12 * idet, c02 * idet, c12 * idet, c22 * idet}};
+    return r;
+}
+
+// base acceleration from [A B; B^T D] [alpha; a] = -[pn; pf]
+template <class Store>
+PP_HD void solve_base(Store& st, V3& alpha, V3& a) {
+    S3 A = lds3(st, F_A), D = lds3(st, F_D);
+    M3 B = ldm3(st, F_B);
+    V3 pn = ldv(st, F_PN), pf = ldv(st, F_PF);
+    M3 Di = inv_sym(D);
+    M3 BDi = mul(B, Di);                       // B D^-1
+    M3 S = mul_t(BDi, B);                      // B D^-1 B^T
+    S3 Sc = {A.xx - S.m[0], A.yy - S.m[4], A.zz - S.m[8], A.xy - 0.5f * (S.m[1] + S.m[3]), A.xz - 0.5f * (S.m[2] + S.m[6]), A.yz - 0.5f * (S.m[5] + S.m[7])};
+    V3 rhs = mul(BDi, pf) - pn;
+    alpha = mul(inv_sym(Sc), rhs);
+    a = -mul(Di, pf + tmul(B, alpha));
+}
+
+// Pass 3: accelerations base -> tips, and the joints' semi-implicit Euler update (q, qd, reported drive torque)
+template <class Store>
+PP_HD void pass_accelerate(const TAConsts& C, Store& st, V3 alpha0, V3 a0) {
+    stv(st, F_AW, alpha0); stv(st, F_AV, a0);
+    for (int i = 1; i < NL; i++) {
+        const LinkC& L = C.link[i];
+        const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, ax = L.axis, dofo = DOF_BASE + (i - 1) * DOF_STRIDE;
+        M3 E = joint_rot_rt(L.R0, ax, st(o + F_C), st(o + F_S));
+        V3 r = ld3(L.r), e = unit(ax);
+        V3 aw = ldv(st, po + F_AW), av = ldv(st, po + F_AV);
+        const float q = st(dofo + G_Q), qd = st(dofo + G_QD), target = st(dofo + G_TARGET);
+        V3 aw2 = tmul(E, aw) + cross(ldv(st, o + F_W), e) * qd;
+        V3 av2 = tmul(E, av + cross(aw, r)) + cross(ldv(st, o + F_V), e) * qd;
+        float qdd = (st(o + F_U) - dot(ldv(st, o + F_UA), aw2) - dot(ldv(st, o + F_UB), av2)) * st(o + F_DINV);
+        if (ax == 0) aw2.x += qdd; else if (ax == 1) aw2.y += qdd; else aw2.z += qdd;
+        stv(st, o + F_AW, aw2); stv(st, o + F_AV, av2);
+        // integrate the joint; report the drive torque within the actuator's limit
+        float err = target - q;
+        float vn = qd + C.h * qdd;
+        st(dofo + G_FORCE) = fminf(fmaxf(L.kp * (err - C.h * vn) - L.kd * vn, -L.effort), L.effort);
+        st(dofo + G_Q) = q + C.h * vn;
+        st(dofo + G_QD) = vn;
+    }
+}
+
+// base: semi-implicit Euler in world coordinates (classical acceleration of the origin = R (a + w x v))
+template <class Store>
+PP_HD void integrate_base(const TAConsts& C, Store& st, BaseState& b, V3 alpha, V3 a) {
+    M3 Rw = ldm3(st, F_RW);
+    V3 wb = ldv(st, F_W), vb = ldv(st, F_V);
+    V3 aw = mul(Rw, a + cross(wb, vb)), alw = mul(Rw, alpha);
+    const float h = C.h;
+    b.vw = madd(b.vw, aw, h);
+    b.ww = madd(b.ww, alw, h);
+    b.p = madd(b.p, b.vw, h);
+    float x = b.quat[0], y = b.quat[1], z = b.quat[2], w = b.quat[3], kq = 0.5f * h;
+    float nx = x + kq * (b.ww.x * w + b.ww.y * z - b.ww.z * y);
+    float ny = y + kq * (b.ww.y * w + b.ww.z * x - b.ww.x * z);
+    float nz = z + kq * (b.ww.z * w + b.ww.x * y - b.ww.y * x);
+    float nw = w + kq * (-b.ww.x * x - b.ww.y * y - b.ww.z * z);
+    float inv = rsq_fast(nx * nx + ny * ny + nz * nz + nw * nw);
+    b.quat[0] = nx * inv; b.quat[1] = ny * inv; b.quat[2] = nz * inv; b.quat[3] = nw * inv;
+}
+
+// world position / velocity of a point fixed in link `link` (after pass_kinematics)
+template <class Store>
+PP_HD void point_state(Store& st, int link, V3 r, V3& p, V3& v) {
+    const int o = link * LINK_STRIDE;
+    M3 Rw = ldm3(st, o + F_RW);
+    p = ldv(st, o + F_PW) + mul(Rw, r);
+    v = mul(Rw, ldv(st, o + F_V) + cross(ldv(st, o + F_W), r));
+}
+
+// ball-collision geometry of the humanoid at the start of a substep
+template <int NSHAPES, class Store>
+PP_HD void collision_geometry(const TAConsts& C, Store& st, ArmGeom<NSHAPES>& g, V3& bound) {
+    const int po = C.paddle_link * LINK_STRIDE;
+    M3 Rp = ldm3(st, po + F_RW);
+    point_state(st, C.paddle_link, ld3(C.paddle_center), g.pc, g.vpc);
+    g.pn = mul(Rp, ld3(C.paddle_normal));
+    g.pnd = cross(mul(Rp, ldv(st, po + F_W)), g.pn);
+    for (int s = 0; s < NSHAPES; s++) {
+        point_state(st, C.shape_link[s], ld3(C.shape_a[s]), g.a[s], g.va[s]);
+        point_state(st, C.shape_link[s], ld3(C.shape_b[s]), g.b[s], g.vb[s]);
+    }
+    V3 dummy;
+    point_state(st, C.bound_link, ld3(C.bound_center), bound, dummy);
+}
+
+// the compiled shape radii / paddle blade are the 3-actor model's; here every shape rides on a moving link
+struct ModelG1TA : ModelG1 {
+    PP_HD static constexpr int shape_link(int) { return 0; }
+};
+
+// One pre_physics_step + gym.simulate for one env.  q / qd / target live in the store; base and ball in registers.
+template <class Store>
+PP_HD void simulate_env_ta(const TAConsts& C, const StepConsts& K, Store& st, BaseState& base, Ball& ball) {
+    for (int s = 0; s < C.substeps; s++) {
+        pass_kinematics<true>(C, st, base);
+        ArmGeom<ModelG1TA::kShapes> g[1];
+        V3 bound[1];
+        collision_geometry(C, st, g[0], bound[0]);          // poses and velocities at the start of the substep
+        pass_inertia(C, st);
+        V3 alpha, a;
+        solve_base(st, alpha, a);
+        pass_accelerate(C, st, alpha, a);                    // also integrates the joints
+        integrate_base(C, st, base, alpha, a);               // uses the start-of-substep base frame (still in the store)
+        ball_substep<ModelG1TA, 1>(K, ball, g, bound);
+    }
+}
+
+// rigid_body_states rows [42][13] of one env (gym.refresh_rigid_body_state_tensor) after pass_kinematics<false>
+template <class Store>
+PP_HD void write_body_row(float* row, const M3& R, V3 p, V3 lin, V3 ang) {
+    float q[4];
+    rot_to_quat(R, q);
+    row[0] = p.x; row[1] = p.y; row[2] = p.z; row[3] = q[0]; row[4] = q[1]; row[5] = q[2]; row[6] = q[3];
+    row[7] = lin.x; row[8] = lin.y; row[9] = lin.z; row[10] = ang.x; row[11] = ang.y; row[12] = ang.z;
+}
+template <class Store>
+PP_HD void write_body_states(const TAConsts& C, Store& st, float* rb) {
+    for (int i = 0; i < NL; i++) {
+        const int o = i * LINK_STRIDE;
+        M3 Rw = ldm3(st, o + F_RW);
+        write_body_row<Store>(rb + C.link[i].body * 13, Rw, ldv(st, o + F_PW), mul(Rw, ldv(st, o + F_V)), mul(Rw, ldv(st, o + F_W)));
+    }
+    for (int f = 0; f < PPENV_TA_NUM_FIXED; f++) {
+        const FixedC& F = C.fixed[f];
+        const int o = F.link * LINK_STRIDE;
+        M3 Rw = ldm3(st, o + F_RW);
+        V3 p, v;
+        point_state(st, F.link, ld3(F.xyz), p, v);
+        write_body_row<Store>(rb + F.body * 13, mul(Rw, ldm(F.rot)), p, v, mul(Rw, ldv(st, o + F_W)));
+    }
+}
+
+}  // namespace ta
+}  // namespace pp
+
+// ------------------------------------------------------------------ TAConsts from the model (host)
+namespace pp {
+namespace ta {
+inline bool make_ta_consts(const ppenv_config& scene, const ppenv_ta_model& m, TAConsts& C, const char** why) {
+    memset(&C, 0, sizeof C);
+    *why = "";
+    if (m.num_contacts < 0 || m.num_contacts > PPENV_TA_MAX_CONTACTS) { *why = "num_contacts out of range"; return false; }
+    if (scene.num_shapes != ModelG1TA::kShapes) { *why = "scene.num_shapes does not match the compiled shape set"; return false; }
+    int nc = 0;
+    for (int i = 0; i < NL; i++) {
+        const ppenv_ta_link& s = m.link[i];
+        LinkC& L = C.link[i];
+        if (i == 0 ? s.parent != -1 : (s.parent < 0 || s.parent >= i)) { *why = "links must list parents before children"; return false; }
+        if (i > 0 && (s.axis < 0 || s.axis > 2)) { *why = "joint axis must be 0, 1 or 2"; return false; }
+        if (!(s.mass > 0.f) || s.body < 0 || s.body >= PPENV_NUM_HUMANOID_BODIES) { *why = "link mass must be > 0 and body in [0, 40)"; return false; }
+        L.parent = s.parent; L.axis = s.axis; L.body = s.body;
+        for (int k = 0; k < 3; k++) { L.r[k] = s.origin_xyz[k]; L.mc[k] = s.mass * s.com[k]; }
+        for (int k = 0; k < 9; k++) L.R0[k] = s.origin_rot[k];
+        L.mass = s.mass;
+        const float cx = s.com[0], cy = s.com[1], cz = s.com[2], cc = cx * cx + cy * cy + cz * cz, mm = s.mass;
+        L.Io[0] = s.inertia[0] + mm * (cc - cx * cx); L.Io[1] = s.inertia[1] + mm * (cc - cy * cy); L.Io[2] = s.inertia[2] + mm * (cc - cz * cz);
+        L.Io[3] = s.inertia[3] - mm * cx * cy; L.Io[4] = s.inertia[4] - mm * cx * cz; L.Io[5] = s.inertia[5] - mm * cy * cz;
+        L.lo = s.lower; L.hi = s.upper; L.kp = s.kp; L.kd = s.kd; L.effort = s.effort; L.vlim = s.vel_limit; L.armature = s.armature;
+        L.cfirst = nc;
+        for (int k = 0; k < m.num_contacts; k++)
+            if (m.contact_link[k] == i) {
+                for (int t = 0; t < 3; t++) C.cpoint[nc][t] = m.contact_point[k][t];
+                nc++;
+            }
+        L.ccount = nc - L.cfirst;
+    }
+    if (nc != m.num_contacts) { *why = "a contact point names a link that does not exist"; return false; }
+    for (int f = 0; f < PPENV_TA_NUM_FIXED; f++) {
+        const ppenv_ta_fixed& s = m.fixed[f];
+        if (s.link < 0 || s.link >= NL || s.body < 0 || s.body >= PPENV_NUM_HUMANOID_BODIES) { *why = "welded body: link / body index out of range"; return false; }
+        C.fixed[f].body = s.body; C.fixed[f].link = s.link;
+        for (int k = 0; k < 3; k++) C.fixed[f].xyz[k] = s.xyz[k];
+        for (int k = 0; k < 9; k++) C.fixed[f].rot[k] = s.rot[k];
+    }
+    C.num_contacts = m.num_contacts; C.paddle_link = scene.paddle_link; C.bound_link = m.bound_link; C.num_shapes = scene.num_shapes;
+    if (C.paddle_link < 0 || C.paddle_link >= NL || C.bound_link < 0 || C.bound_link >= NL) { *why = "paddle_link / bound_link out of range"; return false; }
+    for (int s = 0; s < scene.num_shapes; s++) {
+        if (scene.shape[s].link < 0 || scene.shape[s].link >= NL) { *why = "scene.shape[].link must index the 28-link tree"; return false; }
+        if (scene.shape[s].radius != ModelG1TA::shape(s).radius) { *why = "scene.shape[].radius differs from the compiled shape set"; return false; }
+        C.shape_link[s] = scene.shape[s].link;
+        for (int k = 0; k < 3; k++) { C.shape_a[s][k] = scene.shape[s].a[k]; C.shape_b[s][k] = scene.shape[s].b[k]; }
+    }
+    for (int k = 0; k < 3; k++) { C.paddle_center[k] = scene.paddle_center[k]; C.paddle_normal[k] = scene.paddle_normal[k]; C.bound_center[k] = m.bound_center[k]; }
+    C.ground_z = m.ground_z; C.k_n = m.foot_stiffness; C.c_n = m.foot_damping; C.c_t = m.foot_tangent_damping; C.mu = m.foot_friction;
+    C.pen_max = m.contact_max_penetration; C.fade_depth = m.contact_fade_depth; C.fade_force = m.contact_fade_force;
+    if (!(C.fade_depth > 0.f) || !(C.fade_force > 0.f)) { *why = "contact_fade_depth / contact_fade_force must be positive"; return false; }
+    C.k_lim = m.limit_stiffness; C.c_lim = m.limit_damping; C.c_vlim = m.vel_limit_damping;
+    C.gravity_z = scene.gravity_z; C.substeps = scene.substeps; C.h = scene.dt / (float)scene.substeps; C.clip_actions = scene.clip_actions;
+    if (scene.substeps < 1 || scene.substeps > 16 || !(scene.dt > 0.f)) { *why = "dt / substeps out of range"; return false; }
+    return true;
+}
+}  // namespace ta
+}  // namespace pp

@@ -551,3 +551,269 @@ def initial_root_states(config):
     out[2, 0:3] = list(config.ball_init_pos)
     out[2, 3:7] = list(config.ball_init_quat)
     return out
+
+
+# =====================================================================================================================
+# 27-DoF variant (TA = tasks/humanoid_pingpong_3_actor_all_dof.py): model of the free-floating humanoid
+# =====================================================================================================================
+# UNVERIFIED physical data, like the arm tables above: g1_27dof.urdf (TA:470) is not in the reference; the numbers are
+# recalled from the public Unitree g1_29dof_rev_1_0.urdf (the 27-dof asset welds right_shoulder_yaw and right_elbow,
+# TA:1303-1311 lists 5 right-arm dofs).  Dof order = TA:1303-1311; rigid-body indices = pingpong_note.txt:33.
+TA_NUM_LINKS, TA_NUM_FIXED, TA_MAX_CONTACTS = 28, 12, 24
+
+
+def _leg(side):
+    s = 1.0 if side == "left" else -1.0
+    b0 = 2 if side == "left" else 9
+    ms = lambda lo, hi: (lo, hi) if side == "left" else (-hi, -lo)   # mirrored x / z axes flip the limit interval
+    return [
+        dict(name=f"{side}_hip_pitch_link", body=b0, xyz=(0.0, s * 0.064452, -0.1027), rpy=(0, 0, 0), axis=1, limits=(-2.5307, 2.8798),
+             mass=1.35, com=(0.002741, s * 0.047791, -0.02606), inertia=(0.00182, 0.00153, 0.00116), effort=88.0, vel=32.0),
+        dict(name=f"{side}_hip_roll_link", body=b0 + 1, xyz=(0.0, s * 0.052, -0.030465), rpy=(0, -0.1749, 0), axis=0, limits=ms(-0.5236, 2.9671),
+             mass=1.52, com=(0.029812, s * -0.001045, -0.087934), inertia=(0.00254, 0.00241, 0.00148), effort=88.0, vel=32.0),
+        dict(name=f"{side}_hip_yaw_link", body=b0 + 2, xyz=(0.025001, 0.0, -0.12412), rpy=(0, 0, 0), axis=2, limits=ms(-2.7576, 2.7576),
+             mass=1.702, com=(-0.057709, s * -0.010981, -0.15078), inertia=(0.00776, 0.00717, 0.00160), effort=88.0, vel=32.0),
+        dict(name=f"{side}_knee_link", body=b0 + 3, xyz=(-0.078273, s * 0.0021489, -0.17734), rpy=(0, 0.1749, 0), axis=1, limits=(-0.087267, 2.8798),
+             mass=1.932, com=(0.005457, s * 0.003964, -0.12074), inertia=(0.01139, 0.01127, 0.00146), effort=139.0, vel=20.0),
+        dict(name=f"{side}_ankle_pitch_link", body=b0 + 4, xyz=(0.0, s * -9.4445e-05, -0.30001), rpy=(0, 0, 0), axis=1, limits=(-0.87267, 0.5236),
+             mass=0.074, com=(-0.007269, 0.0, 0.011137), inertia=(8.4e-6, 1.89e-5, 1.26e-5), effort=50.0, vel=37.0),
+        dict(name=f"{side}_ankle_roll_link", body=b0 + 5, xyz=(0.0, 0.0, -0.017558), rpy=(0, 0, 0), axis=0, limits=ms(-0.2618, 0.2618),
+             mass=0.608, com=(0.026505, 0.0, -0.016425), inertia=(0.00022, 0.00161, 0.00167), effort=50.0, vel=37.0),
+    ]
+
+
+G1_WAIST = [
+    dict(name="waist_yaw_link", body=15, xyz=(0.0, 0.0, 0.0), rpy=(0, 0, 0), axis=2, limits=(-2.618, 2.618),
+         mass=0.214, com=(0.003494, 0.000233, 0.018034), inertia=(1.6e-4, 1.2e-4, 1.9e-4), effort=88.0, vel=32.0),
+    dict(name="waist_roll_link", body=16, xyz=PELVIS_TO_TORSO, rpy=(0, 0, 0), axis=0, limits=(-0.52, 0.52),
+         mass=0.086, com=(0.0, 0.0, 0.0), inertia=(7.0e-6, 6.9e-6, 3.0e-6), effort=50.0, vel=37.0),
+    dict(name="torso_link", body=17, xyz=(0.0, 0.0, 0.0), rpy=(0, 0, 0), axis=1, limits=(-0.52, 0.52),
+         mass=7.818, com=(0.00203158, 0.000339683, 0.184568), inertia=(0.1216, 0.1127, 0.0327), effort=50.0, vel=37.0),
+]
+G1_PELVIS = dict(name="pelvis", body=0, mass=3.813, com=(0.0, 0.0, -0.07605), inertia=(0.0106, 0.0093, 0.0080))
+# welded to the torso (bodies 18, 19, 20, 29, 30): only the head and the lidar carry noticeable mass
+G1_TORSO_WELDED = [
+    dict(name="d435_link", body=18, xyz=(0.0576235, 0.01753, 0.42987), mass=0.0),
+    dict(name="head_link", body=19, xyz=(0.0039635, 0.0, 0.40), mass=1.036, com=(0.005, 0.0, 0.02), inertia=(0.0045, 0.0048, 0.0030)),
+    dict(name="imu_in_torso", body=20, xyz=(-0.03959, -0.00224, 0.14792), mass=0.0),
+    dict(name="logo_link", body=29, xyz=(0.0039635, 0.0, 0.10), mass=0.0),
+    dict(name="mid360_link", body=30, xyz=(0.0002835, 0.00003, 0.41618), mass=0.265, com=(0.0, 0.0, 0.02), inertia=(1.2e-4, 1.2e-4, 1.6e-4)),
+]
+G1_PELVIS_WELDED = [dict(name="imu_in_pelvis", body=1, xyz=(0.04525, 0.0, -0.08339), mass=0.0),
+                    dict(name="pelvis_contour_link", body=8, xyz=(0.0, 0.0, 0.0), mass=0.001, com=(0.0, 0.0, 0.0), inertia=(1e-7, 1e-7, 1e-7))]
+# 27 gains, TA:757-772 (the right ankle-pitch 80 vs the left 20 is as written there); Kd = Kp / 40, TA:774
+TA_P_GAINS = [80.0, 80.0, 80.0, 160.0, 20.0, 20.0, 80.0, 80.0, 80.0, 160.0, 80.0, 20.0, 80.0, 80.0, 80.0,
+              20.0, 20.0, 20.0, 20.0, 20.0, 5.0, 5.0, 20.0, 20.0, 20.0, 5.0, 5.0]
+# sole corners in the ankle-roll frame; joint armature (reflected rotor inertia) — named parameters of
+# the build's physics specification, see DESIGN.md "TA physics"
+TA_FOOT = dict(points=[(-0.05, -0.03, -0.035), (-0.05, 0.03, -0.035), (0.12, -0.03, -0.035), (0.12, 0.03, -0.035)],
+               stiffness=1.0e5, damping=1.0e3, tangent_damping=2.0e3, max_penetration=0.02,
+               fade_depth=2.0e-3, fade_force=20.0)
+# further (link, point) pairs tested against the ground, so that a fallen humanoid lies on the plane instead of sinking
+# through it: knees, pelvis, chest / back, head top, shoulders, elbows, hands (link indices of the 28-link tree)
+TA_BODY_CONTACTS = [(4, (0.03, 0.0, 0.0)), (10, (0.03, 0.0, 0.0)), (0, (0.07, 0.0, -0.08)), (0, (-0.09, 0.0, -0.08)),
+                    (15, (0.10, 0.0, 0.25)), (15, (-0.10, 0.0, 0.25)), (15, (0.0, 0.0, 0.50)),
+                    (16, (0.0, 0.05, 0.0)), (23, (0.0, -0.05, 0.0)), (19, (0.0, 0.0, -0.02)), (24, (0.0158, -0.0062, -0.1837)),
+                    (22, (0.11, 0.0, 0.0)), (27, (0.11, 0.0, 0.0))]
+TA_ARMATURE = 0.01            # every joint: without it a saturated drive spins a 50-gram wrist link up by 10^3 rad/s in one substep
+TA_JOINT_LIMITS = dict(stiffness=2000.0, damping=20.0, vel_damping=50.0)   # N m / rad, N m s / rad, N m s / rad
+# PlaneParams.distance = -0.21 (TA:403) with normal +z is the plane z = 0.21: the pelvis is created at z = 1.0 (TA:578)
+# and the G1's soles are 0.787 m below it with straight legs, i.e. at z = 0.213 — the robot is spawned standing on it.
+TA_GROUND_Z = 0.21
+
+
+def _mirror_arm(spec):
+    """left-arm link from the right-arm table: reflect through the xz-plane."""
+    d = dict(spec)
+    d["name"] = spec["name"].replace("right", "left")
+    d["body"] = spec["body"] - 10
+    x, y, z = spec["xyz"]
+    d["xyz"] = (x, -y, z)
+    r, p, yw = spec["rpy"]
+    d["rpy"] = (-r, p, -yw)
+    cx, cy, cz = spec["com"]
+    d["com"] = (cx, -cy, cz)
+    lo, hi = spec["limits"]
+    d["limits"] = (lo, hi) if spec["axis"] == 1 else (-hi, -lo)
+    return d
+
+
+def _diag_parts(spec, offset=(0.0, 0.0, 0.0)):
+    return (spec["mass"], np.asarray(offset) + np.asarray(spec.get("com", (0, 0, 0))), np.diag(spec.get("inertia", (0, 0, 0))), np.eye(3))
+
+
+class TALink(C.Structure):
+    _fields_ = [("parent", C.c_int32), ("axis", C.c_int32), ("body", C.c_int32), ("origin_xyz", C.c_float * 3), ("origin_rot", C.c_float * 9),
+                ("mass", C.c_float), ("com", C.c_float * 3), ("inertia", C.c_float * 6), ("lower", C.c_float), ("upper", C.c_float),
+                ("kp", C.c_float), ("kd", C.c_float), ("effort", C.c_float), ("vel_limit", C.c_float), ("armature", C.c_float)]
+
+
+class TAFixed(C.Structure):
+    _fields_ = [("body", C.c_int32), ("link", C.c_int32), ("xyz", C.c_float * 3), ("rot", C.c_float * 9)]
+
+
+class TAModel(C.Structure):
+    _fields_ = [("link", TALink * TA_NUM_LINKS), ("fixed", TAFixed * TA_NUM_FIXED), ("num_contacts", C.c_int32),
+                ("contact_link", C.c_int32 * TA_MAX_CONTACTS), ("contact_point", (C.c_float * 3) * TA_MAX_CONTACTS),
+                ("ground_z", C.c_float), ("foot_stiffness", C.c_float),
+                ("foot_damping", C.c_float), ("foot_tangent_damping", C.c_float), ("foot_friction", C.c_float),
+                ("contact_fade_depth", C.c_float), ("contact_fade_force", C.c_float), ("contact_max_penetration", C.c_float), ("limit_stiffness", C.c_float), ("limit_damping", C.c_float),
+                ("vel_limit_damping", C.c_float), ("bound_link", C.c_int32), ("bound_center", C.c_float * 3)]
+
+
+def build_ta_model():
+    """ppenv_ta_model: the 28-link tree (pelvis + 27 dofs in the order of TA:1303-1311) with welded bodies merged in."""
+    m = TAModel()
+    right_arm = G1_RIGHT_ARM
+    left_arm = [_mirror_arm(s) for s in right_arm]
+    hand_r, hand_l = G1_HAND, dict(G1_HAND, xyz=(G1_HAND["xyz"][0], -G1_HAND["xyz"][1], G1_HAND["xyz"][2]),
+                                   com=(G1_HAND["com"][0], -G1_HAND["com"][1], G1_HAND["com"][2]))
+    # (spec, parent link, welded parts [(mass, com, I, R)] in the link frame, origin override)
+    links = [(None, -1, [], None)]
+    for s in _leg("left"):
+        links.append((s, len(links) - 1 if len(links) > 1 else 0, [], None))
+    first_right = len(links)
+    for k, s in enumerate(_leg("right")):
+        links.append((s, 0 if k == 0 else len(links) - 1, [], None))
+    for k, s in enumerate(G1_WAIST):
+        welded = [_diag_parts(w, w["xyz"]) for w in G1_TORSO_WELDED if w["mass"] > 0] if s["name"] == "torso_link" else []
+        links.append((s, 0 if k == 0 else len(links) - 1, welded, None))
+    torso = len(links) - 1
+    for k, s in enumerate(left_arm):
+        welded = [_diag_parts(hand_l, hand_l["xyz"])] if k == 6 else []
+        links.append((s, torso if k == 0 else len(links) - 1, welded, None))
+    # right arm: shoulder pitch, shoulder roll (+ welded shoulder-yaw and elbow links), wrist roll / pitch / yaw (+ hand, paddle)
+    yaw_o = np.asarray(right_arm[2]["xyz"])
+    elbow_o = yaw_o + np.asarray(right_arm[3]["xyz"])
+    wrist_o = elbow_o + np.asarray(right_arm[4]["xyz"])
+    links.append((right_arm[0], torso, [], None))
+    links.append((right_arm[1], len(links) - 1, [_diag_parts(right_arm[2], yaw_o), _diag_parts(right_arm[3], elbow_o)], None))
+    links.append((right_arm[4], len(links) - 1, [], wrist_o))
+    links.append((right_arm[5], len(links) - 1, [], None))
+    hand_o = np.asarray(hand_r["xyz"])
+    pad_o = hand_o + np.asarray(PADDLE["xyz_from_hand"])
+    pm, pr, pn = PADDLE["mass"], PADDLE["radius"], np.asarray(PADDLE["normal"], dtype=np.float64)
+    i_disc = 0.25 * pm * pr * pr * np.eye(3) + 0.25 * pm * pr * pr * np.outer(pn, pn)
+    links.append((right_arm[6], len(links) - 1, [_diag_parts(hand_r, hand_o), (pm, pad_o, i_disc, np.eye(3))], None))
+    assert len(links) == TA_NUM_LINKS and first_right == 7 and torso == 15
+
+    for i, (spec, parent, welded, origin) in enumerate(links):
+        L = m.link[i]
+        L.parent = parent
+        if spec is None:   # pelvis
+            parts = [_diag_parts(G1_PELVIS)] + [_diag_parts(w, w["xyz"]) for w in G1_PELVIS_WELDED if w["mass"] > 0]
+            L.axis, L.body = 0, 0
+            _set(L.origin_xyz, (0, 0, 0))
+            _set(L.origin_rot, np.eye(3).reshape(-1))
+            L.lower = L.upper = L.kp = L.kd = L.effort = L.vel_limit = L.armature = 0.0
+        else:
+            parts = [_diag_parts(spec)] + welded
+            L.axis, L.body = spec["axis"], spec["body"]
+            _set(L.origin_xyz, origin if origin is not None else spec["xyz"])
+            _set(L.origin_rot, rpy_to_rot(*spec["rpy"]).reshape(-1))
+            lo, hi = spec["limits"]
+            L.lower, L.upper = min(lo, hi), max(lo, hi)              # TA:719-725 swaps inverted limits
+            L.kp = TA_P_GAINS[i - 1]
+            L.kd = TA_P_GAINS[i - 1] / 40.0                          # TA:774
+            L.effort, L.vel_limit = spec["effort"], spec["vel"]
+            L.armature = TA_ARMATURE
+        mass, com, inertia = composite_inertial(parts)
+        L.mass = mass
+        _set(L.com, com)
+        _set(L.inertia, _inertia_vec(inertia))
+
+    fixed = [(w["body"], 0, w["xyz"]) for w in G1_PELVIS_WELDED] + [(w["body"], torso, w["xyz"]) for w in G1_TORSO_WELDED] + \
+            [(28, 22, hand_l["xyz"]), (33, 24, yaw_o), (34, 24, elbow_o), (38, 27, hand_o), (39, 27, pad_o)]
+    assert len(fixed) == TA_NUM_FIXED
+    for k, (body, link, xyz) in enumerate(sorted(fixed)):
+        f = m.fixed[k]
+        f.body, f.link = body, link
+        _set(f.xyz, xyz)
+        _set(f.rot, np.eye(3).reshape(-1))
+    contacts = [(6, p) for p in TA_FOOT["points"]] + [(12, p) for p in TA_FOOT["points"]] + TA_BODY_CONTACTS
+    assert len(contacts) <= TA_MAX_CONTACTS
+    m.num_contacts = len(contacts)
+    for k, (link, pnt) in enumerate(contacts):
+        m.contact_link[k] = link
+        _set(m.contact_point[k], pnt)
+    m.ground_z = TA_GROUND_Z
+    m.foot_stiffness, m.foot_damping, m.foot_tangent_damping = TA_FOOT["stiffness"], TA_FOOT["damping"], TA_FOOT["tangent_damping"]
+    m.contact_max_penetration = TA_FOOT["max_penetration"]
+    m.contact_fade_depth, m.contact_fade_force = TA_FOOT["fade_depth"], TA_FOOT["fade_force"]
+    m.limit_stiffness, m.limit_damping, m.vel_limit_damping = TA_JOINT_LIMITS["stiffness"], TA_JOINT_LIMITS["damping"], TA_JOINT_LIMITS["vel_damping"]
+    m.foot_friction = 0.5 * (1.0 + 0.5)      # PhysX average of plane 1.0 (TA yaml:78) and humanoid shapes 0.5 (TA:588)
+    m.bound_link = torso
+    _set(m.bound_center, right_arm[0]["xyz"])
+    return m
+
+
+TASK_CFGS["TA"] = dict(
+    name="HumanoidPingpongTiltNESSparse27DOFG1",
+    env=dict(TASK_CFGS["TN"]["env"], numEnvs=2048, episodeLength=160, alphaVelocityReward=3000.0, powerCoefficient=0.002),
+    sim=dict(_SIM_DEFAULT),                                                                 # 27DOFG1.yaml:88-90: dt 0.0083, substeps 2
+    scene=dict(TASK_CFGS["TN"]["scene"],
+               table_material=dict(restitution=1.5, friction=0.2),                         # TA:636-638
+               ball_pos=(2.9, -0.2, 1.0), ball_material=dict(restitution=1.5, friction=0.2),   # TA:678-680,686-687
+               serve_speed=(5.0, 5.4), serve_tilt=(-8.0, 3.0), serve_tilt_z=(14.0, 24.0)),  # TA:129-131
+)
+
+
+def build_ta_scene(num_envs, device_id=0):
+    """The ppenv_config part of the 27-DoF scene (ball, table, net, contact scalars, dt ...) with the humanoid's ball-collision
+    shapes re-attached to links of the 28-link tree (ppenv_ta_model)."""
+    c = build_config("TN", cfg=default_task_cfg("TA"), num_envs=num_envs, device_id=device_id)
+    ra = G1_RIGHT_ARM
+    yaw_o = np.asarray(ra[2]["xyz"])
+    elbow_o = yaw_o + np.asarray(ra[3]["xyz"])
+    c.ground_z = TA_GROUND_Z                       # the ball lands on the same plane as the feet
+    c.paddle_link = 27
+    re_attach = {6: (27, np.zeros(3)), 3: (24, elbow_o), 1: (24, np.zeros(3))}   # 7-dof chain link -> (tree link, frame offset)
+    statics = {3: (15, (0.0, 0.0, 0.05), (0.0, 0.0, 0.30)), 4: (0, (0.0, 0.0, -0.02), (0.0, 0.0, -0.02)), 5: (15, (0.0, 0.0, 0.45), (0.0, 0.0, 0.45))}
+    for k in range(c.num_shapes):
+        sh = c.shape[k]
+        if sh.link >= 0:
+            link, off = re_attach[sh.link]
+            _set(sh.a, np.asarray(list(sh.a)) + off)
+            _set(sh.b, np.asarray(list(sh.b)) + off)
+            sh.link = link
+        else:   # torso / pelvis / head: static in the fixed-base scenes, on their links here
+            sh.link = statics[k][0]
+            _set(sh.a, statics[k][1])
+            _set(sh.b, statics[k][2])
+    return c
+
+
+def _mix64(z):
+    m = 0xFFFFFFFFFFFFFFFF
+    z &= m
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & m
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & m
+    z ^= z >> 31
+    return z
+
+
+def ta_reset_draws(params, env_ids, episodes):
+    """Host restatement of the 27-DoF task's reset draws (ta_post_physics_kernel, TA:976-979 + 346-377): for each (env,
+    episode) the five values ball y, ball z, vx, vy, vz.  Used to lay out the state at creation (episode 0); resets during
+    stepping are drawn on the device by the same keyed function."""
+    import torch
+    m = 0xFFFFFFFFFFFFFFFF
+    out = torch.zeros(len(env_ids), 5, dtype=torch.float32)
+    f32 = np.float32
+    for row, (i, ep) in enumerate(zip([int(x) for x in env_ids], [int(x) for x in episodes])):
+        gid = params.env_id_offset + i
+        u = []
+        for k in range(5):
+            s = _mix64(params.seed + 0x9E3779B97F4A7C15 * (gid + 1))
+            x = _mix64(s + 0x9E3779B97F4A7C15 * (ep * 8 + k + 1))
+            u.append(f32(x >> 40) * f32(1.0 / 16777216.0))
+        deg = f32(0.017453292519943295)
+        y = f32(params.ball_y_lo) + f32(params.ball_y_hi - params.ball_y_lo) * u[0]
+        z = f32(params.ball_z_lo) + f32(params.ball_z_hi - params.ball_z_lo) * u[1]
+        speed = f32(params.serve_speed_lo) + f32(params.serve_speed_hi - params.serve_speed_lo) * u[2]
+        a = (f32(params.serve_tilt_lo_deg) + f32(params.serve_tilt_hi_deg - params.serve_tilt_lo_deg) * u[3]) * deg
+        az = (f32(params.serve_tilt_z_lo_deg) + f32(params.serve_tilt_z_hi_deg - params.serve_tilt_z_lo_deg) * u[4]) * deg
+        out[row] = torch.tensor([y, z, -speed * math.cos(a) * math.cos(az), speed * math.sin(a) * math.cos(az), speed * math.sin(az)])
+    return out

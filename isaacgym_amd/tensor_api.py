@@ -3,7 +3,8 @@
 `TAState.post_physics_step` is the drop-in for the reference's post_physics_step (TA:1145-1192) on the
 simulator tensors the task already wraps: reward (TA:1440-1690), masked reset (TA:965-1028) and the
 313-wide observation (TA:867-904) in one launch (+ one tiny launch for the global count-flag clear).
-The rigid-body step of this variant is not built; physics must come from the caller.
+`TASim` is the rigid-body step of this variant (ppenv_ta_simulate: the free-floating 27-DoF humanoid, its ground contacts
+and the ball) on the same tensors; `TAEnv` chains the two into the task's VecTask step.
 """
 import ctypes as C
 
@@ -45,3 +46,87 @@ class TAState:
             self.reset_buf.data_ptr(), self._any_reset.data_ptr(), stream))
         if ov is not None:
             torch.cuda.current_stream(self.device).synchronize()   # keep `ov` alive until the kernel has read it
+
+
+class TASim:
+    """pre_physics_step + gym.simulate + refresh for the 27-DoF task (TA:1124-1143, 1150) on Isaac-Gym-layout tensors."""
+
+    def __init__(self, num_envs, device="cuda:0", scene_cfg=None, model=None):
+        self.L = _lib.lib()
+        self.device = torch.device(device)
+        self.num_envs = int(num_envs)
+        self.scene = scene_cfg if scene_cfg is not None else scene.build_ta_scene(self.num_envs, device_id=self.device.index or 0)
+        self.model = model if model is not None else scene.build_ta_model()
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.ppenv_ta_sim_create(C.byref(self.scene), C.byref(self.model), self._stream(), C.byref(self.h)))
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self):
+        if getattr(self, "h", None):
+            torch.cuda.synchronize(self.device)
+            self.L.ppenv_ta_sim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, t, numel):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device and t.numel() == numel
+
+    def simulate(self, actions, root_states, dof_states, rb_states, dof_force, pre_ball_vx):
+        n = self.num_envs
+        for t, k in ((actions, n * 27), (root_states, n * 39), (dof_states, n * 54), (rb_states, n * 42 * 13), (dof_force, n * 27), (pre_ball_vx, n)):
+            self._check(t, k)
+        _lib.check(self.L.ppenv_ta_simulate(self.h, n, actions.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(), rb_states.data_ptr(),
+                                            dof_force.data_ptr(), pre_ball_vx.data_ptr(), self._stream()))
+
+    def forward_kinematics(self, root_states, dof_states, rb_states):
+        n = self.num_envs
+        for t, k in ((root_states, n * 39), (dof_states, n * 54), (rb_states, n * 42 * 13)):
+            self._check(t, k)
+        _lib.check(self.L.ppenv_ta_forward_kinematics(self.h, n, root_states.data_ptr(), dof_states.data_ptr(), rb_states.data_ptr(), self._stream()))
+
+
+class TAEnv:
+    """HumanoidPingpongTiltNESSparse27DOF (tasks/humanoid_pingpong_3_actor_all_dof.py:65) as a native task: the tensors the
+    reference class wraps (TA:161-251) live here, `step` = pre_physics_step + simulate (ppenv_ta_simulate) + post_physics_step
+    (ppenv_ta_post_physics_step) — two launches and the tiny count-flag clear.  Surface: obs_buf [N,313], rew_buf, reset_buf,
+    progress_buf, 27 actions."""
+
+    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_offset=0, env=None):
+        self.device = torch.device(device)
+        n = self.num_envs = int(num_envs)
+        self.num_obs, self.num_actions, self.num_agents = scene.TA_NUM_OBS, scene.TA_NUM_DOF, 1
+        self.params = scene.build_ta_params(n, env=env, seed=seed, env_id_offset=env_id_offset)
+        self.sim = TASim(n, device=self.device)
+        self.state = TAState(self.params, device=self.device)
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
+        self.root_states, self.dof_states = z(n, 3, 13), z(n, 27, 2)          # TA:187-193, 237-240
+        self.rb_states, self.dof_force_tensor, self.pre_ball_vx = z(n, 42, 13), z(n, 27), z(n)
+        init = torch.tensor([[self.params.init_root[a][k] for k in range(7)] for a in range(3)], dtype=torch.float32, device=self.device)
+        self.root_states[:, :, 0:7] = init
+        # creation = episode 0: the serve and ball position every env starts with come from the same keyed draws a reset uses
+        ov = scene.ta_reset_draws(self.params, torch.arange(n), torch.zeros(n, dtype=torch.int64))
+        self.root_states[:, 2, 1:3] = ov[:, 0:2].to(self.device)
+        self.root_states[:, 2, 7:10] = ov[:, 2:5].to(self.device)
+        self.sim.forward_kinematics(self.root_states, self.dof_states, self.rb_states)
+        self.initial_rb_states = self.rb_states.clone()                       # TA:1152 initial_body_states
+        self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf = self.state.obs_buf, self.state.rew_buf, self.state.reset_buf, self.state.progress_buf
+        self.reset_buf.fill_(1)   # upstream VecTask.allocate_buffers
+
+    def step(self, actions):
+        if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        self.sim.simulate(actions, self.root_states, self.dof_states, self.rb_states, self.dof_force_tensor, self.pre_ball_vx)
+        self.state.post_physics_step(self.rb_states, self.initial_rb_states, self.root_states, self.dof_states, self.dof_force_tensor, self.pre_ball_vx)
+        return {"obs": self.obs_buf}, self.rew_buf, self.reset_buf, {}
+
+    def close(self):
+        self.sim.close()

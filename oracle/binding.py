@@ -259,3 +259,31 @@ def t4_rewards(params, rb, root, dof, dof_force, pre_vx, progress, flags1, flags
                      progress.ctypes.data, flags1.ctypes.data, flags2.ctypes.data, f1o.ctypes.data, f2o.ctypes.data, rew1.ctypes.data,
                      rew2.ctypes.data, reset1.ctypes.data, reset2.ctypes.data)
     return rew1, rew2, reset1, reset2, f1o, f2o
+
+
+# ---- 27-DoF variant: the rigid-body step ------------------------------------------------------------
+def ta_simulate(scene_cfg, model, actions, root, dof, threads=1):
+    """One pre_physics_step + simulate + refresh of the oracle.  root [N,3,13] and dof [N,27,2] are updated in place;
+    returns rb_states [N,42,13], dof_force [N,27], pre_ball_vx [N]."""
+    L = lib()
+    n = root.shape[0]
+    for a in (actions, root, dof):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    rb = np.zeros((n, 42, 13), np.float32)
+    frc = np.zeros((n, 27), np.float32)
+    pvx = np.zeros(n, np.float32)
+    L.ppo_ta_simulate.argtypes = [C.POINTER(scene.Config), C.POINTER(scene.TAModel), C.c_int, C.c_int] + [C.c_void_p] * 6
+    L.ppo_ta_simulate.restype = None
+    L.ppo_ta_simulate(C.byref(scene_cfg), C.byref(model), n, threads, actions.ctypes.data, root.ctypes.data, dof.ctypes.data,
+                      rb.ctypes.data, frc.ctypes.data, pvx.ctypes.data)
+    return rb, frc, pvx
+
+
+def ta_forward_kinematics(model, root, dof):
+    L = lib()
+    n = root.shape[0]
+    rb = np.zeros((n, 42, 13), np.float32)
+    L.ppo_ta_forward_kinematics.argtypes = [C.POINTER(scene.TAModel), C.c_int] + [C.c_void_p] * 3
+    L.ppo_ta_forward_kinematics.restype = None
+    L.ppo_ta_forward_kinematics(C.byref(model), n, root.ctypes.data, dof.ctypes.data, rb.ctypes.data)
+    return rb

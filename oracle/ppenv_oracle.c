@@ -401,7 +401,7 @@ static void arm_geometry(const ppenv_config* c, const arm_fk* k, arm_geom* g) { 
 /* One substep of the ball.  The arm's shapes move linearly from their pose at the START of the substep with
  * the velocities they have there (contacts are generated from start-of-step poses, as PhysX does); within the
  * substep the ball and the arm therefore do not depend on each other. */
-static void ball_substep_n(const ppenv_config* c, ball_t* b, double quat[4], int narms, const arm_geom* const* garr, double h) {
+static void ball_substep_nb(const ppenv_config* c, ball_t* b, double quat[4], int narms, const arm_geom* const* garr, const v3* bounds, double h) {
     int M = c->ball_substeps;
     double hb = h / M;
     for (int m = 0; m < M; m++) {
@@ -418,7 +418,8 @@ static void ball_substep_n(const ppenv_config* c, ball_t* b, double quat[4], int
             const arm_geom* g = garr[arm];
             const float* bound = arm == 0 ? c->humanoid_bound_center : c->humanoid2_bound_center;
             const ppenv_shape* shapes = arm == 0 ? c->shape : c->shape2;
-            if (!(vnorm(vsub(b->p, vf(bound))) < c->humanoid_bound_radius)) continue;
+            v3 bc = bounds ? bounds[arm] : vf(bound);   /* the 27-DoF humanoid's bound follows its torso */
+            if (!(vnorm(vsub(b->p, bc)) < c->humanoid_bound_radius)) continue;
             v3 cc = vadd(g->pc, vscale(g->vpc, t));
             v3 nn = vadd(g->pn, vscale(g->pnd, t));
             nn = vscale(nn, 1.0 / vnorm(nn));
@@ -442,6 +443,9 @@ static void ball_substep_n(const ppenv_config* c, ball_t* b, double quat[4], int
     quat[0] = x / nrm; quat[1] = y / nrm; quat[2] = z / nrm; quat[3] = w / nrm;
 }
 
+static void ball_substep_n(const ppenv_config* c, ball_t* b, double quat[4], int narms, const arm_geom* const* garr, double h) {
+    ball_substep_nb(c, b, quat, narms, garr, NULL, h);
+}
 static void ball_substep(const ppenv_config* c, ball_t* b, double quat[4], const arm_geom* g, double h) {
     ball_substep_n(c, b, quat, 1, &g, h);
 }
@@ -1312,4 +1316,399 @@ static void step_env_t4(ppo_env* e, int i, const float* actions) {
         compute_obs(bs[a], &qf[a * ND], &qdf[a * ND], ballf, &e->obs[((size_t)i * 2 + a) * PPENV_NUM_OBS]);
     }
     e->rew[(size_t)i * 2] = rew1; e->rew[(size_t)i * 2 + 1] = rew2;
+}
+
+/* ================================================================================================
+ * 27-DoF variant: the rigid-body step (ppenv_ta_simulate).  PARITY UNPINNED (Isaac Gym / PhysX is closed and absent, the
+ * g1_27dof.urdf asset TA:470 too): this restates the build's own specification, DESIGN.md "TA physics":
+ *   - free-floating 28-link tree, generalised velocity nu = [omega_b, v_b (base twist, base coordinates), qd]
+ *   - gravity as a force; PD drives as for the arm (explicit test against the effort limit, else implicit)
+ *   - feet: penalty contacts at the sole corners, active while penetrating and pushing; normal spring-damper and, while
+ *     tangential damper (coefficient capped at mu f_n / |v_t|: Coulomb) integrated implicitly: f(v+) ~ f(v) - h D a with a
+ *     the link's spatial acceleration, i.e. h J^T D J is added to the link's inertia in the inertia term
+ *   - semi-implicit Euler; the base in world coordinates (classical acceleration R (a + omega x v))
+ *   - the ball against the humanoid's shapes exactly as in the 3-actor scenes (start-of-substep geometry)
+ * Algorithm here: inertia matrix and bias by recursive Newton-Euler sweeps + dense 33x33 solve in fp64 (the kernel runs the
+ * floating-base articulated-body algorithm in fp32).
+ * ================================================================================================ */
+#define TL PPENV_TA_NUM_LINKS
+#define TNV (6 + PPENV_TA_NUM_DOF)
+typedef struct { double a[6]; } sv6;                 /* spatial vector, angular part first, link coordinates */
+typedef struct { double m[6][6]; } sm6;
+typedef struct {
+    m3 E[TL];          /* child -> parent rotation */
+    v3 r[TL];          /* child origin in the parent frame */
+    m3 Rw[TL]; v3 pw[TL];
+    sv6 v[TL];         /* link twist, link coordinates */
+    sv6 c[TL];         /* velocity-product acceleration v x S qd */
+} ta_kin;
+
+static sv6 sv_zero(void) { sv6 z; memset(&z, 0, sizeof z); return z; }
+static v3 sv_ang(const sv6* s) { return V(s->a[0], s->a[1], s->a[2]); }
+static v3 sv_lin(const sv6* s) { return V(s->a[3], s->a[4], s->a[5]); }
+static sv6 sv_make(v3 a, v3 l) { sv6 s = {{a.x, a.y, a.z, l.x, l.y, l.z}}; return s; }
+/* motion vector parent -> child coordinates */
+static sv6 xm(const m3* E, v3 r, const sv6* vp) {
+    m3 Et = mt(E);
+    v3 w = sv_ang(vp), l = sv_lin(vp);
+    return sv_make(mv(&Et, w), mv(&Et, vadd(l, vcross(w, r))));
+}
+/* force vector child -> parent coordinates */
+static sv6 xf(const m3* E, v3 r, const sv6* fc) {
+    v3 n = mv(E, sv_ang(fc)), f = mv(E, sv_lin(fc));
+    return sv_make(vadd(n, vcross(r, f)), f);
+}
+static sm6 spatial_inertia(double mass, const float* com, const float* in6) {
+    sm6 I; memset(&I, 0, sizeof I);
+    double c[3] = {com[0], com[1], com[2]};
+    double Ic[3][3] = {{in6[0], in6[3], in6[4]}, {in6[3], in6[1], in6[5]}, {in6[4], in6[5], in6[2]}};
+    double cx[3][3] = {{0, -c[2], c[1]}, {c[2], 0, -c[0]}, {-c[1], c[0], 0}};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double cc = 0;
+            for (int k = 0; k < 3; k++) cc += cx[i][k] * cx[j][k];           /* c^ c^T */
+            I.m[i][j] = Ic[i][j] + mass * cc;
+            I.m[i][3 + j] = mass * cx[i][j];
+            I.m[3 + i][j] = mass * cx[j][i];
+        }
+    for (int i = 0; i < 3; i++) I.m[3 + i][3 + i] = mass;
+    return I;
+}
+static sv6 sm_mul(const sm6* I, const sv6* v) {
+    sv6 r;
+    for (int i = 0; i < 6; i++) { double s = 0; for (int j = 0; j < 6; j++) s += I->m[i][j] * v->a[j]; r.a[i] = s; }
+    return r;
+}
+/* v x* f */
+static sv6 crf(const sv6* v, const sv6* f) {
+    v3 w = sv_ang(v), l = sv_lin(v), n = sv_ang(f), ff = sv_lin(f);
+    return sv_make(vadd(vcross(w, n), vcross(l, ff)), vcross(w, ff));
+}
+/* v x m */
+static sv6 crm(const sv6* v, const sv6* m) {
+    v3 w = sv_ang(v), l = sv_lin(v), mw = sv_ang(m), ml = sv_lin(m);
+    return sv_make(vcross(w, mw), vadd(vcross(w, ml), vcross(l, mw)));
+}
+
+/* base: position, xyzw quaternion, linear and angular velocity in world coordinates (the root_states row layout) */
+static void ta_kinematics_d(const ppenv_ta_model* M, const double* pos, const double* quat, const double* vw, const double* ww,
+                            const double* q, const double* qd, ta_kin* k) {
+    double x = quat[0], y = quat[1], z = quat[2], w = quat[3];
+    m3 R0 = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+              2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+    m3 R0t = mt(&R0);
+    k->Rw[0] = R0; k->pw[0] = V(pos[0], pos[1], pos[2]);
+    k->v[0] = sv_make(mv(&R0t, V(ww[0], ww[1], ww[2])), mv(&R0t, V(vw[0], vw[1], vw[2])));
+    k->c[0] = sv_zero();
+    for (int i = 1; i < TL; i++) {
+        const ppenv_ta_link* L = &M->link[i];
+        int p = L->parent;
+        m3 R0j = mf(L->origin_rot), Rq = axis_rot(L->axis, q[i - 1]);
+        k->E[i] = mm(&R0j, &Rq);
+        k->r[i] = vf(L->origin_xyz);
+        k->Rw[i] = mm(&k->Rw[p], &k->E[i]);
+        k->pw[i] = vadd(k->pw[p], mv(&k->Rw[p], k->r[i]));
+        sv6 vj = sv_zero();
+        vj.a[L->axis] = qd[i - 1];
+        sv6 vp = xm(&k->E[i], k->r[i], &k->v[p]);
+        for (int t = 0; t < 6; t++) k->v[i].a[t] = vp.a[t] + vj.a[t];
+        k->c[i] = crm(&k->v[i], &vj);
+    }
+}
+static void ta_kinematics(const ppenv_ta_model* M, const float* root /*13*/, const double* q, const double* qd, ta_kin* k) {
+    double pos[3] = {root[0], root[1], root[2]}, quat[4] = {root[3], root[4], root[5], root[6]};
+    double vw[3] = {root[7], root[8], root[9]}, ww[3] = {root[10], root[11], root[12]};
+    ta_kinematics_d(M, pos, quat, vw, ww, q, qd, k);
+}
+
+/* Recursive Newton-Euler over the tree.  a0: base spatial acceleration; qdd [27].  The inertia term uses I + dI (implicit
+ * contact dampers); use_vel adds the velocity products and -fext.  Returns the base force and the joint torques. */
+static void ta_rnea(const ppenv_ta_model* M, const ta_kin* k, const sm6* I, const sm6* dI, const sv6* fext, const sv6* a0,
+                    const double* qdd, int use_vel, sv6* f0, double* tau) {
+    sv6 a[TL], f[TL];
+    a[0] = *a0;
+    for (int i = 0; i < TL; i++) {
+        if (i > 0) {
+            const ppenv_ta_link* L = &M->link[i];
+            a[i] = xm(&k->E[i], k->r[i], &a[L->parent]);
+            a[i].a[L->axis] += qdd[i - 1];
+            if (use_vel) for (int t = 0; t < 6; t++) a[i].a[t] += k->c[i].a[t];
+        }
+        sm6 It = I[i];
+        for (int r = 0; r < 6; r++) for (int cidx = 0; cidx < 6; cidx++) It.m[r][cidx] += dI[i].m[r][cidx];
+        f[i] = sm_mul(&It, &a[i]);
+        if (use_vel) {
+            sv6 h = sm_mul(&I[i], &k->v[i]);
+            sv6 b = crf(&k->v[i], &h);
+            for (int t = 0; t < 6; t++) f[i].a[t] += b.a[t] - fext[i].a[t];
+        }
+    }
+    for (int i = TL - 1; i >= 1; i--) {
+        const ppenv_ta_link* L = &M->link[i];
+        tau[i - 1] = f[i].a[L->axis];
+        sv6 fp = xf(&k->E[i], k->r[i], &f[i]);
+        for (int t = 0; t < 6; t++) f[L->parent].a[t] += fp.a[t];
+    }
+    *f0 = f[0];
+}
+
+static int solve_dense(int n, double* A /* n x n row-major */, double* b) {
+    for (int col = 0; col < n; col++) {
+        int piv = col;
+        for (int r = col + 1; r < n; r++) if (fabs(A[r * n + col]) > fabs(A[piv * n + col])) piv = r;
+        if (fabs(A[piv * n + col]) < 1e-300) return -1;
+        if (piv != col) {
+            for (int cidx = 0; cidx < n; cidx++) { double t = A[col * n + cidx]; A[col * n + cidx] = A[piv * n + cidx]; A[piv * n + cidx] = t; }
+            double t = b[col]; b[col] = b[piv]; b[piv] = t;
+        }
+        for (int r = col + 1; r < n; r++) {
+            double f = A[r * n + col] / A[col * n + col];
+            if (f == 0) continue;
+            for (int cidx = col; cidx < n; cidx++) A[r * n + cidx] -= f * A[col * n + cidx];
+            b[r] -= f * b[col];
+        }
+    }
+    for (int r = n - 1; r >= 0; r--) {
+        double sum = b[r];
+        for (int cidx = r + 1; cidx < n; cidx++) sum -= A[r * n + cidx] * b[cidx];
+        b[r] = sum / A[r * n + r];
+    }
+    return 0;
+}
+
+/* external force on each link (gravity + foot contacts) and the implicit contact dampers dI = h J^T D J */
+static void ta_external(const ppenv_config* c, const ppenv_ta_model* M, const ta_kin* k, double h, sv6* fext, sm6* dI) {
+    for (int i = 0; i < TL; i++) {
+        const ppenv_ta_link* L = &M->link[i];
+        m3 Rt = mt(&k->Rw[i]);
+        v3 fg = mv(&Rt, V(0, 0, L->mass * (double)c->gravity_z));
+        fext[i] = sv_make(vcross(vf(L->com), fg), fg);
+        memset(&dI[i], 0, sizeof(sm6));
+    }
+    for (int cp = 0; cp < M->num_contacts; cp++) {
+        int li = M->contact_link[cp];
+        m3 R = k->Rw[li], Rt = mt(&R);
+        v3 w = sv_ang(&k->v[li]), vl = sv_lin(&k->v[li]);
+        {
+            v3 r = vf(M->contact_point[cp]);
+            v3 pw = vadd(k->pw[li], mv(&R, r));
+            double pen = (double)M->ground_z - pw.z;
+            if (!(pen > 0)) continue;
+            v3 vw = mv(&R, vadd(vl, vcross(w, r)));
+            /* Every switch of the contact law is a ramp, so that a state within rounding of one does not change the step:
+             * the damper's coefficient grows with the overlap up to contact_fade_depth (Hunt-Crossley-like; the ramp must
+             * not be steep: it acts as an extra stiffness c_n v_z / fade_depth), the implicit terms fade in with the force. */
+            double wfade = pen < (double)M->contact_fade_depth ? pen / (double)M->contact_fade_depth : 1.0;
+            double pc = pen > (double)M->contact_max_penetration ? (double)M->contact_max_penetration : pen;   /* saturating spring */
+            double fn0 = M->foot_stiffness * pc - wfade * M->foot_damping * vw.z;
+            if (!(fn0 > 0)) continue;
+            double gfade = fn0 < (double)M->contact_fade_force ? fn0 / (double)M->contact_fade_force : 1.0;
+            /* friction: a tangential damper whose coefficient is capped so that its force never exceeds mu f_n (the secant
+             * of Coulomb's law at the current slip speed); implicit in either regime, so it cannot reverse the slip */
+            double vt = sqrt(vw.x * vw.x + vw.y * vw.y);
+            double dt_imp = gfade * M->foot_tangent_damping;
+            if (dt_imp * vt > M->foot_friction * fn0) dt_imp = M->foot_friction * fn0 / vt;
+            v3 fw = V(-dt_imp * vw.x, -dt_imp * vw.y, fn0);
+            v3 fb = mv(&Rt, fw);
+            sv6 add = sv_make(vcross(r, fb), fb);
+            for (int t = 0; t < 6; t++) fext[li].a[t] += add.a[t];
+            /* D_b = R^T diag(dt, dt, cn + h k) R; J = [-r^, 1] */
+            double dw[3] = {dt_imp, dt_imp, gfade * (wfade * M->foot_damping + h * M->foot_stiffness)};
+            double Db[3][3];
+            for (int a = 0; a < 3; a++)
+                for (int b2 = 0; b2 < 3; b2++) {
+                    double sum = 0;
+                    for (int t = 0; t < 3; t++) sum += R.m[3 * t + a] * dw[t] * R.m[3 * t + b2];
+                    Db[a][b2] = sum;
+                }
+            double J[3][6] = {{0, r.z, -r.y, 1, 0, 0}, {-r.z, 0, r.x, 0, 1, 0}, {r.y, -r.x, 0, 0, 0, 1}};
+            for (int a = 0; a < 6; a++)
+                for (int b2 = 0; b2 < 6; b2++) {
+                    double sum = 0;
+                    for (int s1 = 0; s1 < 3; s1++) for (int s2 = 0; s2 < 3; s2++) sum += J[s1][a] * Db[s1][s2] * J[s2][b2];
+                    dI[li].m[a][b2] += h * sum;
+                }
+        }
+    }
+}
+
+/* world pose and velocity of a point fixed in a link */
+static void ta_point_state(const ta_kin* k, int link, const float* local, v3* p, v3* v) {
+    v3 r = vf(local);
+    *p = vadd(k->pw[link], mv(&k->Rw[link], r));
+    *v = mv(&k->Rw[link], vadd(sv_lin(&k->v[link]), vcross(sv_ang(&k->v[link]), r)));
+}
+static void ta_geometry(const ppenv_config* c, const ta_kin* k, arm_geom* g) {
+    int pl = c->paddle_link;
+    ta_point_state(k, pl, c->paddle_center, &g->pc, &g->vpc);
+    g->pn = mv(&k->Rw[pl], vf(c->paddle_normal));
+    g->pnd = vcross(mv(&k->Rw[pl], sv_ang(&k->v[pl])), g->pn);
+    for (int s = 0; s < c->num_shapes; s++) {
+        ta_point_state(k, c->shape[s].link, c->shape[s].a, &g->sa[s], &g->va[s]);
+        ta_point_state(k, c->shape[s].link, c->shape[s].b, &g->sb[s], &g->vb[s]);
+    }
+}
+
+static void ta_write_row(float* row, v3 p, const m3* R, v3 lin, v3 ang) {
+    double qt[4];
+    rot_to_quat(R, qt);
+    row[0] = (float)p.x; row[1] = (float)p.y; row[2] = (float)p.z;
+    for (int t = 0; t < 4; t++) row[3 + t] = (float)qt[t];
+    row[7] = (float)lin.x; row[8] = (float)lin.y; row[9] = (float)lin.z;
+    row[10] = (float)ang.x; row[11] = (float)ang.y; row[12] = (float)ang.z;
+}
+/* rigid_body_states [42][13] of one env from its kinematics (gym.refresh_rigid_body_state_tensor) */
+static void ta_body_states(const ppenv_ta_model* M, const ta_kin* k, const float* root /*[3][13]*/, float* rb) {
+    for (int i = 0; i < TL; i++) {
+        v3 lin = mv(&k->Rw[i], sv_lin(&k->v[i])), ang = mv(&k->Rw[i], sv_ang(&k->v[i]));
+        ta_write_row(&rb[M->link[i].body * 13], k->pw[i], &k->Rw[i], lin, ang);
+    }
+    for (int f = 0; f < PPENV_TA_NUM_FIXED; f++) {
+        const ppenv_ta_fixed* F = &M->fixed[f];
+        v3 p, v;
+        ta_point_state(k, F->link, F->xyz, &p, &v);
+        m3 Rf = mf(F->rot), R = mm(&k->Rw[F->link], &Rf);
+        ta_write_row(&rb[F->body * 13], p, &R, v, mv(&k->Rw[F->link], sv_ang(&k->v[F->link])));
+    }
+    memcpy(&rb[40 * 13], &root[13], 13 * sizeof(float));
+    memcpy(&rb[41 * 13], &root[26], 13 * sizeof(float));
+}
+
+void ppo_ta_forward_kinematics(const ppenv_ta_model* M, int n, const float* root_states, const float* dof_states, float* rb_states) {
+    for (int e = 0; e < n; e++) {
+        double q[PPENV_TA_NUM_DOF], qd[PPENV_TA_NUM_DOF];
+        for (int d = 0; d < PPENV_TA_NUM_DOF; d++) { q[d] = dof_states[((size_t)e * PPENV_TA_NUM_DOF + d) * 2]; qd[d] = dof_states[((size_t)e * PPENV_TA_NUM_DOF + d) * 2 + 1]; }
+        ta_kin k;
+        ta_kinematics(M, &root_states[(size_t)e * 39], q, qd, &k);
+        ta_body_states(M, &k, &root_states[(size_t)e * 39], &rb_states[(size_t)e * 42 * 13]);
+    }
+}
+
+static void ta_simulate_env(const ppenv_config* c, const ppenv_ta_model* M, const float* act, float* root /*[3][13]*/, float* dofs /*[27][2]*/,
+                            float* rb, float* dof_force, float* pre_vx) {
+    enum { NDF = PPENV_TA_NUM_DOF };
+    double q[NDF], qd[NDF], target[NDF], tau_drive[NDF] = {0};
+    for (int d = 0; d < NDF; d++) {
+        const ppenv_ta_link* L = &M->link[d + 1];
+        float a = fminf(fmaxf(act[d], -c->clip_actions), c->clip_actions);
+        float off = 0.5f * (L->upper + L->lower), scale = 0.5f * (L->upper - L->lower);   /* TA:729-733 */
+        target[d] = off + scale * a;                                                       /* TA:1131 */
+        q[d] = dofs[2 * d]; qd[d] = dofs[2 * d + 1];
+    }
+    float* ballf = &root[26];
+    *pre_vx = ballf[7];                                                                    /* TA:1143 */
+    ball_t b = {vf(&ballf[0]), vf(&ballf[7]), vf(&ballf[10])};
+    double bq[4] = {ballf[3], ballf[4], ballf[5], ballf[6]};
+    double pos[3] = {root[0], root[1], root[2]}, quat[4] = {root[3], root[4], root[5], root[6]};
+    double vw[3] = {root[7], root[8], root[9]}, ww[3] = {root[10], root[11], root[12]};
+    double h = (double)c->dt / c->substeps;
+    sm6 I[TL];
+    for (int i = 0; i < TL; i++) I[i] = spatial_inertia(M->link[i].mass, M->link[i].com, M->link[i].inertia);
+
+    for (int s = 0; s < c->substeps; s++) {
+        ta_kin k;
+        ta_kinematics_d(M, pos, quat, vw, ww, q, qd, &k);
+        sv6 fext[TL];
+        sm6 dI[TL];
+        ta_external(c, M, &k, h, fext, dI);
+
+        /* drives */
+        double tau[NDF], tau_lim[NDF], arm_eff[NDF];
+        for (int d = 0; d < NDF; d++) {
+            const ppenv_ta_link* L = &M->link[d + 1];
+            double err = target[d] - q[d];
+            /* implicit PD whose explicit part is clamped to the effort limit: continuous at saturation (the 7-dof arm's
+             * spec switches branch there; on a floating base that switch would also be a momentum glitch) */
+            tau[d] = clampd(L->kp * (err - h * qd[d]) - L->kd * qd[d], -L->effort, L->effort);
+            arm_eff[d] = L->armature + h * L->kd + h * h * L->kp;
+            tau_lim[d] = 0.0;
+            double over = q[d] > L->upper ? q[d] - L->upper : (q[d] < L->lower ? q[d] - L->lower : 0.0);
+            if (over != 0.0) {                       /* position limit: implicit spring-damper */
+                /* limit spring with a quadratic toe over the first 0.01 rad (torque and stiffness start from zero: no jump at
+                 * the limit); the implicit term uses the tangent stiffness, the damper fades in on the same ramp */
+                double x = fabs(over), ramp = x < 0.01 ? x / 0.01 : 1.0;
+                double phi = x < 0.01 ? x * x / 0.02 : x - 0.005;
+                double kt = (double)M->limit_stiffness * ramp;
+                tau_lim[d] += -(over > 0 ? 1.0 : -1.0) * (double)M->limit_stiffness * phi - kt * h * qd[d] - ramp * (double)M->limit_damping * qd[d];
+                arm_eff[d] += h * (ramp * (double)M->limit_damping + h * kt);
+            }
+            if (fabs(qd[d]) > L->vel_limit) {        /* velocity limit: implicit damper on the excess, fading in over 1 rad/s */
+                double ex = fabs(qd[d]) - L->vel_limit;
+                tau_lim[d] += -(double)M->vel_limit_damping * (qd[d] > 0 ? ex : -ex);
+                arm_eff[d] += h * (double)M->vel_limit_damping * (ex < 1.0 ? ex : 1.0);
+            }
+        }
+        /* (M + diag) nu_dot = [0; tau] - C */
+        static const double zero27[NDF] = {0};
+        double A[TNV * TNV], rhs[TNV];
+        sv6 f0, z6 = sv_zero();
+        double tq[NDF];
+        ta_rnea(M, &k, I, dI, fext, &z6, zero27, 1, &f0, tq);
+        for (int t = 0; t < 6; t++) rhs[t] = -f0.a[t];
+        for (int d = 0; d < NDF; d++) rhs[6 + d] = tau[d] + tau_lim[d] - tq[d];
+        for (int col = 0; col < TNV; col++) {
+            sv6 a0 = sv_zero();
+            double qdd[NDF] = {0};
+            if (col < 6) a0.a[col] = 1.0; else qdd[col - 6] = 1.0;
+            ta_rnea(M, &k, I, dI, fext, &a0, qdd, 0, &f0, tq);
+            for (int t = 0; t < 6; t++) A[t * TNV + col] = f0.a[t];
+            for (int d = 0; d < NDF; d++) A[(6 + d) * TNV + col] = tq[d];
+        }
+        for (int d = 0; d < NDF; d++) A[(6 + d) * TNV + 6 + d] += arm_eff[d];
+        solve_dense(TNV, A, rhs);
+
+        /* ball against the start-of-substep geometry */
+        arm_geom g;
+        ta_geometry(c, &k, &g);
+        const arm_geom* garr[1] = {&g};
+        v3 bound = vadd(k.pw[M->bound_link], mv(&k.Rw[M->bound_link], vf(M->bound_center)));
+        ball_substep_nb(c, &b, bq, 1, garr, &bound, h);
+
+        /* integrate: base in world coordinates */
+        v3 alpha = V(rhs[0], rhs[1], rhs[2]), ab = V(rhs[3], rhs[4], rhs[5]);
+        v3 wb = sv_ang(&k.v[0]), vb = sv_lin(&k.v[0]);
+        v3 aw = mv(&k.Rw[0], vadd(ab, vcross(wb, vb))), alw = mv(&k.Rw[0], alpha);
+        vw[0] += h * aw.x; vw[1] += h * aw.y; vw[2] += h * aw.z;
+        ww[0] += h * alw.x; ww[1] += h * alw.y; ww[2] += h * alw.z;
+        for (int t = 0; t < 3; t++) pos[t] += h * vw[t];
+        {
+            double x = quat[0], y = quat[1], z = quat[2], w = quat[3], kq = 0.5 * h;
+            double nx = x + kq * (ww[0] * w + ww[1] * z - ww[2] * y);
+            double ny = y + kq * (ww[1] * w + ww[2] * x - ww[0] * z);
+            double nz = z + kq * (ww[2] * w + ww[0] * y - ww[1] * x);
+            double nw = w + kq * (-ww[0] * x - ww[1] * y - ww[2] * z);
+            double nrm = sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+            quat[0] = nx / nrm; quat[1] = ny / nrm; quat[2] = nz / nrm; quat[3] = nw / nrm;
+        }
+        for (int d = 0; d < NDF; d++) {
+            const ppenv_ta_link* L = &M->link[d + 1];
+            double err = target[d] - q[d];
+            double v_new = qd[d] + h * rhs[6 + d];
+            tau_drive[d] = clampd(L->kp * (err - h * v_new) - L->kd * v_new, -L->effort, L->effort);
+            q[d] += h * v_new; qd[d] = v_new;   /* limits act through tau_lim: no clamp */
+        }
+    }
+    /* refresh: round to the fp32 tensors */
+    for (int t = 0; t < 3; t++) { root[t] = (float)pos[t]; root[7 + t] = (float)vw[t]; root[10 + t] = (float)ww[t]; }
+    for (int t = 0; t < 4; t++) root[3 + t] = (float)quat[t];
+    for (int d = 0; d < NDF; d++) { dofs[2 * d] = (float)q[d]; dofs[2 * d + 1] = (float)qd[d]; dof_force[d] = (float)tau_drive[d]; }
+    ballf[0] = (float)b.p.x; ballf[1] = (float)b.p.y; ballf[2] = (float)b.p.z;
+    for (int t = 0; t < 4; t++) ballf[3 + t] = (float)bq[t];
+    ballf[7] = (float)b.v.x; ballf[8] = (float)b.v.y; ballf[9] = (float)b.v.z;
+    ballf[10] = (float)b.w.x; ballf[11] = (float)b.w.y; ballf[12] = (float)b.w.z;
+    double qf[NDF], qdf[NDF];
+    for (int d = 0; d < NDF; d++) { qf[d] = dofs[2 * d]; qdf[d] = dofs[2 * d + 1]; }
+    ta_kin kf;
+    ta_kinematics(M, root, qf, qdf, &kf);
+    ta_body_states(M, &kf, root, rb);
+}
+
+void ppo_ta_simulate(const ppenv_config* c, const ppenv_ta_model* M, int n, int threads, const float* actions, float* root_states,
+                     float* dof_states, float* rb_states, float* dof_force, float* pre_ball_vx) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+#endif
+    for (int e = 0; e < n; e++)
+        ta_simulate_env(c, M, &actions[(size_t)e * PPENV_TA_NUM_DOF], &root_states[(size_t)e * 39], &dof_states[(size_t)e * 54],
+                        &rb_states[(size_t)e * 42 * 13], &dof_force[(size_t)e * PPENV_TA_NUM_DOF], &pre_ball_vx[e]);
 }

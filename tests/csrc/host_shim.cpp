@@ -100,3 +100,58 @@ void shim_serve_velocity(const ppenv_config* cfg, uint32_t gid, uint32_t episode
     out[0] = v.x; out[1] = v.y; out[2] = v.z;
 }
 }
+
+// ---- 27-DoF variant: the rigid-body step through the kernels' arithmetic (ppenv_ta_device.h)
+#include "../../isaacgym_amd/csrc/ppenv_ta_device.h"
+namespace {
+struct ArrayStore {
+    float* buf;
+    inline float& operator()(int slot) { return buf[slot]; }
+};
+}  // namespace
+extern "C" int shim_ta_simulate(const ppenv_config* scene, const ppenv_ta_model* model, int n, const float* actions, float* root_states,
+                                float* dof_states, float* rb_states, float* dof_force, float* pre_vx) {
+    using namespace pp::ta;
+    static TAConsts C;
+    const char* why;
+    if (!make_ta_consts(*scene, *model, C, &why)) return -1;
+    const StepConsts K = make_step_consts(*scene);
+    static float buf[NUM_SLOTS];
+    for (int e = 0; e < n; e++) {
+        ArrayStore st{buf};
+        float* root = &root_states[(size_t)e * 39];
+        float* dofs = &dof_states[(size_t)e * 2 * NDOF];
+        for (int d = 0; d < NDOF; d++) {
+            const LinkC& L = C.link[d + 1];
+            float a = fminf(fmaxf(actions[(size_t)e * NDOF + d], -C.clip_actions), C.clip_actions);
+            st(DOF_BASE + d * DOF_STRIDE + G_TARGET) = 0.5f * (L.hi + L.lo) + 0.5f * (L.hi - L.lo) * a;
+            st(DOF_BASE + d * DOF_STRIDE + G_Q) = dofs[2 * d];
+            st(DOF_BASE + d * DOF_STRIDE + G_QD) = dofs[2 * d + 1];
+            st(DOF_BASE + d * DOF_STRIDE + G_FORCE) = 0.f;
+        }
+        BaseState b;
+        b.p = ld3(&root[0]); for (int k = 0; k < 4; k++) b.quat[k] = root[3 + k];
+        b.vw = ld3(&root[7]); b.ww = ld3(&root[10]);
+        float* bl = &root[26];
+        Ball ball;
+        ball.p = ld3(&bl[0]); for (int k = 0; k < 4; k++) ball.quat[k] = bl[3 + k];
+        ball.v = ld3(&bl[7]); ball.w = ld3(&bl[10]);
+        pre_vx[e] = ball.v.x;
+        simulate_env_ta(C, K, st, b, ball);
+        root[0] = b.p.x; root[1] = b.p.y; root[2] = b.p.z; for (int k = 0; k < 4; k++) root[3 + k] = b.quat[k];
+        root[7] = b.vw.x; root[8] = b.vw.y; root[9] = b.vw.z; root[10] = b.ww.x; root[11] = b.ww.y; root[12] = b.ww.z;
+        bl[0] = ball.p.x; bl[1] = ball.p.y; bl[2] = ball.p.z; for (int k = 0; k < 4; k++) bl[3 + k] = ball.quat[k];
+        bl[7] = ball.v.x; bl[8] = ball.v.y; bl[9] = ball.v.z; bl[10] = ball.w.x; bl[11] = ball.w.y; bl[12] = ball.w.z;
+        for (int d = 0; d < NDOF; d++) {
+            dofs[2 * d] = st(DOF_BASE + d * DOF_STRIDE + G_Q);
+            dofs[2 * d + 1] = st(DOF_BASE + d * DOF_STRIDE + G_QD);
+            dof_force[(size_t)e * NDOF + d] = st(DOF_BASE + d * DOF_STRIDE + G_FORCE);
+        }
+        pass_kinematics<false>(C, st, b);
+        float* rb = &rb_states[(size_t)e * 42 * 13];
+        write_body_states(C, st, rb);
+        memcpy(&rb[40 * 13], &root[13], 13 * sizeof(float));
+        memcpy(&rb[41 * 13], &root[26], 13 * sizeof(float));
+    }
+    return 0;
+}

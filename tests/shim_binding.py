@@ -11,6 +11,7 @@ from isaacgym_amd import scene
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "csrc", "host_shim.cpp")
 _HDR = os.path.join(_HERE, "..", "isaacgym_amd", "csrc", "ppenv_device.h")
+_HDR2 = os.path.join(_HERE, "..", "isaacgym_amd", "csrc", "ppenv_ta_device.h")
 _LIB = os.path.join(_HERE, "csrc", "libppenv_hostshim.so")
 _lib = None
 
@@ -18,7 +19,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < max(os.path.getmtime(_SRC), os.path.getmtime(_HDR)):
+        if (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < max(os.path.getmtime(_SRC), os.path.getmtime(_HDR), os.path.getmtime(_HDR2)):
             subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=fast", "-fno-signed-zeros", "-ffinite-math-only", "-Wno-unknown-pragmas",
                             "-o", _LIB, _SRC], check=True, capture_output=True)
         _lib = C.CDLL(_LIB)
@@ -78,3 +79,16 @@ def serve_velocity(config, gid, episode):
     out = np.zeros(3, np.float32)
     lib().shim_serve_velocity(C.byref(config), C.c_uint32(gid), C.c_uint32(episode), _p(out))
     return out
+
+
+def ta_simulate(scene_cfg, model, actions, root, dof):
+    """One step of the 27-DoF rigid-body kernel arithmetic on the CPU (root [N,3,13], dof [N,27,2] updated in place)."""
+    n = root.shape[0]
+    for a in (actions, root, dof):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    rb = np.zeros((n, 42, 13), np.float32)
+    frc = np.zeros((n, 27), np.float32)
+    pvx = np.zeros(n, np.float32)
+    rc = lib().shim_ta_simulate(C.byref(scene_cfg), C.byref(model), n, _p(actions), _p(root), _p(dof), _p(rb), _p(frc), _p(pvx))
+    assert rc == 0
+    return rb, frc, pvx

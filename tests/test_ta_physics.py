@@ -1,0 +1,202 @@
+"""Rigid-body step of the 27-DoF variant (ppenv_ta_simulate: free-floating 28-link humanoid, ground contacts, ball).
+
+PARITY UNPINNED against the reference (its physics is the closed Isaac Gym binary; the g1_27dof.urdf asset is absent): the
+tests pin the kernels' floating-base articulated-body algorithm (fp32) to the oracle's Newton-Euler + dense solve (fp64) —
+two independent formulations of the build's written specification — and check physical invariants."""
+import numpy as np
+import pytest
+
+import shim_binding as sb
+from helpers import assert_close
+from isaacgym_amd import scene
+
+
+def initial_tensors(n, seed=0):
+    p = scene.build_ta_params(n)
+    root = np.zeros((n, 3, 13), np.float32)
+    for a in range(3):
+        root[:, a, :7] = np.array(list(p.init_root[a]))
+    rng = np.random.default_rng(seed)
+    root[:, 2, 1] = rng.uniform(-0.5, 0.1, n)
+    root[:, 2, 2] = rng.uniform(0.96, 1.05, n)
+    root[:, 2, 7:10] = np.stack([rng.uniform(-5.2, -4.6, n), rng.uniform(-0.5, 0.2, n), rng.uniform(1.2, 2.0, n)], axis=1)
+    return root, np.zeros((n, 27, 2), np.float32)
+
+
+# Tolerances of the single-step comparison: rtol 1e-4 plus a fraction of each tensor's range.  Positions hold 1e-4 of the
+# range; velocities and torques get 5e-4: the ankle links (74 g, I = 1e-5 kg m^2) under the 1e5 N/m contact springs amplify
+# fp32 rounding — a handful of env-steps in 10^4 reach 1.5e-2 rad/s on a joint moving at 8 rad/s.  Every switch of the TA
+# physics specification is a ramp (contact fade-in, clamped implicit PD, limit spring with a toe), so no env has to be skipped.
+TOL = dict(root_pos=1e-4 * 1.0, root_quat=2e-4, root_vel=5e-4 * 10.0, q=1e-4 * 3.14, qd=5e-4 * 40.0, frc=5e-4 * 139.0, rb_pos=1e-4,
+           rb_vel=5e-4 * 20.0, rb_ang=5e-4 * 100.0)   # a link's angular velocity stacks up to seven joint rates of <= 37 rad/s
+
+
+def check_step(got, want, what):
+    (root_g, dof_g, rb_g, frc_g), (root_w, dof_w, rb_w, frc_w) = got, want
+    assert_close(root_g[..., 0:3], root_w[..., 0:3], f"{what}: root pos", atol=TOL["root_pos"])
+    sign = np.sign(np.sum(root_g[..., 3:7] * root_w[..., 3:7], axis=-1, keepdims=True))
+    assert_close(root_g[..., 3:7] * sign, root_w[..., 3:7], f"{what}: root quat", atol=TOL["root_quat"])
+    assert_close(root_g[..., 7:13], root_w[..., 7:13], f"{what}: root vel", atol=TOL["root_vel"])
+    assert_close(dof_g[..., 0], dof_w[..., 0], f"{what}: dof pos", atol=TOL["q"])
+    assert_close(dof_g[..., 1], dof_w[..., 1], f"{what}: dof vel", atol=TOL["qd"])
+    assert_close(frc_g, frc_w, f"{what}: dof force", atol=TOL["frc"])
+    assert_close(rb_g[..., 0:3], rb_w[..., 0:3], f"{what}: body pos", atol=TOL["rb_pos"])
+    assert_close(rb_g[..., 7:10], rb_w[..., 7:10], f"{what}: body vel", atol=TOL["rb_vel"])
+    assert_close(rb_g[..., 10:13], rb_w[..., 10:13], f"{what}: body ang vel", atol=TOL["rb_ang"])
+
+
+def test_model_tables():
+    m = scene.build_ta_model()
+    assert abs(sum(m.link[i].mass for i in range(28)) - 35.7) < 0.2           # a G1 weighs about 35 kg
+    assert [m.link[i].parent for i in range(28)] == [-1, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10, 11, 0, 13, 14, 15, 16, 17, 18, 19, 20, 21, 15, 23, 24, 25, 26]
+    kp = [m.link[i].kp for i in range(1, 28)]
+    assert kp == scene.TA_P_GAINS and kp[10] == 80.0 and kp[4] == 20.0        # TA:757-772, the asymmetric ankle gain as written
+    bodies = sorted([m.link[i].body for i in range(28)] + [m.fixed[k].body for k in range(12)])
+    assert bodies == list(range(40))                                           # every rigid body of pingpong_note.txt:33 exactly once
+
+
+def test_standing_pose_and_kinematics(oracle_lib):
+    """All dofs at 0: the soles are on the plane z = 0.21 (TA:403) with the pelvis where the task creates it (TA:578)."""
+    m = scene.build_ta_model()
+    root, dof = initial_tensors(4)
+    rb = oracle_lib.ta_forward_kinematics(m, root, dof)
+    sole_z = rb[0, [7, 14], 2] - 0.035
+    assert np.all(np.abs(sole_z - scene.TA_GROUND_Z) < 0.005)
+    np.testing.assert_allclose(rb[0, 7, 1], -rb[0, 14, 1], atol=1e-6)          # mirrored legs
+    np.testing.assert_allclose(rb[0, 28, [0, 2]], rb[0, 38, [0, 2]], atol=1e-5)   # mirrored hands (welded bodies 28 / 38)
+    np.testing.assert_allclose(rb[0, 28, 1], -rb[0, 38, 1], atol=1e-5)
+    np.testing.assert_allclose(rb[:, 40, :3], root[:, 1, :3])                  # table and ball rows are the actor roots
+    np.testing.assert_allclose(rb[:, 41], root[:, 2])
+
+
+def test_free_flight_conserves_momentum(oracle_lib):
+    """No gravity, no ground, drives off: total linear momentum is conserved up to the integrator's O(h^2) error."""
+    n = 1
+    cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
+    cfg.gravity_z = 0.0
+    m.ground_z = cfg.ground_z = -100.0
+    for i in range(1, 28):
+        L = m.link[i]
+        L.kp = L.kd = 0.0
+        L.lower, L.upper, L.vel_limit = -1e3, 1e3, 1e6
+    root, dof = initial_tensors(n)
+    rng = np.random.default_rng(0)
+    dof[0, :, 0], dof[0, :, 1] = rng.uniform(-0.3, 0.3, 27), rng.uniform(-1, 1, 27)
+    root[0, 0, 7:13] = [0.3, -0.2, 0.1, 0.5, 1.0, -0.7]
+
+    def momentum(rb):
+        P = np.zeros(3)
+        for i in range(28):
+            L = m.link[i]
+            r = rb[0, L.body].astype(np.float64)
+            x, y, z, w = r[3:7]
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            P += L.mass * (r[7:10] + np.cross(r[10:13], R @ np.array(list(L.com))))
+        return P
+    p0 = momentum(oracle_lib.ta_forward_kinematics(m, root, dof))
+    act = np.zeros((n, 27), np.float32)
+    for _ in range(20):
+        rb, _, _ = oracle_lib.ta_simulate(cfg, m, act, root, dof)
+    assert np.abs(momentum(rb) - p0).max() < 0.01 * np.abs(p0).max()
+
+
+def test_kernel_arithmetic_matches_oracle_single_steps(oracle_lib):
+    """ppenv_ta_device.h compiled for the host (floating-base ABA, fp32) vs the oracle (Newton-Euler + dense solve, fp64),
+    both restarted from the oracle's state every step; standing, falling, lying and thrashing states all occur."""
+    n = 96
+    cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
+    root, dof = initial_tensors(n, seed=1)
+    rng = np.random.default_rng(2)
+    act = np.zeros((n, 27), np.float32)
+    ball_flips, contacts = 0, 0
+    for t in range(140):
+        if t % 4 == 0:
+            act = rng.uniform(-1.2, 1.2, (n, 27)).astype(np.float32)
+            act[: n // 3] *= 0.1                                           # a third of the envs moves gently
+        r2, d2 = root.copy(), dof.copy()
+        rb, frc, pvx = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=8)
+        rb2, frc2, pvx2 = sb.ta_simulate(cfg, m, act, r2, d2)
+        contacts += int((rb[:, :40, 2].min(axis=1) < scene.TA_GROUND_Z + 0.05).sum())
+        np.testing.assert_array_equal(pvx2, pvx)
+        hit = np.abs(r2[:, 2, 7:10] - root[:, 2, 7:10]).max(axis=1) > 1e-3     # ball contact decided differently (discrete, as in the 3-actor scenes)
+        ball_flips += int(hit.sum())
+        check_step((r2[~hit], d2[~hit], rb2[~hit], frc2[~hit]), (root[~hit], dof[~hit], rb[~hit], frc[~hit]), f"step {t}")
+    assert ball_flips <= 3 and contacts > n * 60
+    assert np.isfinite(root).all() and np.isfinite(dof).all()
+
+
+def test_long_run_stays_physical(oracle_lib):
+    """Random bang-bang actions for 3 episodes' worth of steps: nothing blows up, nothing sinks through the ground."""
+    n = 16
+    cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
+    root, dof = initial_tensors(n, seed=3)
+    rng = np.random.default_rng(4)
+    for t in range(480):
+        if t % 5 == 0:
+            act = rng.uniform(-1, 1, (n, 27)).astype(np.float32)
+        rb, frc, _ = sb.ta_simulate(cfg, m, act, root, dof)
+    assert np.isfinite(root).all() and np.isfinite(dof).all()
+    assert np.abs(root[:, 0, 7:10]).max() < 8.0 and np.abs(dof[..., 1]).max() < 80.0
+    assert rb[:, :40, 2].min() > scene.TA_GROUND_Z - 0.15 and root[:, 0, 2].max() < 1.6
+    effort = np.array([m.link[i].effort for i in range(1, 28)])
+    assert (np.abs(frc) <= effort * (1 + 1e-6)).all()
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [512, 50])
+def test_ta_simulate_kernel_matches_oracle(oracle_lib, n):
+    import torch
+    from isaacgym_amd.tensor_api import TASim
+    cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
+    sim = TASim(n, device="cuda:0")
+    root, dof = initial_tensors(n, seed=1)
+    rng = np.random.default_rng(2)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    rb_d, frc_d, pvx_d = torch.zeros(n, 42, 13, device="cuda"), torch.zeros(n, 27, device="cuda"), torch.zeros(n, device="cuda")
+    # forward kinematics entry (initial_body_states of TA:1152)
+    sim.forward_kinematics(dev(root), dev(dof), rb_d)
+    assert_close(rb_d.cpu().numpy()[..., :3], oracle_lib.ta_forward_kinematics(m, root, dof)[..., :3], "fk pos", atol=1e-5)
+    excluded = 0
+    for t in range(120):
+        if t % 4 == 0:
+            act = rng.uniform(-1.2, 1.2, (n, 27)).astype(np.float32)
+            act[: n // 3] *= 0.1
+        root_d, dof_d = dev(root), dev(dof)
+        sim.simulate(dev(act), root_d, dof_d, rb_d, frc_d, pvx_d)
+        rb, frc, pvx = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=8)
+        np.testing.assert_array_equal(pvx_d.cpu().numpy(), pvx)
+        rg = root_d.cpu().numpy()
+        keep = ~(np.abs(rg[:, 2, 7:10] - root[:, 2, 7:10]).max(axis=1) > 1e-3)   # ball contact decided differently (discrete)
+        excluded += int((~keep).sum())
+        got = (rg[keep], dof_d.cpu().numpy()[keep], rb_d.cpu().numpy()[keep], frc_d.cpu().numpy()[keep])
+        check_step(got, (root[keep], dof[keep], rb[keep], frc[keep]), f"step {t}")
+    assert excluded <= 5
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_ta_env_steps_end_to_end():
+    """TAEnv = ppenv_ta_simulate + ppenv_ta_post_physics_step: the 27-DoF task's VecTask step, BASELINE config 5's per-GPU size."""
+    import torch
+    from isaacgym_amd.tensor_api import TAEnv
+    n = 4096
+    envs = [TAEnv(n, device="cuda:0", seed=5) for _ in range(2)]
+    assert envs[0].obs_buf.shape == (n, 313)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    resets = 0
+    for t in range(400):
+        a = torch.rand(n, 27, device="cuda", generator=gen) * 2 - 1
+        for e in envs:
+            e.step(a)
+        resets += int(envs[0].reset_buf.sum())
+    torch.cuda.synchronize()
+    a_, b_ = envs
+    for name in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "root_states", "dof_states"):
+        assert torch.equal(getattr(a_, name), getattr(b_, name)), name      # deterministic
+    assert torch.isfinite(a_.obs_buf).all() and torch.isfinite(a_.rew_buf).all() and torch.isfinite(a_.root_states).all()
+    assert resets == 2 * n                                                 # no early stop: every env times out at 160 steps (TA:1688)
+    assert float(a_.rb_states[:, :40, 2].min()) > scene.TA_GROUND_Z - 0.2
+    for e in envs:
+        e.close()
