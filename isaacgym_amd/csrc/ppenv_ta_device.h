@@ -79,11 +79,12 @@ PP_HD S3 rsr(V3 r, const S3& s) {
 // world pose + link-frame twist of the pelvis from its root_states row (pos3 quat4 linvel3 angvel3, world)
 struct BaseState { V3 p; float quat[4]; V3 vw, ww; };
 
-// Rigid-body inertia, velocity-product and gravity bias, ground contacts of one link -> its record (A B D pn pf).
-template <class Store>
-PP_HD void init_link_dynamics(const TAConsts& C, Store& st, int i, const M3& Rw, V3 pw, V3 w, V3 v) {
-    const LinkC& L = C.link[i];
-    const int o = i * LINK_STRIDE;
+// ---- register-level primitives (shared by the one-lane-per-env passes below and the four-lanes-per-env kernel)
+struct ArtI { S3 A; M3 B; S3 D; V3 pn, pf; };        // articulated inertia [A B; B^T D] and bias force (angular, linear)
+struct JointOut { V3 ua, ub; float dinv, u; };       // what the outward pass needs from the inward one
+
+// Rigid-body inertia, velocity-product and gravity bias, ground contacts of one link (link coordinates, about its origin).
+PP_HD ArtI link_dynamics(const TAConsts& C, const LinkC& L, const M3& Rw, V3 pw, V3 w, V3 v) {
     S3 A = sym_from(L.Io);
     V3 mc = ld3(L.mc);
     const float m = L.mass;
@@ -127,37 +128,26 @@ PP_HD void init_link_dynamics(const TAConsts& C, Store& st, int i, const M3& Rw,
         B.m[3] += b0.y; B.m[4] += b1.y; B.m[5] += b2.y;
         B.m[6] += b0.z; B.m[7] += b1.z; B.m[8] += b2.z;
     }
-    sts3(st, o + F_A, A); stm3(st, o + F_B, B); sts3(st, o + F_D, D);
-    stv(st, o + F_PN, pn); stv(st, o + F_PF, pf);
+    ArtI o = {A, B, D, pn, pf};
+    return o;
+}
+PP_HD void add_art(ArtI& a, const ArtI& b) {
+    add_sym(a.A, b.A); add_sym(a.D, b.D);
+    for (int k = 0; k < 9; k++) a.B.m[k] += b.B.m[k];
+    a.pn = a.pn + b.pn; a.pf = a.pf + b.pf;
 }
 
-// Pass 1: kinematics base -> tips.  Fills c s w v Rw pw of every link; with DYN also the link's inertia / bias record.
-template <bool DYN, class Store>
-PP_HD void pass_kinematics(const TAConsts& C, Store& st, const BaseState& b) {
-    {
-        M3 Rw = quat_to_m3(b.quat);
-        V3 w = tmul(Rw, b.ww), v = tmul(Rw, b.vw);
-        stv(st, F_W, w); stv(st, F_V, v); stm3(st, F_RW, Rw); stv(st, F_PW, b.p);
-        if (DYN) init_link_dynamics(C, st, 0, Rw, b.p, w, v);
-    }
-    for (int i = 1; i < NL; i++) {
-        const LinkC& L = C.link[i];
-        const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, ax = L.axis;
-        float q = st(DOF_BASE + (i - 1) * DOF_STRIDE + G_Q), qd = st(DOF_BASE + (i - 1) * DOF_STRIDE + G_QD);
-        float s, c;
-        sincos_joint(q, s, c);
-        M3 E = joint_rot_rt(L.R0, ax, c, s);
-        V3 r = ld3(L.r);
-        M3 Rp = ldm3(st, po + F_RW);
-        V3 pp = ldv(st, po + F_PW), wp = ldv(st, po + F_W), vp = ldv(st, po + F_V);
-        M3 Rw = mul(Rp, E);
-        V3 pw = pp + mul(Rp, r);
-        V3 w = tmul(E, wp), v = tmul(E, vp + cross(wp, r));
-        if (ax == 0) w.x += qd; else if (ax == 1) w.y += qd; else w.z += qd;
-        st(o + F_C) = c; st(o + F_S) = s;
-        stv(st, o + F_W, w); stv(st, o + F_V, v); stm3(st, o + F_RW, Rw); stv(st, o + F_PW, pw);
-        if (DYN) init_link_dynamics(C, st, i, Rw, pw, w, v);
-    }
+// pose and link-frame twist of a link from its parent's (in: parent's Rw pw w v; out: the link's)
+PP_HD void link_kinematics(const LinkC& L, float q, float qd, M3& Rw, V3& pw, V3& w, V3& v, float& c, float& s) {
+    sincos_joint(q, s, c);
+    const int ax = L.axis;
+    M3 E = joint_rot_rt(L.R0, ax, c, s);
+    V3 r = ld3(L.r);
+    V3 wn = tmul(E, w), vn = tmul(E, v + cross(w, r));
+    if (ax == 0) wn.x += qd; else if (ax == 1) wn.y += qd; else wn.z += qd;
+    pw = pw + mul(Rw, r);
+    Rw = mul(Rw, E);
+    w = wn; v = vn;
 }
 
 // drive + limit torques of dof d at the start of a substep (implicit PD with its explicit part clamped to the effort
@@ -183,60 +173,116 @@ PP_HD void joint_torque(const TAConsts& C, const LinkC& L, float q, float qd, fl
     }
 }
 
-// Pass 2: articulated inertias tips -> base (RBDA 9.4 with the drive's implicit terms on the joint diagonal)
+// One joint of the inward pass (RBDA 9.4 with the drive's implicit terms on the joint diagonal).
+// I: in = the link's articulated inertia and bias (own + children, link coordinates); out = its contribution to the
+// parent (parent coordinates, about the parent's origin).
+PP_HD void inward_step(const TAConsts& C, const LinkC& L, ArtI& I, V3 w, V3 v, float c, float s, float q, float qd, float target, JointOut& jo) {
+    const int ax = L.axis;
+    float tau, arm;
+    joint_torque(C, L, q, qd, target, tau, arm);
+    S3& A = I.A; S3& D = I.D; M3& B = I.B;
+    V3 ua = symcol(A, ax), ub = row(B, ax);
+    float dinv = rcp_fast(symdiag(A, ax) + arm);
+    float u = tau - comp(I.pn, ax);
+    jo.ua = ua; jo.ub = ub; jo.dinv = dinv; jo.u = u;
+    sym_rank1_sub(A, ua, dinv);
+    sym_rank1_sub(D, ub, dinv);
+    V3 uad = ua * dinv;
+    for (int r = 0; r < 3; r++) {
+        float k = comp(uad, r);
+        B.m[3 * r] -= k * ub.x; B.m[3 * r + 1] -= k * ub.y; B.m[3 * r + 2] -= k * ub.z;
+    }
+    V3 e = unit(ax);
+    V3 cw = cross(w, e) * qd, cv = cross(v, e) * qd;
+    float ud = u * dinv;
+    V3 pan = I.pn + mul(A, cw) + mul(B, cv) + ua * ud;
+    V3 paf = I.pf + tmul(B, cw) + mul(D, cv) + ub * ud;
+    M3 E = joint_rot_rt(L.R0, ax, c, s);
+    V3 r = ld3(L.r);
+    S3 Ar = rot_sym(E, A), Dr = rot_sym(E, D);
+    M3 Br = mul_t(mul(E, B), E);
+    V3 nr = mul(E, pan), fr = mul(E, paf);
+    M3 Dm = from_sym(Dr);
+    M3 Bp;
+    for (int j = 0; j < 3; j++) {
+        V3 x = cross(r, col(Dm, j));
+        Bp.m[j] = Br.m[j] + x.x; Bp.m[3 + j] = Br.m[3 + j] + x.y; Bp.m[6 + j] = Br.m[6 + j] + x.z;
+    }
+    V3 wp0 = cross(r, row(Bp, 0)), wp1 = cross(r, row(Bp, 1)), wp2 = cross(r, row(Bp, 2));
+    V3 wb0 = cross(r, row(Br, 0)), wb1 = cross(r, row(Br, 1)), wb2 = cross(r, row(Br, 2));
+    S3 Ap = {Ar.xx + wp0.x + wb0.x, Ar.yy + wp1.y + wb1.y, Ar.zz + wp2.z + wb2.z,
+             Ar.xy + wp1.x + wb0.y, Ar.xz + wp2.x + wb0.z, Ar.yz + wp2.y + wb1.z};
+    I.A = Ap; I.B = Bp; I.D = Dr;
+    I.pn = nr + cross(r, fr); I.pf = fr;
+}
+
+// One joint of the outward pass: the link's acceleration from its parent's (aw, av: in = parent's, out = the link's), and
+// the joint's semi-implicit Euler update with the reported drive torque.
+PP_HD void outward_step(const TAConsts& C, const LinkC& L, float c, float s, V3 w, V3 v, const JointOut& jo, V3& aw, V3& av,
+                        float target, float& q, float& qd, float& force) {
+    const int ax = L.axis;
+    M3 E = joint_rot_rt(L.R0, ax, c, s);
+    V3 r = ld3(L.r), e = unit(ax);
+    V3 aw2 = tmul(E, aw) + cross(w, e) * qd;
+    V3 av2 = tmul(E, av + cross(aw, r)) + cross(v, e) * qd;
+    float qdd = (jo.u - dot(jo.ua, aw2) - dot(jo.ub, av2)) * jo.dinv;
+    if (ax == 0) aw2.x += qdd; else if (ax == 1) aw2.y += qdd; else aw2.z += qdd;
+    aw = aw2; av = av2;
+    float err = target - q;
+    float vn = qd + C.h * qdd;
+    force = fminf(fmaxf(L.kp * (err - C.h * vn) - L.kd * vn, -L.effort), L.effort);   // reported within the actuator's limit
+    q = q + C.h * vn;
+    qd = vn;
+}
+
+// ---- one lane per env: the passes over the lane's store
+// Pass 1: kinematics base -> tips.  Fills c s w v Rw pw of every link; with DYN also the link's inertia / bias record.
+template <class Store>
+PP_HD void store_art(Store& st, int o, const ArtI& I) {
+    sts3(st, o + F_A, I.A); stm3(st, o + F_B, I.B); sts3(st, o + F_D, I.D);
+    stv(st, o + F_PN, I.pn); stv(st, o + F_PF, I.pf);
+}
+template <class Store>
+PP_HD ArtI load_art(Store& st, int o) {
+    ArtI I = {lds3(st, o + F_A), ldm3(st, o + F_B), lds3(st, o + F_D), ldv(st, o + F_PN), ldv(st, o + F_PF)};
+    return I;
+}
+template <bool DYN, class Store>
+PP_HD void pass_kinematics(const TAConsts& C, Store& st, const BaseState& b) {
+    {
+        M3 Rw = quat_to_m3(b.quat);
+        V3 w = tmul(Rw, b.ww), v = tmul(Rw, b.vw);
+        stv(st, F_W, w); stv(st, F_V, v); stm3(st, F_RW, Rw); stv(st, F_PW, b.p);
+        if (DYN) store_art(st, 0, link_dynamics(C, C.link[0], Rw, b.p, w, v));
+    }
+    for (int i = 1; i < NL; i++) {
+        const LinkC& L = C.link[i];
+        const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE;
+        float q = st(DOF_BASE + (i - 1) * DOF_STRIDE + G_Q), qd = st(DOF_BASE + (i - 1) * DOF_STRIDE + G_QD);
+        M3 Rw = ldm3(st, po + F_RW);
+        V3 pw = ldv(st, po + F_PW), w = ldv(st, po + F_W), v = ldv(st, po + F_V);
+        float c, s;
+        link_kinematics(L, q, qd, Rw, pw, w, v, c, s);
+        st(o + F_C) = c; st(o + F_S) = s;
+        stv(st, o + F_W, w); stv(st, o + F_V, v); stm3(st, o + F_RW, Rw); stv(st, o + F_PW, pw);
+        if (DYN) store_art(st, o, link_dynamics(C, L, Rw, pw, w, v));
+    }
+}
+
+// Pass 2: articulated inertias tips -> base
 template <class Store>
 PP_HD void pass_inertia(const TAConsts& C, Store& st) {
     for (int i = NL - 1; i >= 1; i--) {
         const LinkC& L = C.link[i];
-        const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, ax = L.axis, dofo = DOF_BASE + (i - 1) * DOF_STRIDE;
-        S3 A = lds3(st, o + F_A), D = lds3(st, o + F_D);
-        M3 B = ldm3(st, o + F_B);
-        V3 pn = ldv(st, o + F_PN), pf = ldv(st, o + F_PF), w = ldv(st, o + F_W), v = ldv(st, o + F_V);
-        const float qd = st(dofo + G_QD);
-        float tau, arm;
-        joint_torque(C, L, st(dofo + G_Q), qd, st(dofo + G_TARGET), tau, arm);
-        V3 ua = symcol(A, ax), ub = row(B, ax);
-        float dinv = rcp_fast(symdiag(A, ax) + arm);
-        float u = tau - comp(pn, ax);
-        sym_rank1_sub(A, ua, dinv);
-        sym_rank1_sub(D, ub, dinv);
-        V3 uad = ua * dinv;
-        for (int r = 0; r < 3; r++) {
-            float k = comp(uad, r);
-            B.m[3 * r] -= k * ub.x; B.m[3 * r + 1] -= k * ub.y; B.m[3 * r + 2] -= k * ub.z;
-        }
-        V3 e = unit(ax);
-        V3 cw = cross(w, e) * qd, cv = cross(v, e) * qd;
-        float ud = u * dinv;
-        V3 pan = pn + mul(A, cw) + mul(B, cv) + ua * ud;
-        V3 paf = pf + tmul(B, cw) + mul(D, cv) + ub * ud;
+        const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, dofo = DOF_BASE + (i - 1) * DOF_STRIDE;
+        ArtI I = load_art(st, o);
+        JointOut jo;
+        inward_step(C, L, I, ldv(st, o + F_W), ldv(st, o + F_V), st(o + F_C), st(o + F_S), st(dofo + G_Q), st(dofo + G_QD), st(dofo + G_TARGET), jo);
         // the link's own record is consumed: keep what pass 3 needs in its place
-        stv(st, o + F_UA, ua); stv(st, o + F_UB, ub); st(o + F_DINV) = dinv; st(o + F_U) = u;
-        // to the parent's coordinates
-        M3 E = joint_rot_rt(L.R0, ax, st(o + F_C), st(o + F_S));
-        V3 r = ld3(L.r);
-        S3 Ar = rot_sym(E, A), Dr = rot_sym(E, D);
-        M3 Br = mul_t(mul(E, B), E);
-        V3 nr = mul(E, pan), fr = mul(E, paf);
-        M3 Dm = from_sym(Dr);
-        M3 Bp;
-        for (int j = 0; j < 3; j++) {
-            V3 x = cross(r, col(Dm, j));
-            Bp.m[j] = Br.m[j] + x.x; Bp.m[3 + j] = Br.m[3 + j] + x.y; Bp.m[6 + j] = Br.m[6 + j] + x.z;
-        }
-        V3 wp0 = cross(r, row(Bp, 0)), wp1 = cross(r, row(Bp, 1)), wp2 = cross(r, row(Bp, 2));
-        V3 wb0 = cross(r, row(Br, 0)), wb1 = cross(r, row(Br, 1)), wb2 = cross(r, row(Br, 2));
-        S3 Ap = {Ar.xx + wp0.x + wb0.x, Ar.yy + wp1.y + wb1.y, Ar.zz + wp2.z + wb2.z,
-                 Ar.xy + wp1.x + wb0.y, Ar.xz + wp2.x + wb0.z, Ar.yz + wp2.y + wb1.z};
-        V3 np = nr + cross(r, fr);
-        // accumulate into the parent's record
-        S3 PA = lds3(st, po + F_A), PD = lds3(st, po + F_D);
-        M3 PB = ldm3(st, po + F_B);
-        add_sym(PA, Ap); add_sym(PD, Dr);
-        for (int k = 0; k < 9; k++) PB.m[k] += Bp.m[k];
-        sts3(st, po + F_A, PA); sts3(st, po + F_D, PD); stm3(st, po + F_B, PB);
-        stv(st, po + F_PN, ldv(st, po + F_PN) + np);
-        stv(st, po + F_PF, ldv(st, po + F_PF) + fr);
+        stv(st, o + F_UA, jo.ua); stv(st, o + F_UB, jo.ub); st(o + F_DINV) = jo.dinv; st(o + F_U) = jo.u;
+        ArtI P = load_art(st, po);
+        add_art(P, I);
+        store_art(st, po, P);
     }
 }
 
@@ -249,19 +295,18 @@ PP_HD M3 inv_sym(const S3& s) {   // inverse of a symmetric positive-definite 3x
 }
 
 // base acceleration from [A B; B^T D] [alpha; a] = -[pn; pf]
-template <class Store>
-PP_HD void solve_base(Store& st, V3& alpha, V3& a) {
-    S3 A = lds3(st, F_A), D = lds3(st, F_D);
-    M3 B = ldm3(st, F_B);
-    V3 pn = ldv(st, F_PN), pf = ldv(st, F_PF);
-    M3 Di = inv_sym(D);
-    M3 BDi = mul(B, Di);                       // B D^-1
-    M3 S = mul_t(BDi, B);                      // B D^-1 B^T
-    S3 Sc = {A.xx - S.m[0], A.yy - S.m[4], A.zz - S.m[8], A.xy - 0.5f * (S.m[1] + S.m[3]), A.xz - 0.5f * (S.m[2] + S.m[6]), A.yz - 0.5f * (S.m[5] + S.m[7])};
-    V3 rhs = mul(BDi, pf) - pn;
+PP_HD void solve_base_art(const ArtI& I, V3& alpha, V3& a) {
+    M3 Di = inv_sym(I.D);
+    M3 BDi = mul(I.B, Di);                     // B D^-1
+    M3 S = mul_t(BDi, I.B);                    // B D^-1 B^T
+    S3 Sc = {I.A.xx - S.m[0], I.A.yy - S.m[4], I.A.zz - S.m[8], I.A.xy - 0.5f * (S.m[1] + S.m[3]), I.A.xz - 0.5f * (S.m[2] + S.m[6]),
+             I.A.yz - 0.5f * (S.m[5] + S.m[7])};
+    V3 rhs = mul(BDi, I.pf) - I.pn;
     alpha = mul(inv_sym(Sc), rhs);
-    a = -mul(Di, pf + tmul(B, alpha));
+    a = -mul(Di, I.pf + tmul(I.B, alpha));
 }
+template <class Store>
+PP_HD void solve_base(Store& st, V3& alpha, V3& a) { solve_base_art(load_art(st, 0), alpha, a); }
 
 // Pass 3: accelerations base -> tips, and the joints' semi-implicit Euler update (q, qd, reported drive torque)
 template <class Store>
@@ -269,30 +314,18 @@ PP_HD void pass_accelerate(const TAConsts& C, Store& st, V3 alpha0, V3 a0) {
     stv(st, F_AW, alpha0); stv(st, F_AV, a0);
     for (int i = 1; i < NL; i++) {
         const LinkC& L = C.link[i];
-        const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, ax = L.axis, dofo = DOF_BASE + (i - 1) * DOF_STRIDE;
-        M3 E = joint_rot_rt(L.R0, ax, st(o + F_C), st(o + F_S));
-        V3 r = ld3(L.r), e = unit(ax);
+        const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, dofo = DOF_BASE + (i - 1) * DOF_STRIDE;
         V3 aw = ldv(st, po + F_AW), av = ldv(st, po + F_AV);
-        const float q = st(dofo + G_Q), qd = st(dofo + G_QD), target = st(dofo + G_TARGET);
-        V3 aw2 = tmul(E, aw) + cross(ldv(st, o + F_W), e) * qd;
-        V3 av2 = tmul(E, av + cross(aw, r)) + cross(ldv(st, o + F_V), e) * qd;
-        float qdd = (st(o + F_U) - dot(ldv(st, o + F_UA), aw2) - dot(ldv(st, o + F_UB), av2)) * st(o + F_DINV);
-        if (ax == 0) aw2.x += qdd; else if (ax == 1) aw2.y += qdd; else aw2.z += qdd;
-        stv(st, o + F_AW, aw2); stv(st, o + F_AV, av2);
-        // integrate the joint; report the drive torque within the actuator's limit
-        float err = target - q;
-        float vn = qd + C.h * qdd;
-        st(dofo + G_FORCE) = fminf(fmaxf(L.kp * (err - C.h * vn) - L.kd * vn, -L.effort), L.effort);
-        st(dofo + G_Q) = q + C.h * vn;
-        st(dofo + G_QD) = vn;
+        JointOut jo = {ldv(st, o + F_UA), ldv(st, o + F_UB), st(o + F_DINV), st(o + F_U)};
+        float q = st(dofo + G_Q), qd = st(dofo + G_QD), force;
+        outward_step(C, L, st(o + F_C), st(o + F_S), ldv(st, o + F_W), ldv(st, o + F_V), jo, aw, av, st(dofo + G_TARGET), q, qd, force);
+        stv(st, o + F_AW, aw); stv(st, o + F_AV, av);
+        st(dofo + G_FORCE) = force; st(dofo + G_Q) = q; st(dofo + G_QD) = qd;
     }
 }
 
 // base: semi-implicit Euler in world coordinates (classical acceleration of the origin = R (a + w x v))
-template <class Store>
-PP_HD void integrate_base(const TAConsts& C, Store& st, BaseState& b, V3 alpha, V3 a) {
-    M3 Rw = ldm3(st, F_RW);
-    V3 wb = ldv(st, F_W), vb = ldv(st, F_V);
+PP_HD void integrate_base_regs(const TAConsts& C, const M3& Rw, V3 wb, V3 vb, BaseState& b, V3 alpha, V3 a) {
     V3 aw = mul(Rw, a + cross(wb, vb)), alw = mul(Rw, alpha);
     const float h = C.h;
     b.vw = madd(b.vw, aw, h);
@@ -305,6 +338,10 @@ PP_HD void integrate_base(const TAConsts& C, Store& st, BaseState& b, V3 alpha, 
     float nw = w + kq * (-b.ww.x * x - b.ww.y * y - b.ww.z * z);
     float inv = rsq_fast(nx * nx + ny * ny + nz * nz + nw * nw);
     b.quat[0] = nx * inv; b.quat[1] = ny * inv; b.quat[2] = nz * inv; b.quat[3] = nw * inv;
+}
+template <class Store>
+PP_HD void integrate_base(const TAConsts& C, Store& st, BaseState& b, V3 alpha, V3 a) {
+    integrate_base_regs(C, ldm3(st, F_RW), ldv(st, F_W), ldv(st, F_V), b, alpha, a);
 }
 
 // world position / velocity of a point fixed in link `link` (after pass_kinematics)

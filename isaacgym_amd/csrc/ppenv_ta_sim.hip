@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -86,6 +87,265 @@ __global__ __launch_bounds__(kTaLanes) void ta_sim_kernel(const TAConsts* __rest
     write_body_states(C, st, rb);
     for (int k = 0; k < 13; k++) { rb[40 * 13 + k] = root[13 + k]; rb[41 * 13 + k] = root[26 + k]; }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Four lanes per env.  The humanoid is four limbs on two hubs (pelvis: legs + the waist chain; torso: arms), so a quad of
+// lanes walks the four limbs in parallel: lane role 0 = left leg, 1 = right leg, 2 = waist + left arm, 3 = waist + right arm
+// (the 3-link waist chain is computed redundantly by both arm lanes).  A lane carries its chain's running quantities (pose,
+// twist, articulated inertia, acceleration) in registers and keeps only what a later pass needs in its LDS column; the two
+// hub accumulations travel through quad shuffles.  Serial depth: 10 joint visits per pass instead of 27, 64 active lanes
+// per wave instead of 16.  The chains below are the topology of scene.build_ta_model (checked at create time; any other
+// tree runs on ta_sim_kernel).
+constexpr int kQuadEnvs = 16;      // envs per 64-lane workgroup
+constexpr int kChainLen = 10;
+constexpr int kRec = 35;           // c s w3 v3 | A6 B9 D6 pn3 pf3  (later: ua3 ub3 dinv u over the A.. slots)
+constexpr int R_C = 0, R_S = 1, R_W = 2, R_V = 5, R_ART = 8, R_JO = 8;
+__device__ const int kChains[4][kChainLen] = {{1, 2, 3, 4, 5, 6, -1, -1, -1, -1},
+                                              {7, 8, 9, 10, 11, 12, -1, -1, -1, -1},
+                                              {13, 14, 15, 16, 17, 18, 19, 20, 21, 22},
+                                              {13, 14, 15, 23, 24, 25, 26, 27, -1, -1}};
+constexpr int kHubPos = 2;         // chain position of the torso on the two arm lanes: the arms merge before it is processed
+
+struct QuadRec {
+    float* col;   // &s_rec[0][0][lane]
+    __device__ __forceinline__ float& operator()(int k, int f) { return col[(k * kRec + f) * 64]; }
+};
+__device__ __forceinline__ void rec_store_art(QuadRec& rc, int k, const ArtI& I) {
+    const float v[27] = {I.A.xx, I.A.yy, I.A.zz, I.A.xy, I.A.xz, I.A.yz, I.B.m[0], I.B.m[1], I.B.m[2], I.B.m[3], I.B.m[4], I.B.m[5], I.B.m[6], I.B.m[7], I.B.m[8],
+                         I.D.xx, I.D.yy, I.D.zz, I.D.xy, I.D.xz, I.D.yz, I.pn.x, I.pn.y, I.pn.z, I.pf.x, I.pf.y, I.pf.z};
+#pragma unroll
+    for (int t = 0; t < 27; t++) rc(k, R_ART + t) = v[t];
+}
+__device__ __forceinline__ ArtI rec_load_art(QuadRec& rc, int k) {
+    float v[27];
+#pragma unroll
+    for (int t = 0; t < 27; t++) v[t] = rc(k, R_ART + t);
+    ArtI I = {{v[0], v[1], v[2], v[3], v[4], v[5]}, {{v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13], v[14]}},
+              {v[15], v[16], v[17], v[18], v[19], v[20]}, mk(v[21], v[22], v[23]), mk(v[24], v[25], v[26])};
+    return I;
+}
+__device__ __forceinline__ ArtI art_zero() {
+    ArtI I = {{0, 0, 0, 0, 0, 0}, {{0, 0, 0, 0, 0, 0, 0, 0, 0}}, {0, 0, 0, 0, 0, 0}, mk(0, 0, 0), mk(0, 0, 0)};
+    return I;
+}
+__device__ __forceinline__ ArtI art_shfl_xor(const ArtI& I, int m) {
+    ArtI o;
+    o.A.xx = __shfl_xor(I.A.xx, m); o.A.yy = __shfl_xor(I.A.yy, m); o.A.zz = __shfl_xor(I.A.zz, m);
+    o.A.xy = __shfl_xor(I.A.xy, m); o.A.xz = __shfl_xor(I.A.xz, m); o.A.yz = __shfl_xor(I.A.yz, m);
+#pragma unroll
+    for (int t = 0; t < 9; t++) o.B.m[t] = __shfl_xor(I.B.m[t], m);
+    o.D.xx = __shfl_xor(I.D.xx, m); o.D.yy = __shfl_xor(I.D.yy, m); o.D.zz = __shfl_xor(I.D.zz, m);
+    o.D.xy = __shfl_xor(I.D.xy, m); o.D.xz = __shfl_xor(I.D.xz, m); o.D.yz = __shfl_xor(I.D.yz, m);
+    o.pn = mk(__shfl_xor(I.pn.x, m), __shfl_xor(I.pn.y, m), __shfl_xor(I.pn.z, m));
+    o.pf = mk(__shfl_xor(I.pf.x, m), __shfl_xor(I.pf.y, m), __shfl_xor(I.pf.z, m));
+    return o;
+}
+__device__ __forceinline__ void point_of(const M3& Rw, V3 pw, V3 w, V3 v, V3 r, V3& p, V3& vel) {
+    p = pw + mul(Rw, r);
+    vel = mul(Rw, v + cross(w, r));
+}
+// the ball-collision shapes / paddle / bound centre that ride on link `li` (run-time compare against the shape table)
+__device__ __forceinline__ void capture_geometry(const TAConsts& C, int li, const M3& Rw, V3 pw, V3 w, V3 v, ArmGeom<ModelG1TA::kShapes>& g, V3& bound) {
+#pragma unroll
+    for (int s = 0; s < ModelG1TA::kShapes; s++)
+        if (C.shape_link[s] == li) {
+            point_of(Rw, pw, w, v, ld3(C.shape_a[s]), g.a[s], g.va[s]);
+            point_of(Rw, pw, w, v, ld3(C.shape_b[s]), g.b[s], g.vb[s]);
+        }
+    if (C.paddle_link == li) {
+        point_of(Rw, pw, w, v, ld3(C.paddle_center), g.pc, g.vpc);
+        g.pn = mul(Rw, ld3(C.paddle_normal));
+        g.pnd = cross(mul(Rw, w), g.pn);
+    }
+    if (C.bound_link == li) { V3 d; point_of(Rw, pw, w, v, ld3(C.bound_center), bound, d); }
+}
+__device__ __forceinline__ void write_row(float* row, const M3& R, V3 p, V3 lin, V3 ang) {
+    float q[4];
+    rot_to_quat(R, q);
+    row[0] = p.x; row[1] = p.y; row[2] = p.z; row[3] = q[0]; row[4] = q[1]; row[5] = q[2]; row[6] = q[3];
+    row[7] = lin.x; row[8] = lin.y; row[9] = lin.z; row[10] = ang.x; row[11] = ang.y; row[12] = ang.z;
+}
+// rows of link `li` and of the bodies welded to it
+__device__ __forceinline__ void write_link_rows(const TAConsts& C, const LinkC& L, int li, const M3& Rw, V3 pw, V3 w, V3 v, float* rb) {
+    V3 ang = mul(Rw, w);
+    write_row(rb + L.body * 13, Rw, pw, mul(Rw, v), ang);
+    for (int f = 0; f < PPENV_TA_NUM_FIXED; f++)
+        if (C.fixed[f].link == li) {
+            V3 p, vel;
+            point_of(Rw, pw, w, v, ld3(C.fixed[f].xyz), p, vel);
+            write_row(rb + C.fixed[f].body * 13, mul(Rw, ldm(C.fixed[f].rot)), p, vel, ang);
+        }
+}
+
+template <bool STEP>
+__global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restrict__ Cp, const StepConsts K, int n, const float* __restrict__ actions,
+                                                         float* root_states, float* dof_states, float* __restrict__ rb_states,
+                                                         float* __restrict__ dof_force, float* __restrict__ pre_vx) {
+    __shared__ LinkC s_link[NL];
+    __shared__ float s_rec[kChainLen * kRec * 64];
+    __shared__ float s_q[NDOF][kQuadEnvs], s_qd[NDOF][kQuadEnvs], s_target[NDOF][kQuadEnvs], s_force[NDOF][kQuadEnvs];
+    const TAConsts& C = *Cp;
+    const int lane = threadIdx.x, role = lane & 3, es = lane >> 2;
+    const int e = blockIdx.x * kQuadEnvs + es;
+    const bool live = e < n;
+    {   // the link table into LDS: the lanes of a quad visit different links, so its reads are per-lane from here on
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(C.link);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_link);
+        for (int t = lane; t < (int)(sizeof(LinkC) * NL / 4); t += 64) dst[t] = src[t];
+    }
+    float* root = root_states + (size_t)(live ? e : 0) * 39;
+    float* dofs = dof_states + (size_t)(live ? e : 0) * 2 * NDOF;
+    for (int d = role; d < NDOF; d += 4) {   // the quad shares its env's dof rows
+        s_q[d][es] = dofs[2 * d];
+        s_qd[d][es] = dofs[2 * d + 1];
+        if (STEP) {
+            float a = fminf(fmaxf(actions[(size_t)(live ? e : 0) * NDOF + d], -C.clip_actions), C.clip_actions);   // VecTask.step clamp
+            const float lo = C.link[d + 1].lo, hi = C.link[d + 1].hi;
+            s_target[d][es] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;                                            // TA:1131, 729-733
+            s_force[d][es] = 0.f;
+        }
+    }
+    __syncthreads();   // one wave: orders the LDS fills above against the reads below
+    BaseState base;
+    load_base(root, base);
+    QuadRec rc{&s_rec[lane]};
+    Ball ball;
+    if (STEP) {
+        float* bl = root + 26;
+        ball.p = mk(bl[0], bl[1], bl[2]);
+        for (int k = 0; k < 4; k++) ball.quat[k] = bl[3 + k];
+        ball.v = mk(bl[7], bl[8], bl[9]);
+        ball.w = mk(bl[10], bl[11], bl[12]);
+        if (live && role == 0) pre_vx[e] = ball.v.x;                                                               // TA:1143
+
+        for (int sub = 0; sub < C.substeps; sub++) {
+            // ---- pass 1: kinematics + each link's own inertia / bias / contacts, base -> tip of this lane's limb
+            M3 Rw = quat_to_m3(base.quat);
+            V3 pw = base.p, w = tmul(Rw, base.ww), v = tmul(Rw, base.vw);
+            const M3 R0 = Rw;
+            const V3 w0 = w, v0 = v;
+            ArtI I0 = link_dynamics(C, s_link[0], Rw, pw, w, v);     // the pelvis: every lane of the quad computes it
+            ArmGeom<ModelG1TA::kShapes> g[1];
+            V3 bound[1];
+            capture_geometry(C, 0, Rw, pw, w, v, g[0], bound[0]);
+            for (int k = 0; k < kChainLen; k++) {
+                const int li = kChains[role][k];
+                if (li < 0) continue;
+                const LinkC& L = s_link[li];
+                float c, s;
+                link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, c, s);
+                rc(k, R_C) = c; rc(k, R_S) = s;
+                rc(k, R_W) = w.x; rc(k, R_W + 1) = w.y; rc(k, R_W + 2) = w.z;
+                rc(k, R_V) = v.x; rc(k, R_V + 1) = v.y; rc(k, R_V + 2) = v.z;
+                rec_store_art(rc, k, link_dynamics(C, L, Rw, pw, w, v));
+                capture_geometry(C, li, Rw, pw, w, v, g[0], bound[0]);   // complete on the right-arm lane (pelvis, torso, right arm)
+            }
+            // ---- pass 2: articulated inertias tip -> base; the arms meet at the torso, everything at the pelvis
+            ArtI acc = art_zero();
+            for (int k = kChainLen - 1; k >= 0; k--) {
+                if (k == kHubPos) {
+                    ArtI other = art_shfl_xor(acc, 1);                   // lanes 2 <-> 3 (and, unused, 0 <-> 1)
+                    if (role >= 2) add_art(acc, other);
+                }
+                const int li = kChains[role][k];
+                if (li < 0) continue;
+                const LinkC& L = s_link[li];
+                ArtI I = rec_load_art(rc, k);
+                add_art(I, acc);
+                JointOut jo;
+                inward_step(C, L, I, mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), rc(k, R_C), rc(k, R_S),
+                            s_q[li - 1][es], s_qd[li - 1][es], s_target[li - 1][es], jo);
+                rc(k, R_JO) = jo.ua.x; rc(k, R_JO + 1) = jo.ua.y; rc(k, R_JO + 2) = jo.ua.z;
+                rc(k, R_JO + 3) = jo.ub.x; rc(k, R_JO + 4) = jo.ub.y; rc(k, R_JO + 5) = jo.ub.z;
+                rc(k, R_JO + 6) = jo.dinv; rc(k, R_JO + 7) = jo.u;
+                acc = I;
+            }
+            if (role == 3) acc = art_zero();                             // its waist chain duplicates lane 2's
+            {
+                ArtI t = art_shfl_xor(acc, 1);
+                add_art(acc, t);
+                t = art_shfl_xor(acc, 2);
+                add_art(acc, t);
+            }
+            add_art(I0, acc);
+            V3 alpha, a;
+            solve_base_art(I0, alpha, a);
+            // ---- pass 3: accelerations base -> tip, joints integrated on the way
+            V3 aw = alpha, av = a;
+            for (int k = 0; k < kChainLen; k++) {
+                const int li = kChains[role][k];
+                if (li < 0) continue;
+                const LinkC& L = s_link[li];
+                JointOut jo = {mk(rc(k, R_JO), rc(k, R_JO + 1), rc(k, R_JO + 2)), mk(rc(k, R_JO + 3), rc(k, R_JO + 4), rc(k, R_JO + 5)), rc(k, R_JO + 6),
+                               rc(k, R_JO + 7)};
+                float q = s_q[li - 1][es], qd = s_qd[li - 1][es], force;
+                outward_step(C, L, rc(k, R_C), rc(k, R_S), mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), jo,
+                             aw, av, s_target[li - 1][es], q, qd, force);
+                if (!(role == 3 && k < 3)) {                             // the waist dofs are written by lane 2
+                    s_q[li - 1][es] = q; s_qd[li - 1][es] = qd; s_force[li - 1][es] = force;
+                }
+            }
+            integrate_base_regs(C, R0, w0, v0, base, alpha, a);
+            if (role == 3) ball_substep<ModelG1TA, 1>(K, ball, g, bound);
+            __builtin_amdgcn_wave_barrier();                             // lane 2's waist dofs before every lane's next pass 1
+        }
+        if (live) {
+            if (role == 0) {
+                root[0] = base.p.x; root[1] = base.p.y; root[2] = base.p.z;
+                for (int k = 0; k < 4; k++) root[3 + k] = base.quat[k];
+                root[7] = base.vw.x; root[8] = base.vw.y; root[9] = base.vw.z;
+                root[10] = base.ww.x; root[11] = base.ww.y; root[12] = base.ww.z;
+            }
+            if (role == 3) {
+                float* bl = root + 26;
+                bl[0] = ball.p.x; bl[1] = ball.p.y; bl[2] = ball.p.z;
+                for (int k = 0; k < 4; k++) bl[3 + k] = ball.quat[k];
+                bl[7] = ball.v.x; bl[8] = ball.v.y; bl[9] = ball.v.z; bl[10] = ball.w.x; bl[11] = ball.w.y; bl[12] = ball.w.z;
+            }
+            for (int d = role; d < NDOF; d += 4) {
+                dofs[2 * d] = s_q[d][es];
+                dofs[2 * d + 1] = s_qd[d][es];
+                dof_force[(size_t)e * NDOF + d] = s_force[d][es];
+            }
+        }
+    }
+    // ---- gym.refresh_rigid_body_state_tensor: every lane writes the rows of its limb (the waist rows: lane 2)
+    if (live) {
+        float* rb = rb_states + (size_t)e * PPENV_NUM_BODIES * 13;
+        M3 Rw = quat_to_m3(base.quat);
+        V3 pw = base.p, w = tmul(Rw, base.ww), v = tmul(Rw, base.vw);
+        if (role == 0) write_link_rows(C, s_link[0], 0, Rw, pw, w, v, rb);
+        for (int k = 0; k < kChainLen; k++) {
+            const int li = kChains[role][k];
+            if (li < 0) continue;
+            const LinkC& L = s_link[li];
+            float c, s;
+            link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, c, s);
+            if (!(role == 3 && k < 3)) write_link_rows(C, L, li, Rw, pw, w, v, rb);
+        }
+        if (role == 1) {
+            const float* tr = root + 13;   // table row: untouched by the step
+            for (int k = 0; k < 13; k++) rb[40 * 13 + k] = tr[k];
+        }
+        if (role == 3) {                   // ball row: this lane holds the stepped ball
+            if (STEP) {
+                const float bl[13] = {ball.p.x, ball.p.y, ball.p.z, ball.quat[0], ball.quat[1], ball.quat[2], ball.quat[3],
+                                      ball.v.x, ball.v.y, ball.v.z, ball.w.x, ball.w.y, ball.w.z};
+                for (int k = 0; k < 13; k++) rb[41 * 13 + k] = bl[k];
+            } else {
+                for (int k = 0; k < 13; k++) rb[41 * 13 + k] = root[26 + k];
+            }
+        }
+    }
+}
+
+// does the model have the tree the quad kernel's chains are written for?
+bool quad_topology(const TAConsts& C) {
+    static const int parents[NL] = {-1, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10, 11, 0, 13, 14, 15, 16, 17, 18, 19, 20, 21, 15, 23, 24, 25, 26};
+    for (int i = 0; i < NL; i++)
+        if (C.link[i].parent != parents[i]) return false;
+    return true;
+}
 }  // namespace
 
 struct ppenv_ta_sim {
@@ -93,6 +353,7 @@ struct ppenv_ta_sim {
     TAConsts* dev;
     StepConsts K;
     int device;
+    int quad;     // 1: ta_sim_quad_kernel (four lanes per env), 0: ta_sim_kernel (one lane per env; any tree)
 };
 
 extern "C" {
@@ -113,6 +374,10 @@ int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, 
     }
     s->K = make_step_consts(*scene);
     s->dev = nullptr;
+    {   // PPENV_TA_KERNEL=lane|quad forces a mapping (same arithmetic; the quad kernel needs the G1 tree)
+        const char* k = getenv("PPENV_TA_KERNEL");
+        s->quad = quad_topology(s->host) && !(k && strcmp(k, "lane") == 0);
+    }
     if (hipGetDevice(&s->device) != hipSuccess || hipMalloc((void**)&s->dev, sizeof(TAConsts)) != hipSuccess) {
         ppenv_set_error("ppenv_ta_sim_create: hipMalloc of the model constants failed");
         delete s;
@@ -141,8 +406,12 @@ int ppenv_ta_simulate(ppenv_ta_sim* s, int32_t n, const float* actions_dev, floa
         ppenv_set_error("ppenv_ta_simulate: NULL argument or num_envs <= 0");
         return PPENV_EINVAL;
     }
-    hipLaunchKernelGGL(ta_sim_kernel<true>, dim3((n + kTaLanes - 1) / kTaLanes), dim3(kTaLanes), 0, (hipStream_t)stream, s->dev, s->K, n, actions_dev,
-                       root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev);
+    if (s->quad)
+        hipLaunchKernelGGL(ta_sim_quad_kernel<true>, dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->K, n, actions_dev,
+                           root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev);
+    else
+        hipLaunchKernelGGL(ta_sim_kernel<true>, dim3((n + kTaLanes - 1) / kTaLanes), dim3(kTaLanes), 0, (hipStream_t)stream, s->dev, s->K, n, actions_dev,
+                           root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching ta_sim_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }
@@ -153,9 +422,14 @@ int ppenv_ta_forward_kinematics(ppenv_ta_sim* s, int32_t n, const float* root_st
         ppenv_set_error("ppenv_ta_forward_kinematics: NULL argument or num_envs <= 0");
         return PPENV_EINVAL;
     }
-    hipLaunchKernelGGL(ta_sim_kernel<false>, dim3((n + kTaLanes - 1) / kTaLanes), dim3(kTaLanes), 0, (hipStream_t)stream, s->dev, s->K, n,
-                       (const float*)nullptr, const_cast<float*>(root_states_dev), const_cast<float*>(dof_states_dev), rb_states_dev,
-                       (float*)nullptr, (float*)nullptr);
+    if (s->quad)
+        hipLaunchKernelGGL(ta_sim_quad_kernel<false>, dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->K, n,
+                           (const float*)nullptr, const_cast<float*>(root_states_dev), const_cast<float*>(dof_states_dev), rb_states_dev,
+                           (float*)nullptr, (float*)nullptr);
+    else
+        hipLaunchKernelGGL(ta_sim_kernel<false>, dim3((n + kTaLanes - 1) / kTaLanes), dim3(kTaLanes), 0, (hipStream_t)stream, s->dev, s->K, n,
+                           (const float*)nullptr, const_cast<float*>(root_states_dev), const_cast<float*>(dof_states_dev), rb_states_dev,
+                           (float*)nullptr, (float*)nullptr);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching ta_sim_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }

@@ -145,10 +145,13 @@ def test_long_run_stays_physical(oracle_lib):
 
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [512, 50])
-def test_ta_simulate_kernel_matches_oracle(oracle_lib, n):
+@pytest.mark.parametrize("mapping,n", [("quad", 512), ("quad", 50), ("lane", 200)])
+def test_ta_simulate_kernel_matches_oracle(oracle_lib, monkeypatch, mapping, n):
+    """Both mappings of the rigid-body step — four lanes per env (one per limb, hub merges through quad shuffles) and one
+    lane per env (any tree) — against the oracle; n = 50 / 200 leave ragged last workgroups."""
     import torch
     from isaacgym_amd.tensor_api import TASim
+    monkeypatch.setenv("PPENV_TA_KERNEL", mapping)
     cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
     sim = TASim(n, device="cuda:0")
     root, dof = initial_tensors(n, seed=1)

@@ -7,7 +7,9 @@ rc=$?; tail -5 gpurun_out/pytest_ta.log; [ $rc -ne 0 ] && { tail -60 gpurun_out/
 timeout -k 10 300 python - <<'PY'
 import time, torch
 from isaacgym_amd.tensor_api import TAEnv
-for n in (4096, 16384):
+import os
+for mapping, n in (("quad", 4096), ("lane", 4096), ("quad", 16384)):
+    os.environ["PPENV_TA_KERNEL"] = mapping
     env = TAEnv(n, device="cuda:0")
     gen = torch.Generator(device="cuda").manual_seed(0)
     pool = [torch.rand(n, 27, device="cuda", generator=gen) * 2 - 1 for _ in range(8)]
@@ -19,6 +21,6 @@ for n in (4096, 16384):
     for s in range(K): env.step(pool[s & 7])
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / K
-    print("TA n=%d  step %.1f us  %.1f M env-steps/s" % (n, us, n / us))
+    print("TA %s n=%d  step %.1f us  %.1f M env-steps/s" % (mapping, n, us, n / us))
     env.close()
 PY
