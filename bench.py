@@ -30,11 +30,13 @@ if ROOT not in sys.path:
 NUM_ENVS = 16384
 VARIANT = "TT"
 WORKLOAD_NAMES = {"TT": "3-actor tilt (HumanoidPingpongTiltG1)", "TN": "3-actor tilt, no early stop (HumanoidPingpongTiltNoEarlyStopG1)",
-                  "T3": "3-actor (HumanoidPingpongG1)", "T4": "4-actor tilt (Humanoid12PingpongTiltG1: two humanoids, two agent rows per env)"}
+                  "T3": "3-actor (HumanoidPingpongG1)", "T4": "4-actor tilt (Humanoid12PingpongTiltG1: two humanoids, two agent rows per env)",
+                  "TA": "3-actor all-dof (HumanoidPingpongTiltNESSparse27DOF: free-floating 27-dof humanoid, 313 observations)"}
 HORIZON = 32
 # SURVEY.md §8(d) "minimal algorithmic bytes / env-step": 7-DoF variants R 156 + W 452 = 608; 4-actor ("~1.1 KB"): R actions 56 +
 # q,qd 112 + ball 52 + progress/flags/prev-vx 16 + rng 8 = 244, W q,qd 112 + ball 52 + misc 24 + obs 640 + rew 8 + reset 8 = 844
-ALGO_BYTES = {"TT": 608, "TN": 608, "T3": 608, "T4": 1088}
+# 27-dof ("~2.0 KB"): R 444 + W 1596 (obs 1252)
+ALGO_BYTES = {"TT": 608, "TN": 608, "T3": 608, "T4": 1088, "TA": 2040}
 ALGO_BYTES_PER_ENV_STEP = ALGO_BYTES["TT"]
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -60,6 +62,8 @@ def cpu_baseline(num_envs, target_seconds=12.0, variant=VARIANT):
     from oracle import binding as ob
     ob.build()
     cores = usable_cores()
+    if variant == "TA":
+        return cpu_baseline_ta(num_envs, cores, target_seconds)
     env = ob.OracleEnv(scene.build_config(variant, num_envs=num_envs, seed=0), threads=cores)
     rng = np.random.default_rng(0)
     actions = [rng.uniform(-1, 1, (num_envs * env.num_agents, 7)).astype(np.float32) for _ in range(4)]
@@ -74,6 +78,35 @@ def cpu_baseline(num_envs, target_seconds=12.0, variant=VARIANT):
             break
     return {"value": num_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps of the {variant} variant at num_envs={num_envs}, OpenMP over envs, {dt:.1f} s"}
+
+
+def cpu_baseline_ta(num_envs, cores, target_seconds):
+    """27-dof variant: the oracle's rigid-body step (OpenMP over envs) + its post_physics_step (one thread)."""
+    import numpy as np
+    from isaacgym_amd import scene
+    from oracle import binding as ob
+    n = num_envs
+    cfg, model, p = scene.build_ta_scene(n), scene.build_ta_model(), scene.build_ta_params(n)
+    root = np.zeros((n, 3, 13), np.float32)
+    for a in range(3):
+        root[:, a, :7] = np.array(list(p.init_root[a]))
+    root[:, 2, 7:10] = (-5.0, 0.0, 1.5)
+    dof = np.zeros((n, 27, 2), np.float32)
+    irb = ob.ta_forward_kinematics(model, root, dof)
+    flags, episode, progress = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64)
+    rng = np.random.default_rng(0)
+    actions = [rng.uniform(-1, 1, (n, 27)).astype(np.float32) for _ in range(4)]
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        rb, frc, pvx = ob.ta_simulate(cfg, model, actions[steps % 4], root, dof, threads=cores)
+        ob.ta_post_physics_step(p, rb, irb, root, dof, frc, pvx, None, flags, episode, progress)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or steps >= 2000:
+            break
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of the TA variant at num_envs={n}, OpenMP over envs in the rigid-body step, {dt:.1f} s"}
 
 
 def pmc_traffic(num_envs):
@@ -94,6 +127,8 @@ def kernel_name(variant):
     forced; three waves (two arm waves + the ball wave) for the 4-actor variant."""
     if variant == "T4":
         return "step_kernel_split<ModelG1, 2>"
+    if variant == "TA":
+        return "ta_sim_quad_kernel<true>" if os.environ.get("PPENV_TA_KERNEL") != "lane" else "ta_sim_kernel<true>"
     split = os.environ.get("PPENV_STEP_KERNEL") != "fused"
     return "step_kernel_split<ModelG1, 1>" if split else "step_kernel<ModelG1>"
 
@@ -105,7 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", default=VARIANT, choices=["TT", "TN", "T3", "T4"],
+    ap.add_argument("--variant", default=VARIANT, choices=["TT", "TN", "T3", "T4", "TA"],
                     help="task variant; the headline workload is TT (BASELINE.json configs[2]), the others are parity-test cases")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL (default); gloo only to rehearse the rank logic on one GPU")
     args = ap.parse_args()
@@ -140,13 +175,21 @@ def main():
 
     n = args.num_envs
     off, cnt = D.shard_range(n * world, rank, world)   # contiguous global env ids; trajectories do not depend on the split
-    env = PPEnv(scene.build_config(args.variant, num_envs=cnt, seed=0, device_id=device.index, env_id_offset=off), device=device)
     gen = torch.Generator(device=device).manual_seed(rank)
-    pool = [(torch.rand(n * env.num_agents, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
-    stats = D.AsyncHorizonStats(env)   # what the reference prints every 40 steps (TT:763-766) + finished episodes
+    if args.variant == "TA":           # the 27-dof task: rigid-body kernel + task kernel on Isaac-Gym-layout tensors
+        from isaacgym_amd.tensor_api import TAEnv
+        with torch.cuda.device(device):
+            env = TAEnv(cnt, device=device, seed=0, env_id_offset=off)
+        pool = [(torch.rand(n, 27, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
+        stats = None
+    else:
+        env = PPEnv(scene.build_config(args.variant, num_envs=cnt, seed=0, device_id=device.index, env_id_offset=off), device=device)
+        pool = [(torch.rand(n * env.num_agents, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
+        stats = D.AsyncHorizonStats(env)   # what the reference prints every 40 steps (TT:763-766) + finished episodes
 
     def horizon_stats():
-        stats.push()                   # one reduction launch + one asynchronous 4-double all-reduce over RCCL
+        if stats is not None:
+            stats.push()               # one reduction launch + one asynchronous 4-double all-reduce over RCCL
 
     def run(k):
         for s in range(k):
@@ -185,7 +228,10 @@ def main():
     torch.cuda.synchronize(device)
     kernel_us = ev0.elapsed_time(ev1) * 1e3 / kreg
     horizon_stats()
-    final_stats = stats.latest().cpu().tolist()
+    if stats is not None:
+        final_stats = stats.latest().cpu().tolist()
+    else:
+        final_stats = [float(env.rew_buf.mean()), float(env.progress_buf.float().mean()), float(env.state.episode.sum())]
 
     if rank == 0:
         total_env_steps = n * world * args.steps

@@ -12,7 +12,7 @@ using namespace pp;
 
 namespace {
 
-constexpr int kTaBlock = 64;
+constexpr int kTaBlock = 16;   // one lane per env with strided AoS rows: small workgroups spread the envs over all CUs (4096 envs -> 256 workgroups)
 constexpr int TA_ND = PPENV_TA_NUM_DOF;
 constexpr int TA_NBAL = PPENV_TA_NUM_BALANCE_BODIES;
 

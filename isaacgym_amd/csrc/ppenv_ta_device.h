@@ -21,17 +21,16 @@ constexpr int NDOF = PPENV_TA_NUM_DOF;
 
 // ---- constants of the tree, derived once on the host (make_ta_consts) and read from global memory by the kernels
 struct LinkC {
-    int32_t parent, axis, body, cfirst, ccount, pad_[3];   // contacts [cfirst, cfirst + ccount) sit on this link
+    int32_t parent, axis, body, cfirst, ccount;            // contacts [cfirst, cfirst + ccount) sit on this link
+    int32_t geo_mask, pad_[2];                              // bit s: ball-collision shape s rides on this link; bit 6 paddle; bit 7 bound centre
     float r[3], R0[9];                                      // child frame in the parent frame at q = 0
     float mass, mc[3], Io[6];                               // m, m * com, inertia about the link ORIGIN (xx yy zz xy xz yz)
     float lo, hi, kp, kd, effort, vlim, armature;
 };
 struct FixedC { int32_t body, link, pad_[2]; float xyz[3], rot[9]; };
-struct TAConsts {
-    LinkC link[NL];
-    FixedC fixed[PPENV_TA_NUM_FIXED];
+// the scalars and small tables: ~70 dwords, small enough to travel by value in a kernel argument
+struct TAScal {
     int32_t num_contacts, paddle_link, bound_link, num_shapes;
-    float cpoint[PPENV_TA_MAX_CONTACTS][3];                 // sorted by link
     int32_t shape_link[PPENV_MAX_SHAPES];
     float shape_a[PPENV_MAX_SHAPES][3], shape_b[PPENV_MAX_SHAPES][3];
     float paddle_center[3], paddle_normal[3], bound_center[3];
@@ -39,6 +38,12 @@ struct TAConsts {
     float k_lim, c_lim, c_vlim;
     float gravity_z, h, clip_actions;
     int32_t substeps;
+};
+struct TAConsts {
+    TAScal sc;
+    LinkC link[NL];
+    FixedC fixed[PPENV_TA_NUM_FIXED];
+    float cpoint[PPENV_TA_MAX_CONTACTS][3];                 // sorted by link
 };
 
 // ---- per-lane storage layout: NL link records, then NDOF dof records
@@ -84,7 +89,8 @@ struct ArtI { S3 A; M3 B; S3 D; V3 pn, pf; };        // articulated inertia [A B
 struct JointOut { V3 ua, ub; float dinv, u; };       // what the outward pass needs from the inward one
 
 // Rigid-body inertia, velocity-product and gravity bias, ground contacts of one link (link coordinates, about its origin).
-PP_HD ArtI link_dynamics(const TAConsts& C, const LinkC& L, const M3& Rw, V3 pw, V3 w, V3 v) {
+// cpoint: the contact-point table (C.cpoint, or a copy of it nearer to the lanes).
+PP_HD ArtI link_dynamics(const TAScal& C, const LinkC& L, const float (*cpoint)[3], const M3& Rw, V3 pw, V3 w, V3 v) {
     S3 A = sym_from(L.Io);
     V3 mc = ld3(L.mc);
     const float m = L.mass;
@@ -99,7 +105,7 @@ PP_HD ArtI link_dynamics(const TAConsts& C, const LinkC& L, const M3& Rw, V3 pw,
     S3 D = {m, m, m, 0.f, 0.f, 0.f};
     const V3 zb = mk(Rw.m[6], Rw.m[7], Rw.m[8]);           // world z axis in link coordinates
     for (int k = L.cfirst; k < L.cfirst + L.ccount; k++) {
-        V3 r = ld3(C.cpoint[k]);
+        V3 r = ld3(cpoint[k]);
         V3 pc = pw + mul(Rw, r);
         float pen = C.ground_z - pc.z;
         if (!(pen > 0.f)) continue;
@@ -152,7 +158,7 @@ PP_HD void link_kinematics(const LinkC& L, float q, float qd, M3& Rw, V3& pw, V3
 
 // drive + limit torques of dof d at the start of a substep (implicit PD with its explicit part clamped to the effort
 // limit; limit spring-damper and velocity-cap damper implicit): torque and the joint-space inertia they add
-PP_HD void joint_torque(const TAConsts& C, const LinkC& L, float q, float qd, float target, float& tau, float& arm) {
+PP_HD void joint_torque(const TAScal& C, const LinkC& L, float q, float qd, float target, float& tau, float& arm) {
     const float h = C.h;
     float err = target - q;
     tau = fminf(fmaxf(L.kp * (err - h * qd) - L.kd * qd, -L.effort), L.effort);   // implicit PD, explicit part within the effort limit
@@ -176,7 +182,7 @@ PP_HD void joint_torque(const TAConsts& C, const LinkC& L, float q, float qd, fl
 // One joint of the inward pass (RBDA 9.4 with the drive's implicit terms on the joint diagonal).
 // I: in = the link's articulated inertia and bias (own + children, link coordinates); out = its contribution to the
 // parent (parent coordinates, about the parent's origin).
-PP_HD void inward_step(const TAConsts& C, const LinkC& L, ArtI& I, V3 w, V3 v, float c, float s, float q, float qd, float target, JointOut& jo) {
+PP_HD void inward_step(const TAScal& C, const LinkC& L, ArtI& I, V3 w, V3 v, float c, float s, float q, float qd, float target, JointOut& jo) {
     const int ax = L.axis;
     float tau, arm;
     joint_torque(C, L, q, qd, target, tau, arm);
@@ -218,7 +224,7 @@ PP_HD void inward_step(const TAConsts& C, const LinkC& L, ArtI& I, V3 w, V3 v, f
 
 // One joint of the outward pass: the link's acceleration from its parent's (aw, av: in = parent's, out = the link's), and
 // the joint's semi-implicit Euler update with the reported drive torque.
-PP_HD void outward_step(const TAConsts& C, const LinkC& L, float c, float s, V3 w, V3 v, const JointOut& jo, V3& aw, V3& av,
+PP_HD void outward_step(const TAScal& C, const LinkC& L, float c, float s, V3 w, V3 v, const JointOut& jo, V3& aw, V3& av,
                         float target, float& q, float& qd, float& force) {
     const int ax = L.axis;
     M3 E = joint_rot_rt(L.R0, ax, c, s);
@@ -253,7 +259,7 @@ PP_HD void pass_kinematics(const TAConsts& C, Store& st, const BaseState& b) {
         M3 Rw = quat_to_m3(b.quat);
         V3 w = tmul(Rw, b.ww), v = tmul(Rw, b.vw);
         stv(st, F_W, w); stv(st, F_V, v); stm3(st, F_RW, Rw); stv(st, F_PW, b.p);
-        if (DYN) store_art(st, 0, link_dynamics(C, C.link[0], Rw, b.p, w, v));
+        if (DYN) store_art(st, 0, link_dynamics(C.sc, C.link[0], C.cpoint, Rw, b.p, w, v));
     }
     for (int i = 1; i < NL; i++) {
         const LinkC& L = C.link[i];
@@ -265,7 +271,7 @@ PP_HD void pass_kinematics(const TAConsts& C, Store& st, const BaseState& b) {
         link_kinematics(L, q, qd, Rw, pw, w, v, c, s);
         st(o + F_C) = c; st(o + F_S) = s;
         stv(st, o + F_W, w); stv(st, o + F_V, v); stm3(st, o + F_RW, Rw); stv(st, o + F_PW, pw);
-        if (DYN) store_art(st, o, link_dynamics(C, L, Rw, pw, w, v));
+        if (DYN) store_art(st, o, link_dynamics(C.sc, L, C.cpoint, Rw, pw, w, v));
     }
 }
 
@@ -277,7 +283,7 @@ PP_HD void pass_inertia(const TAConsts& C, Store& st) {
         const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, dofo = DOF_BASE + (i - 1) * DOF_STRIDE;
         ArtI I = load_art(st, o);
         JointOut jo;
-        inward_step(C, L, I, ldv(st, o + F_W), ldv(st, o + F_V), st(o + F_C), st(o + F_S), st(dofo + G_Q), st(dofo + G_QD), st(dofo + G_TARGET), jo);
+        inward_step(C.sc, L, I, ldv(st, o + F_W), ldv(st, o + F_V), st(o + F_C), st(o + F_S), st(dofo + G_Q), st(dofo + G_QD), st(dofo + G_TARGET), jo);
         // the link's own record is consumed: keep what pass 3 needs in its place
         stv(st, o + F_UA, jo.ua); stv(st, o + F_UB, jo.ub); st(o + F_DINV) = jo.dinv; st(o + F_U) = jo.u;
         ArtI P = load_art(st, po);
@@ -318,14 +324,14 @@ PP_HD void pass_accelerate(const TAConsts& C, Store& st, V3 alpha0, V3 a0) {
         V3 aw = ldv(st, po + F_AW), av = ldv(st, po + F_AV);
         JointOut jo = {ldv(st, o + F_UA), ldv(st, o + F_UB), st(o + F_DINV), st(o + F_U)};
         float q = st(dofo + G_Q), qd = st(dofo + G_QD), force;
-        outward_step(C, L, st(o + F_C), st(o + F_S), ldv(st, o + F_W), ldv(st, o + F_V), jo, aw, av, st(dofo + G_TARGET), q, qd, force);
+        outward_step(C.sc, L, st(o + F_C), st(o + F_S), ldv(st, o + F_W), ldv(st, o + F_V), jo, aw, av, st(dofo + G_TARGET), q, qd, force);
         stv(st, o + F_AW, aw); stv(st, o + F_AV, av);
         st(dofo + G_FORCE) = force; st(dofo + G_Q) = q; st(dofo + G_QD) = qd;
     }
 }
 
 // base: semi-implicit Euler in world coordinates (classical acceleration of the origin = R (a + w x v))
-PP_HD void integrate_base_regs(const TAConsts& C, const M3& Rw, V3 wb, V3 vb, BaseState& b, V3 alpha, V3 a) {
+PP_HD void integrate_base_regs(const TAScal& C, const M3& Rw, V3 wb, V3 vb, BaseState& b, V3 alpha, V3 a) {
     V3 aw = mul(Rw, a + cross(wb, vb)), alw = mul(Rw, alpha);
     const float h = C.h;
     b.vw = madd(b.vw, aw, h);
@@ -341,7 +347,7 @@ PP_HD void integrate_base_regs(const TAConsts& C, const M3& Rw, V3 wb, V3 vb, Ba
 }
 template <class Store>
 PP_HD void integrate_base(const TAConsts& C, Store& st, BaseState& b, V3 alpha, V3 a) {
-    integrate_base_regs(C, ldm3(st, F_RW), ldv(st, F_W), ldv(st, F_V), b, alpha, a);
+    integrate_base_regs(C.sc, ldm3(st, F_RW), ldv(st, F_W), ldv(st, F_V), b, alpha, a);
 }
 
 // world position / velocity of a point fixed in link `link` (after pass_kinematics)
@@ -356,17 +362,17 @@ PP_HD void point_state(Store& st, int link, V3 r, V3& p, V3& v) {
 // ball-collision geometry of the humanoid at the start of a substep
 template <int NSHAPES, class Store>
 PP_HD void collision_geometry(const TAConsts& C, Store& st, ArmGeom<NSHAPES>& g, V3& bound) {
-    const int po = C.paddle_link * LINK_STRIDE;
+    const int po = C.sc.paddle_link * LINK_STRIDE;
     M3 Rp = ldm3(st, po + F_RW);
-    point_state(st, C.paddle_link, ld3(C.paddle_center), g.pc, g.vpc);
-    g.pn = mul(Rp, ld3(C.paddle_normal));
+    point_state(st, C.sc.paddle_link, ld3(C.sc.paddle_center), g.pc, g.vpc);
+    g.pn = mul(Rp, ld3(C.sc.paddle_normal));
     g.pnd = cross(mul(Rp, ldv(st, po + F_W)), g.pn);
     for (int s = 0; s < NSHAPES; s++) {
-        point_state(st, C.shape_link[s], ld3(C.shape_a[s]), g.a[s], g.va[s]);
-        point_state(st, C.shape_link[s], ld3(C.shape_b[s]), g.b[s], g.vb[s]);
+        point_state(st, C.sc.shape_link[s], ld3(C.sc.shape_a[s]), g.a[s], g.va[s]);
+        point_state(st, C.sc.shape_link[s], ld3(C.sc.shape_b[s]), g.b[s], g.vb[s]);
     }
     V3 dummy;
-    point_state(st, C.bound_link, ld3(C.bound_center), bound, dummy);
+    point_state(st, C.sc.bound_link, ld3(C.sc.bound_center), bound, dummy);
 }
 
 // the compiled shape radii / paddle blade are the 3-actor model's; here every shape rides on a moving link
@@ -377,7 +383,7 @@ struct ModelG1TA : ModelG1 {
 // One pre_physics_step + gym.simulate for one env.  q / qd / target live in the store; base and ball in registers.
 template <class Store>
 PP_HD void simulate_env_ta(const TAConsts& C, const StepConsts& K, Store& st, BaseState& base, Ball& ball) {
-    for (int s = 0; s < C.substeps; s++) {
+    for (int s = 0; s < C.sc.substeps; s++) {
         pass_kinematics<true>(C, st, base);
         ArmGeom<ModelG1TA::kShapes> g[1];
         V3 bound[1];
@@ -458,20 +464,23 @@ inline bool make_ta_consts(const ppenv_config& scene, const ppenv_ta_model& m, T
         for (int k = 0; k < 3; k++) C.fixed[f].xyz[k] = s.xyz[k];
         for (int k = 0; k < 9; k++) C.fixed[f].rot[k] = s.rot[k];
     }
-    C.num_contacts = m.num_contacts; C.paddle_link = scene.paddle_link; C.bound_link = m.bound_link; C.num_shapes = scene.num_shapes;
-    if (C.paddle_link < 0 || C.paddle_link >= NL || C.bound_link < 0 || C.bound_link >= NL) { *why = "paddle_link / bound_link out of range"; return false; }
+    C.sc.num_contacts = m.num_contacts; C.sc.paddle_link = scene.paddle_link; C.sc.bound_link = m.bound_link; C.sc.num_shapes = scene.num_shapes;
+    if (C.sc.paddle_link < 0 || C.sc.paddle_link >= NL || C.sc.bound_link < 0 || C.sc.bound_link >= NL) { *why = "paddle_link / bound_link out of range"; return false; }
     for (int s = 0; s < scene.num_shapes; s++) {
         if (scene.shape[s].link < 0 || scene.shape[s].link >= NL) { *why = "scene.shape[].link must index the 28-link tree"; return false; }
         if (scene.shape[s].radius != ModelG1TA::shape(s).radius) { *why = "scene.shape[].radius differs from the compiled shape set"; return false; }
-        C.shape_link[s] = scene.shape[s].link;
-        for (int k = 0; k < 3; k++) { C.shape_a[s][k] = scene.shape[s].a[k]; C.shape_b[s][k] = scene.shape[s].b[k]; }
+        C.sc.shape_link[s] = scene.shape[s].link;
+        for (int k = 0; k < 3; k++) { C.sc.shape_a[s][k] = scene.shape[s].a[k]; C.sc.shape_b[s][k] = scene.shape[s].b[k]; }
     }
-    for (int k = 0; k < 3; k++) { C.paddle_center[k] = scene.paddle_center[k]; C.paddle_normal[k] = scene.paddle_normal[k]; C.bound_center[k] = m.bound_center[k]; }
-    C.ground_z = m.ground_z; C.k_n = m.foot_stiffness; C.c_n = m.foot_damping; C.c_t = m.foot_tangent_damping; C.mu = m.foot_friction;
-    C.pen_max = m.contact_max_penetration; C.fade_depth = m.contact_fade_depth; C.fade_force = m.contact_fade_force;
-    if (!(C.fade_depth > 0.f) || !(C.fade_force > 0.f)) { *why = "contact_fade_depth / contact_fade_force must be positive"; return false; }
-    C.k_lim = m.limit_stiffness; C.c_lim = m.limit_damping; C.c_vlim = m.vel_limit_damping;
-    C.gravity_z = scene.gravity_z; C.substeps = scene.substeps; C.h = scene.dt / (float)scene.substeps; C.clip_actions = scene.clip_actions;
+    for (int s = 0; s < scene.num_shapes; s++) C.link[C.sc.shape_link[s]].geo_mask |= 1 << s;
+    C.link[C.sc.paddle_link].geo_mask |= 1 << 6;
+    C.link[C.sc.bound_link].geo_mask |= 1 << 7;
+    for (int k = 0; k < 3; k++) { C.sc.paddle_center[k] = scene.paddle_center[k]; C.sc.paddle_normal[k] = scene.paddle_normal[k]; C.sc.bound_center[k] = m.bound_center[k]; }
+    C.sc.ground_z = m.ground_z; C.sc.k_n = m.foot_stiffness; C.sc.c_n = m.foot_damping; C.sc.c_t = m.foot_tangent_damping; C.sc.mu = m.foot_friction;
+    C.sc.pen_max = m.contact_max_penetration; C.sc.fade_depth = m.contact_fade_depth; C.sc.fade_force = m.contact_fade_force;
+    if (!(C.sc.fade_depth > 0.f) || !(C.sc.fade_force > 0.f)) { *why = "contact_fade_depth / contact_fade_force must be positive"; return false; }
+    C.sc.k_lim = m.limit_stiffness; C.sc.c_lim = m.limit_damping; C.sc.c_vlim = m.vel_limit_damping;
+    C.sc.gravity_z = scene.gravity_z; C.sc.substeps = scene.substeps; C.sc.h = scene.dt / (float)scene.substeps; C.sc.clip_actions = scene.clip_actions;
     if (scene.substeps < 1 || scene.substeps > 16 || !(scene.dt > 0.f)) { *why = "dt / substeps out of range"; return false; }
     return true;
 }

@@ -8,6 +8,7 @@
 // operations per env, not by these bytes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +18,7 @@
 
 using namespace pp;
 using namespace pp::ta;
+using std::min;
 
 void ppenv_set_error(const char* msg);   // ppenv.hip
 
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(kTaLanes) void ta_sim_kernel(const TAConsts* __rest
     if (STEP) {
         for (int d = 0; d < NDOF; d++) {   // VecTask.step clamp + TA:1131 (offset / scale TA:729-733)
             const LinkC& L = C.link[d + 1];
-            float a = fminf(fmaxf(actions[(size_t)e * NDOF + d], -C.clip_actions), C.clip_actions);
+            float a = fminf(fmaxf(actions[(size_t)e * NDOF + d], -C.sc.clip_actions), C.sc.clip_actions);
             st(DOF_BASE + d * DOF_STRIDE + G_TARGET) = 0.5f * (L.hi + L.lo) + 0.5f * (L.hi - L.lo) * a;
             st(DOF_BASE + d * DOF_STRIDE + G_FORCE) = 0.f;
         }
@@ -100,10 +102,13 @@ constexpr int kQuadEnvs = 16;      // envs per 64-lane workgroup
 constexpr int kChainLen = 10;
 constexpr int kRec = 35;           // c s w3 v3 | A6 B9 D6 pn3 pf3  (later: ua3 ub3 dinv u over the A.. slots)
 constexpr int R_C = 0, R_S = 1, R_W = 2, R_V = 5, R_ART = 8, R_JO = 8;
-__device__ const int kChains[4][kChainLen] = {{1, 2, 3, 4, 5, 6, -1, -1, -1, -1},
-                                              {7, 8, 9, 10, 11, 12, -1, -1, -1, -1},
-                                              {13, 14, 15, 16, 17, 18, 19, 20, 21, 22},
-                                              {13, 14, 15, 23, 24, 25, 26, 27, -1, -1}};
+// link at position k of role r's chain (-1 past its end):  0: 1..6   1: 7..12   2: 13..22   3: 13 14 15 23..27
+// (arithmetic, not a table: a per-lane table read would be a vector memory load in every loop iteration)
+__device__ __forceinline__ int chain_link(int role, int k) {
+    if (role < 2) return k < 6 ? 1 + 6 * role + k : -1;
+    if (role == 2) return 13 + k;
+    return k < 3 ? 13 + k : (k < 8 ? 20 + k : -1);
+}
 constexpr int kHubPos = 2;         // chain position of the torso on the two arm lanes: the arms merge before it is processed
 
 struct QuadRec {
@@ -145,19 +150,20 @@ __device__ __forceinline__ void point_of(const M3& Rw, V3 pw, V3 w, V3 v, V3 r, 
     vel = mul(Rw, v + cross(w, r));
 }
 // the ball-collision shapes / paddle / bound centre that ride on link `li` (run-time compare against the shape table)
-__device__ __forceinline__ void capture_geometry(const TAConsts& C, int li, const M3& Rw, V3 pw, V3 w, V3 v, ArmGeom<ModelG1TA::kShapes>& g, V3& bound) {
+__device__ __forceinline__ void capture_geometry(const TAScal& C, int mask, const M3& Rw, V3 pw, V3 w, V3 v, ArmGeom<ModelG1TA::kShapes>& g, V3& bound) {
+    if (mask == 0) return;
 #pragma unroll
     for (int s = 0; s < ModelG1TA::kShapes; s++)
-        if (C.shape_link[s] == li) {
+        if (mask & (1 << s)) {
             point_of(Rw, pw, w, v, ld3(C.shape_a[s]), g.a[s], g.va[s]);
             point_of(Rw, pw, w, v, ld3(C.shape_b[s]), g.b[s], g.vb[s]);
         }
-    if (C.paddle_link == li) {
+    if (mask & (1 << 6)) {
         point_of(Rw, pw, w, v, ld3(C.paddle_center), g.pc, g.vpc);
         g.pn = mul(Rw, ld3(C.paddle_normal));
         g.pnd = cross(mul(Rw, w), g.pn);
     }
-    if (C.bound_link == li) { V3 d; point_of(Rw, pw, w, v, ld3(C.bound_center), bound, d); }
+    if (mask & (1 << 7)) { V3 d; point_of(Rw, pw, w, v, ld3(C.bound_center), bound, d); }
 }
 __device__ __forceinline__ void write_row(float* row, const M3& R, V3 p, V3 lin, V3 ang) {
     float q[4];
@@ -178,10 +184,11 @@ __device__ __forceinline__ void write_link_rows(const TAConsts& C, const LinkC& 
 }
 
 template <bool STEP>
-__global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restrict__ Cp, const StepConsts K, int n, const float* __restrict__ actions,
+__global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restrict__ Cp, const TAScal P, const StepConsts K, int n, const float* __restrict__ actions,
                                                          float* root_states, float* dof_states, float* __restrict__ rb_states,
                                                          float* __restrict__ dof_force, float* __restrict__ pre_vx) {
     __shared__ LinkC s_link[NL];
+    __shared__ float s_cpoint[PPENV_TA_MAX_CONTACTS][3];
     __shared__ float s_rec[kChainLen * kRec * 64];
     __shared__ float s_q[NDOF][kQuadEnvs], s_qd[NDOF][kQuadEnvs], s_target[NDOF][kQuadEnvs], s_force[NDOF][kQuadEnvs];
     const TAConsts& C = *Cp;
@@ -192,6 +199,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         const uint32_t* src = reinterpret_cast<const uint32_t*>(C.link);
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_link);
         for (int t = lane; t < (int)(sizeof(LinkC) * NL / 4); t += 64) dst[t] = src[t];
+        for (int t = lane; t < PPENV_TA_MAX_CONTACTS * 3; t += 64) (&s_cpoint[0][0])[t] = (&C.cpoint[0][0])[t];
     }
     float* root = root_states + (size_t)(live ? e : 0) * 39;
     float* dofs = dof_states + (size_t)(live ? e : 0) * 2 * NDOF;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         s_q[d][es] = dofs[2 * d];
         s_qd[d][es] = dofs[2 * d + 1];
         if (STEP) {
-            float a = fminf(fmaxf(actions[(size_t)(live ? e : 0) * NDOF + d], -C.clip_actions), C.clip_actions);   // VecTask.step clamp
+            float a = fminf(fmaxf(actions[(size_t)(live ? e : 0) * NDOF + d], -P.clip_actions), P.clip_actions);   // VecTask.step clamp
             const float lo = C.link[d + 1].lo, hi = C.link[d + 1].hi;
             s_target[d][es] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;                                            // TA:1131, 729-733
             s_force[d][es] = 0.f;
@@ -218,27 +226,27 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         ball.w = mk(bl[10], bl[11], bl[12]);
         if (live && role == 0) pre_vx[e] = ball.v.x;                                                               // TA:1143
 
-        for (int sub = 0; sub < C.substeps; sub++) {
+        for (int sub = 0; sub < P.substeps; sub++) {
             // ---- pass 1: kinematics + each link's own inertia / bias / contacts, base -> tip of this lane's limb
             M3 Rw = quat_to_m3(base.quat);
             V3 pw = base.p, w = tmul(Rw, base.ww), v = tmul(Rw, base.vw);
             const M3 R0 = Rw;
             const V3 w0 = w, v0 = v;
-            ArtI I0 = link_dynamics(C, s_link[0], Rw, pw, w, v);     // the pelvis: every lane of the quad computes it
+            ArtI I0 = link_dynamics(P, s_link[0], s_cpoint, Rw, pw, w, v);     // the pelvis: every lane of the quad computes it
             ArmGeom<ModelG1TA::kShapes> g[1];
             V3 bound[1];
-            capture_geometry(C, 0, Rw, pw, w, v, g[0], bound[0]);
+            capture_geometry(P, s_link[0].geo_mask, Rw, pw, w, v, g[0], bound[0]);
             for (int k = 0; k < kChainLen; k++) {
-                const int li = kChains[role][k];
+                const int li = chain_link(role, k);
                 if (li < 0) continue;
-                const LinkC& L = s_link[li];
+                const LinkC L = s_link[li];   // by value: plain LDS reads into registers
                 float c, s;
                 link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, c, s);
                 rc(k, R_C) = c; rc(k, R_S) = s;
                 rc(k, R_W) = w.x; rc(k, R_W + 1) = w.y; rc(k, R_W + 2) = w.z;
                 rc(k, R_V) = v.x; rc(k, R_V + 1) = v.y; rc(k, R_V + 2) = v.z;
-                rec_store_art(rc, k, link_dynamics(C, L, Rw, pw, w, v));
-                capture_geometry(C, li, Rw, pw, w, v, g[0], bound[0]);   // complete on the right-arm lane (pelvis, torso, right arm)
+                rec_store_art(rc, k, link_dynamics(P, L, s_cpoint, Rw, pw, w, v));
+                capture_geometry(P, L.geo_mask, Rw, pw, w, v, g[0], bound[0]);   // complete on the right-arm lane (pelvis, torso, right arm)
             }
             // ---- pass 2: articulated inertias tip -> base; the arms meet at the torso, everything at the pelvis
             ArtI acc = art_zero();
@@ -247,13 +255,13 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                     ArtI other = art_shfl_xor(acc, 1);                   // lanes 2 <-> 3 (and, unused, 0 <-> 1)
                     if (role >= 2) add_art(acc, other);
                 }
-                const int li = kChains[role][k];
+                const int li = chain_link(role, k);
                 if (li < 0) continue;
-                const LinkC& L = s_link[li];
+                const LinkC L = s_link[li];   // by value: plain LDS reads into registers
                 ArtI I = rec_load_art(rc, k);
                 add_art(I, acc);
                 JointOut jo;
-                inward_step(C, L, I, mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), rc(k, R_C), rc(k, R_S),
+                inward_step(P, L, I, mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), rc(k, R_C), rc(k, R_S),
                             s_q[li - 1][es], s_qd[li - 1][es], s_target[li - 1][es], jo);
                 rc(k, R_JO) = jo.ua.x; rc(k, R_JO + 1) = jo.ua.y; rc(k, R_JO + 2) = jo.ua.z;
                 rc(k, R_JO + 3) = jo.ub.x; rc(k, R_JO + 4) = jo.ub.y; rc(k, R_JO + 5) = jo.ub.z;
@@ -273,19 +281,19 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
             // ---- pass 3: accelerations base -> tip, joints integrated on the way
             V3 aw = alpha, av = a;
             for (int k = 0; k < kChainLen; k++) {
-                const int li = kChains[role][k];
+                const int li = chain_link(role, k);
                 if (li < 0) continue;
-                const LinkC& L = s_link[li];
+                const LinkC L = s_link[li];   // by value: plain LDS reads into registers
                 JointOut jo = {mk(rc(k, R_JO), rc(k, R_JO + 1), rc(k, R_JO + 2)), mk(rc(k, R_JO + 3), rc(k, R_JO + 4), rc(k, R_JO + 5)), rc(k, R_JO + 6),
                                rc(k, R_JO + 7)};
                 float q = s_q[li - 1][es], qd = s_qd[li - 1][es], force;
-                outward_step(C, L, rc(k, R_C), rc(k, R_S), mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), jo,
+                outward_step(P, L, rc(k, R_C), rc(k, R_S), mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), jo,
                              aw, av, s_target[li - 1][es], q, qd, force);
                 if (!(role == 3 && k < 3)) {                             // the waist dofs are written by lane 2
                     s_q[li - 1][es] = q; s_qd[li - 1][es] = qd; s_force[li - 1][es] = force;
                 }
             }
-            integrate_base_regs(C, R0, w0, v0, base, alpha, a);
+            integrate_base_regs(P, R0, w0, v0, base, alpha, a);
             if (role == 3) ball_substep<ModelG1TA, 1>(K, ball, g, bound);
             __builtin_amdgcn_wave_barrier();                             // lane 2's waist dofs before every lane's next pass 1
         }
@@ -302,23 +310,34 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 for (int k = 0; k < 4; k++) bl[3 + k] = ball.quat[k];
                 bl[7] = ball.v.x; bl[8] = ball.v.y; bl[9] = ball.v.z; bl[10] = ball.w.x; bl[11] = ball.w.y; bl[12] = ball.w.z;
             }
-            for (int d = role; d < NDOF; d += 4) {
-                dofs[2 * d] = s_q[d][es];
-                dofs[2 * d + 1] = s_qd[d][es];
-                dof_force[(size_t)e * NDOF + d] = s_force[d][es];
-            }
+        }
+        // dof_states [N,27,2] and dof_force [N,27] of the workgroup's envs are contiguous: the wave writes them out together
+        __builtin_amdgcn_wave_barrier();
+        const int nvalid = min(kQuadEnvs, n - blockIdx.x * kQuadEnvs);
+        float* dofs_out = dof_states + (size_t)blockIdx.x * kQuadEnvs * 2 * NDOF;
+        for (int t = lane; t < nvalid * 2 * NDOF; t += 64) {
+            const int env = t / (2 * NDOF), j = t - env * 2 * NDOF;
+            dofs_out[t] = (j & 1) ? s_qd[j >> 1][env] : s_q[j >> 1][env];
+        }
+        float* force_out = dof_force + (size_t)blockIdx.x * kQuadEnvs * NDOF;
+        for (int t = lane; t < nvalid * NDOF; t += 64) {
+            const int env = t / NDOF, j = t - env * NDOF;
+            force_out[t] = s_force[j][env];
         }
     }
-    // ---- gym.refresh_rigid_body_state_tensor: every lane writes the rows of its limb (the waist rows: lane 2)
-    if (live) {
-        float* rb = rb_states + (size_t)e * PPENV_NUM_BODIES * 13;
+    // ---- gym.refresh_rigid_body_state_tensor: every lane computes the rows of its limb (the waist rows: lane 2) into an LDS
+    // tile [16 envs][42 x 13] — the workgroup's rows are one contiguous 35 KB block of the tensor, written out coalesced
+    __builtin_amdgcn_wave_barrier();
+    float* s_out = s_rec;                  // the link records are dead by now
+    {
+        float* rb = s_out + es * (PPENV_NUM_BODIES * 13);
         M3 Rw = quat_to_m3(base.quat);
         V3 pw = base.p, w = tmul(Rw, base.ww), v = tmul(Rw, base.vw);
         if (role == 0) write_link_rows(C, s_link[0], 0, Rw, pw, w, v, rb);
         for (int k = 0; k < kChainLen; k++) {
-            const int li = kChains[role][k];
+            const int li = chain_link(role, k);
             if (li < 0) continue;
-            const LinkC& L = s_link[li];
+            const LinkC L = s_link[li];
             float c, s;
             link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, c, s);
             if (!(role == 3 && k < 3)) write_link_rows(C, L, li, Rw, pw, w, v, rb);
@@ -336,6 +355,14 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 for (int k = 0; k < 13; k++) rb[41 * 13 + k] = root[26 + k];
             }
         }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int nv = min(kQuadEnvs, n - blockIdx.x * kQuadEnvs);
+        const int total2 = nv * (PPENV_NUM_BODIES * 13 / 2);                     // 546 floats per env = 273 float2
+        float2* dst = reinterpret_cast<float2*>(rb_states + (size_t)blockIdx.x * kQuadEnvs * PPENV_NUM_BODIES * 13);
+        const float2* src = reinterpret_cast<const float2*>(s_out);
+        for (int t = lane; t < total2; t += 64) dst[t] = src[t];
     }
 }
 
@@ -407,7 +434,7 @@ int ppenv_ta_simulate(ppenv_ta_sim* s, int32_t n, const float* actions_dev, floa
         return PPENV_EINVAL;
     }
     if (s->quad)
-        hipLaunchKernelGGL(ta_sim_quad_kernel<true>, dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->K, n, actions_dev,
+        hipLaunchKernelGGL(ta_sim_quad_kernel<true>, dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->K, n, actions_dev,
                            root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev);
     else
         hipLaunchKernelGGL(ta_sim_kernel<true>, dim3((n + kTaLanes - 1) / kTaLanes), dim3(kTaLanes), 0, (hipStream_t)stream, s->dev, s->K, n, actions_dev,
@@ -423,7 +450,7 @@ int ppenv_ta_forward_kinematics(ppenv_ta_sim* s, int32_t n, const float* root_st
         return PPENV_EINVAL;
     }
     if (s->quad)
-        hipLaunchKernelGGL(ta_sim_quad_kernel<false>, dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->K, n,
+        hipLaunchKernelGGL(ta_sim_quad_kernel<false>, dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->K, n,
                            (const float*)nullptr, const_cast<float*>(root_states_dev), const_cast<float*>(dof_states_dev), rb_states_dev,
                            (float*)nullptr, (float*)nullptr);
     else

@@ -123,7 +123,7 @@ extern "C" int shim_ta_simulate(const ppenv_config* scene, const ppenv_ta_model*
         float* dofs = &dof_states[(size_t)e * 2 * NDOF];
         for (int d = 0; d < NDOF; d++) {
             const LinkC& L = C.link[d + 1];
-            float a = fminf(fmaxf(actions[(size_t)e * NDOF + d], -C.clip_actions), C.clip_actions);
+            float a = fminf(fmaxf(actions[(size_t)e * NDOF + d], -C.sc.clip_actions), C.sc.clip_actions);
             st(DOF_BASE + d * DOF_STRIDE + G_TARGET) = 0.5f * (L.hi + L.lo) + 0.5f * (L.hi - L.lo) * a;
             st(DOF_BASE + d * DOF_STRIDE + G_Q) = dofs[2 * d];
             st(DOF_BASE + d * DOF_STRIDE + G_QD) = dofs[2 * d + 1];
