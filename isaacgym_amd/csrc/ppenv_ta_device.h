@@ -47,10 +47,10 @@ struct TAConsts {
 };
 
 // ---- per-lane storage layout: NL link records, then NDOF dof records
-constexpr int F_C = 0, F_S = 1, F_W = 2, F_V = 5, F_RW = 8, F_PW = 17;
-constexpr int F_A = 20, F_B = 26, F_D = 35, F_PN = 41, F_PF = 44;    // articulated inertia blocks A (sym) B D (sym), bias force
-constexpr int F_UA = 20, F_UB = 23, F_DINV = 26, F_U = 27, F_AW = 28, F_AV = 31;   // overlay A..: written once the link's inertia is consumed
-constexpr int LINK_STRIDE = 47;
+constexpr int F_E = 0, F_W = 9, F_V = 12, F_RW = 15, F_PW = 24;     // E = joint transform child -> parent (kept: three passes use it)
+constexpr int F_A = 27, F_B = 33, F_D = 42, F_PN = 48, F_PF = 51;    // articulated inertia blocks A (sym) B D (sym), bias force
+constexpr int F_UA = 27, F_UB = 30, F_DINV = 33, F_U = 34, F_AW = 35, F_AV = 38;   // overlay A..: written once the link's inertia is consumed
+constexpr int LINK_STRIDE = 54;
 constexpr int DOF_BASE = NL * LINK_STRIDE;
 constexpr int G_Q = 0, G_QD = 1, G_TARGET = 2, G_FORCE = 3;
 constexpr int DOF_STRIDE = 4;
@@ -144,10 +144,11 @@ PP_HD void add_art(ArtI& a, const ArtI& b) {
 }
 
 // pose and link-frame twist of a link from its parent's (in: parent's Rw pw w v; out: the link's)
-PP_HD void link_kinematics(const LinkC& L, float q, float qd, M3& Rw, V3& pw, V3& w, V3& v, float& c, float& s) {
+PP_HD void link_kinematics(const LinkC& L, float q, float qd, M3& Rw, V3& pw, V3& w, V3& v, M3& E) {
+    float s, c;
     sincos_joint(q, s, c);
     const int ax = L.axis;
-    M3 E = joint_rot_rt(L.R0, ax, c, s);
+    E = joint_rot_rt(L.R0, ax, c, s);
     V3 r = ld3(L.r);
     V3 wn = tmul(E, w), vn = tmul(E, v + cross(w, r));
     if (ax == 0) wn.x += qd; else if (ax == 1) wn.y += qd; else wn.z += qd;
@@ -182,7 +183,7 @@ PP_HD void joint_torque(const TAScal& C, const LinkC& L, float q, float qd, floa
 // One joint of the inward pass (RBDA 9.4 with the drive's implicit terms on the joint diagonal).
 // I: in = the link's articulated inertia and bias (own + children, link coordinates); out = its contribution to the
 // parent (parent coordinates, about the parent's origin).
-PP_HD void inward_step(const TAScal& C, const LinkC& L, ArtI& I, V3 w, V3 v, float c, float s, float q, float qd, float target, JointOut& jo) {
+PP_HD void inward_step(const TAScal& C, const LinkC& L, ArtI& I, V3 w, V3 v, const M3& E, float q, float qd, float target, JointOut& jo) {
     const int ax = L.axis;
     float tau, arm;
     joint_torque(C, L, q, qd, target, tau, arm);
@@ -203,7 +204,6 @@ PP_HD void inward_step(const TAScal& C, const LinkC& L, ArtI& I, V3 w, V3 v, flo
     float ud = u * dinv;
     V3 pan = I.pn + mul(A, cw) + mul(B, cv) + ua * ud;
     V3 paf = I.pf + tmul(B, cw) + mul(D, cv) + ub * ud;
-    M3 E = joint_rot_rt(L.R0, ax, c, s);
     V3 r = ld3(L.r);
     S3 Ar = rot_sym(E, A), Dr = rot_sym(E, D);
     M3 Br = mul_t(mul(E, B), E);
@@ -224,10 +224,9 @@ PP_HD void inward_step(const TAScal& C, const LinkC& L, ArtI& I, V3 w, V3 v, flo
 
 // One joint of the outward pass: the link's acceleration from its parent's (aw, av: in = parent's, out = the link's), and
 // the joint's semi-implicit Euler update with the reported drive torque.
-PP_HD void outward_step(const TAScal& C, const LinkC& L, float c, float s, V3 w, V3 v, const JointOut& jo, V3& aw, V3& av,
+PP_HD void outward_step(const TAScal& C, const LinkC& L, const M3& E, V3 w, V3 v, const JointOut& jo, V3& aw, V3& av,
                         float target, float& q, float& qd, float& force) {
     const int ax = L.axis;
-    M3 E = joint_rot_rt(L.R0, ax, c, s);
     V3 r = ld3(L.r), e = unit(ax);
     V3 aw2 = tmul(E, aw) + cross(w, e) * qd;
     V3 av2 = tmul(E, av + cross(aw, r)) + cross(v, e) * qd;
@@ -267,9 +266,9 @@ PP_HD void pass_kinematics(const TAConsts& C, Store& st, const BaseState& b) {
         float q = st(DOF_BASE + (i - 1) * DOF_STRIDE + G_Q), qd = st(DOF_BASE + (i - 1) * DOF_STRIDE + G_QD);
         M3 Rw = ldm3(st, po + F_RW);
         V3 pw = ldv(st, po + F_PW), w = ldv(st, po + F_W), v = ldv(st, po + F_V);
-        float c, s;
-        link_kinematics(L, q, qd, Rw, pw, w, v, c, s);
-        st(o + F_C) = c; st(o + F_S) = s;
+        M3 E;
+        link_kinematics(L, q, qd, Rw, pw, w, v, E);
+        stm3(st, o + F_E, E);
         stv(st, o + F_W, w); stv(st, o + F_V, v); stm3(st, o + F_RW, Rw); stv(st, o + F_PW, pw);
         if (DYN) store_art(st, o, link_dynamics(C.sc, L, C.cpoint, Rw, pw, w, v));
     }
@@ -283,7 +282,7 @@ PP_HD void pass_inertia(const TAConsts& C, Store& st) {
         const int o = i * LINK_STRIDE, po = L.parent * LINK_STRIDE, dofo = DOF_BASE + (i - 1) * DOF_STRIDE;
         ArtI I = load_art(st, o);
         JointOut jo;
-        inward_step(C.sc, L, I, ldv(st, o + F_W), ldv(st, o + F_V), st(o + F_C), st(o + F_S), st(dofo + G_Q), st(dofo + G_QD), st(dofo + G_TARGET), jo);
+        inward_step(C.sc, L, I, ldv(st, o + F_W), ldv(st, o + F_V), ldm3(st, o + F_E), st(dofo + G_Q), st(dofo + G_QD), st(dofo + G_TARGET), jo);
         // the link's own record is consumed: keep what pass 3 needs in its place
         stv(st, o + F_UA, jo.ua); stv(st, o + F_UB, jo.ub); st(o + F_DINV) = jo.dinv; st(o + F_U) = jo.u;
         ArtI P = load_art(st, po);
@@ -324,7 +323,7 @@ PP_HD void pass_accelerate(const TAConsts& C, Store& st, V3 alpha0, V3 a0) {
         V3 aw = ldv(st, po + F_AW), av = ldv(st, po + F_AV);
         JointOut jo = {ldv(st, o + F_UA), ldv(st, o + F_UB), st(o + F_DINV), st(o + F_U)};
         float q = st(dofo + G_Q), qd = st(dofo + G_QD), force;
-        outward_step(C.sc, L, st(o + F_C), st(o + F_S), ldv(st, o + F_W), ldv(st, o + F_V), jo, aw, av, st(dofo + G_TARGET), q, qd, force);
+        outward_step(C.sc, L, ldm3(st, o + F_E), ldv(st, o + F_W), ldv(st, o + F_V), jo, aw, av, st(dofo + G_TARGET), q, qd, force);
         stv(st, o + F_AW, aw); stv(st, o + F_AV, av);
         st(dofo + G_FORCE) = force; st(dofo + G_Q) = q; st(dofo + G_QD) = qd;
     }

@@ -1,7 +1,7 @@
 // ppenv_ta_sim.hip — the 27-DoF variant's rigid-body step on gfx950: kernel + C ABI (include/ppenv.h, ppenv_ta_simulate).
 //
 // Mapping: one lane per env, 16 envs per workgroup.  The 28-link tree does not fit a lane's registers, so each lane keeps its
-// link / dof records in its own column of an LDS array [slot][16] (1424 slots -> 89 KB per workgroup; consecutive lanes hit
+// link / dof records in its own column of an LDS array [slot][16] (1620 slots -> 101 KB per workgroup; consecutive lanes hit
 // consecutive banks).  At BASELINE config 5's size (4096 envs per GPU) that is 256 workgroups, one per CU; the link loops are
 // uniform across the wave, so the model tables in global memory are read with scalar loads.  The simulation state is the
 // caller's Isaac-Gym-layout tensors (AoS, ~0.7 KB per env in and 2.9 KB out): the step is bound by its ~1e5 dependent fp32
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(kTaLanes) void ta_sim_kernel(const TAConsts* __rest
 // tree runs on ta_sim_kernel).
 constexpr int kQuadEnvs = 16;      // envs per 64-lane workgroup
 constexpr int kChainLen = 10;
-constexpr int kRec = 35;           // c s w3 v3 | A6 B9 D6 pn3 pf3  (later: ua3 ub3 dinv u over the A.. slots)
-constexpr int R_C = 0, R_S = 1, R_W = 2, R_V = 5, R_ART = 8, R_JO = 8;
+constexpr int kRec = 42;           // E9 w3 v3 | A6 B9 D6 pn3 pf3  (later: ua3 ub3 dinv u over the A.. slots)
+constexpr int R_E = 0, R_W = 9, R_V = 12, R_ART = 15, R_JO = 15;
 // link at position k of role r's chain (-1 past its end):  0: 1..6   1: 7..12   2: 13..22   3: 13 14 15 23..27
 // (arithmetic, not a table: a per-lane table read would be a vector memory load in every loop iteration)
 __device__ __forceinline__ int chain_link(int role, int k) {
@@ -240,9 +240,10 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 const int li = chain_link(role, k);
                 if (li < 0) continue;
                 const LinkC L = s_link[li];   // by value: plain LDS reads into registers
-                float c, s;
-                link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, c, s);
-                rc(k, R_C) = c; rc(k, R_S) = s;
+                M3 E;
+                link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, E);
+#pragma unroll
+                for (int t = 0; t < 9; t++) rc(k, R_E + t) = E.m[t];
                 rc(k, R_W) = w.x; rc(k, R_W + 1) = w.y; rc(k, R_W + 2) = w.z;
                 rc(k, R_V) = v.x; rc(k, R_V + 1) = v.y; rc(k, R_V + 2) = v.z;
                 rec_store_art(rc, k, link_dynamics(P, L, s_cpoint, Rw, pw, w, v));
@@ -261,7 +262,10 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 ArtI I = rec_load_art(rc, k);
                 add_art(I, acc);
                 JointOut jo;
-                inward_step(P, L, I, mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), rc(k, R_C), rc(k, R_S),
+                M3 E;
+#pragma unroll
+                for (int t = 0; t < 9; t++) E.m[t] = rc(k, R_E + t);
+                inward_step(P, L, I, mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), E,
                             s_q[li - 1][es], s_qd[li - 1][es], s_target[li - 1][es], jo);
                 rc(k, R_JO) = jo.ua.x; rc(k, R_JO + 1) = jo.ua.y; rc(k, R_JO + 2) = jo.ua.z;
                 rc(k, R_JO + 3) = jo.ub.x; rc(k, R_JO + 4) = jo.ub.y; rc(k, R_JO + 5) = jo.ub.z;
@@ -287,7 +291,10 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 JointOut jo = {mk(rc(k, R_JO), rc(k, R_JO + 1), rc(k, R_JO + 2)), mk(rc(k, R_JO + 3), rc(k, R_JO + 4), rc(k, R_JO + 5)), rc(k, R_JO + 6),
                                rc(k, R_JO + 7)};
                 float q = s_q[li - 1][es], qd = s_qd[li - 1][es], force;
-                outward_step(P, L, rc(k, R_C), rc(k, R_S), mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), jo,
+                M3 E;
+#pragma unroll
+                for (int t = 0; t < 9; t++) E.m[t] = rc(k, R_E + t);
+                outward_step(P, L, E, mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), jo,
                              aw, av, s_target[li - 1][es], q, qd, force);
                 if (!(role == 3 && k < 3)) {                             // the waist dofs are written by lane 2
                     s_q[li - 1][es] = q; s_qd[li - 1][es] = qd; s_force[li - 1][es] = force;
@@ -338,8 +345,8 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
             const int li = chain_link(role, k);
             if (li < 0) continue;
             const LinkC L = s_link[li];
-            float c, s;
-            link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, c, s);
+            M3 E;
+            link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, E);
             if (!(role == 3 && k < 3)) write_link_rows(C, L, li, Rw, pw, w, v, rb);
         }
         if (role == 1) {

@@ -38,6 +38,7 @@ TASK_VARIANTS = {
     "HumanoidPingpongTiltG1": "TT",
     "HumanoidPingpongTiltNoEarlyStopG1": "TN",
     "Humanoid12PingpongTiltG1": "T4",
+    "HumanoidPingpongTiltNESSparse27DOFG1": "TA",
 }
 
 
@@ -749,7 +750,9 @@ def build_ta_model():
 
 TASK_CFGS["TA"] = dict(
     name="HumanoidPingpongTiltNESSparse27DOFG1",
-    env=dict(TASK_CFGS["TN"]["env"], numEnvs=2048, episodeLength=160, alphaVelocityReward=3000.0, powerCoefficient=0.002),
+    env=dict(TASK_CFGS["TN"]["env"], numEnvs=2048, episodeLength=160, alphaVelocityReward=3000.0, powerCoefficient=0.002,      # yaml:8-17
+             hitTableReward=3000.0, nothitTablePenalty=-1000.0, crossNetRewardFloat=1000.0, diePenaltyFloat=-3000.0,            # yaml:21-30
+             hitPaddleReward=200.0, missPaddlePenaltyCoefficient=-100.0),
     sim=dict(_SIM_DEFAULT),                                                                 # 27DOFG1.yaml:88-90: dt 0.0083, substeps 2
     scene=dict(TASK_CFGS["TN"]["scene"],
                table_material=dict(restitution=1.5, friction=0.2),                         # TA:636-638

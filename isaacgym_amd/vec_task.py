@@ -267,3 +267,49 @@ class Humanoid12PingpongTilt(_HumanoidPingpongBase):
 
     def _flag(self, bit):   # [2, N]: row a = side a
         return (self.env.flags & bit) != 0
+
+
+class HumanoidPingpongTiltNESSparse27DOF(VecTask):
+    """tasks/humanoid_pingpong_3_actor_all_dof.py:65 (TA; the reference does not register it, its yaml is
+    cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml): the free-floating 27-dof humanoid.  313 observations (TA:106),
+    27 actions (TA:109); `step` = ppenv_ta_simulate + ppenv_ta_post_physics_step on the Isaac-Gym-layout tensors the
+    reference class wraps (TA:161-251), which are attributes here under the reference's names."""
+    VARIANT = "TA"
+
+    def __init__(self, cfg, rl_device, sim_device, graphics_device_id=-1, headless=True, virtual_screen_capture=False, force_render=False):
+        cfg = copy.deepcopy(cfg) if cfg is not None else scene.default_task_cfg("TA")
+        env = cfg["env"]
+        env["numObservations"] = scene.TA_NUM_OBS      # TA:106
+        env["numActions"] = scene.TA_NUM_DOF           # TA:109
+        self.max_episode_length = env["episodeLength"]
+        self._seed = int(cfg.get("seed", 0))
+        self._env_id_offset = int(cfg.get("env_id_offset", 0))
+        super().__init__(config=cfg, rl_device=rl_device, sim_device=sim_device, graphics_device_id=graphics_device_id, headless=headless,
+                         virtual_screen_capture=virtual_screen_capture, force_render=force_render)
+        self.actors_per_env, self.dofs_per_env, self.rigid_bodies_per_env = 3, scene.TA_NUM_DOF, scene.NUM_BODIES     # TA:156-158
+
+    def create_sim(self):
+        from .tensor_api import TAEnv
+        keys = ("episodeLength", "alphaVelocityReward", "powerCoefficient", "hitTableReward", "nothitTablePenalty", "crossNetRewardFloat",
+                "diePenaltyFloat", "hitPaddleReward", "missPaddlePenaltyCoefficient")
+        env = {k: self.cfg["env"][k] for k in keys if k in self.cfg["env"]}
+        with torch.cuda.device(self.device):
+            self.env = TAEnv(self.num_envs, device=self.device, seed=self._seed, env_id_offset=self._env_id_offset, env=env)
+        e = self.env
+        self.root_states = self.vec_root_states = e.root_states
+        self.vec_dof_states = e.dof_states
+        self.dof_pos, self.dof_vel = e.dof_states[..., 0], e.dof_states[..., 1]
+        self.body_states = self.vec_rb_states = e.rb_states
+        self.initial_body_states = e.initial_rb_states
+        self.dof_force_tensor = e.dof_force_tensor
+        return e
+
+    def step(self, actions):
+        for _ in range(self.control_freq_inv):
+            self.env.step(actions)          # the clipActions clamp happens inside the kernel
+        self.control_steps += 1
+        self.extras["time_outs"] = self.timeout_buf if self.rl_device == self.device else self.timeout_buf.to(self.rl_device)
+        return self._obs_dict(), self._to_rl(self.rew_buf), self._to_rl(self.reset_buf), self.extras
+
+    def reset_idx(self, env_ids=None):
+        raise NotImplementedError("the 27-dof task resets inside post_physics_step (TA:965-1028); a forced full reset is not part of its surface")

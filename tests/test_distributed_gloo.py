@@ -123,3 +123,50 @@ def test_single_process_helpers_are_identity():
     assert D.gather_rollout(x) is x
     s = D.horizon_stats(torch.tensor([1.0, 3.0]), torch.tensor([4, 6]), torch.tensor([2, 5]))
     assert s.tolist() == [2.0, 5.0, 7.0]
+
+
+# ---- BASELINE config 4 (4-actor, sharded, obs / reward gather) and config 5 (27-dof) on two gloo ranks --------------
+N4, STEPS4 = 37, 45      # 37 envs = 74 agent rows: ragged split 19 + 18 envs
+
+
+def _actions4(step):
+    return np.random.default_rng(2000 + step).uniform(-1, 1, (2 * N4, 7)).astype(np.float32)
+
+
+def _worker_t4_ta(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from isaacgym_amd import distributed as D
+    from isaacgym_amd import scene
+    from oracle import binding as ob
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    off, cnt = D.shard_range(N4, rank, world)
+    env = ob.OracleEnv(scene.build_config("T4", num_envs=cnt, seed=SEED, env_id_offset=off))
+    for t in range(STEPS4):
+        env.step(_actions4(t)[2 * off:2 * (off + cnt)])      # agent rows 2e, 2e + 1 travel with env e
+    obs = D.gather_rollout(torch.from_numpy(env.obs_buf.copy()))
+    rew = D.gather_rollout(torch.from_numpy(env.rew_buf.copy()))
+    # 27-dof task: the reset draws are keyed by the global env id, so a shard lays out the same initial balls
+    p = scene.build_ta_params(cnt, seed=SEED, env_id_offset=off)
+    draws = D.gather_rollout(scene.ta_reset_draws(p, torch.arange(cnt), torch.zeros(cnt, dtype=torch.int64)))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "t4.npz"), obs=obs.numpy(), rew=rew.numpy(), draws=draws.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_of_the_two_agent_and_27dof_tasks(oracle_lib, tmp_path):
+    from isaacgym_amd import scene
+    oracle_lib.build()
+    mp.spawn(_worker_t4_ta, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "t4.npz")
+    env = oracle_lib.OracleEnv(scene.build_config("T4", num_envs=N4, seed=SEED))
+    for t in range(STEPS4):
+        env.step(_actions4(t))
+    assert got["obs"].shape == (2 * N4, 80)
+    np.testing.assert_array_equal(got["obs"], env.obs_buf)
+    np.testing.assert_array_equal(got["rew"], env.rew_buf)
+    p = scene.build_ta_params(N4, seed=SEED)
+    want = scene.ta_reset_draws(p, torch.arange(N4), torch.zeros(N4, dtype=torch.int64)).numpy()
+    np.testing.assert_array_equal(got["draws"], want)
+    assert (want[:, 0] >= -0.5).all() and (want[:, 0] <= 0.1).all() and (want[:, 2] < -4.0).all()   # TA:133-134, serve towards the humanoid

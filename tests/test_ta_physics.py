@@ -203,3 +203,21 @@ def test_ta_env_steps_end_to_end():
     assert float(a_.rb_states[:, :40, 2].min()) > scene.TA_GROUND_Z - 0.2
     for e in envs:
         e.close()
+
+
+@pytest.mark.gpu
+def test_ta_vec_task_surface():
+    """`isaacgym_amd.make("HumanoidPingpongTiltNESSparse27DOFG1")`: the 27-dof task on the VecTask surface."""
+    import torch
+    import isaacgym_amd
+    n = 128
+    task = isaacgym_amd.make(task="HumanoidPingpongTiltNESSparse27DOFG1", num_envs=n, seed=2)
+    assert task.num_obs == 313 and task.num_actions == 27 and task.get_number_of_agents() == 1
+    assert (task.actors_per_env, task.dofs_per_env, task.rigid_bodies_per_env) == (3, 27, 42)          # TA:156-158
+    assert task.reset()["obs"].shape == (n, 313)
+    for _ in range(3):
+        od, rew, done, extras = task.step(torch.rand(n, 27, device="cuda") * 2 - 1)
+    assert od["obs"].shape == (n, 313) and rew.shape == (n,) and done.dtype == torch.int64 and "time_outs" in extras
+    assert task.body_states.shape == (n, 42, 13) and task.dof_pos.shape == (n, 27)
+    assert task.env.params.hit_table_reward == 3000.0 and task.env.params.max_episode_length == 160    # 27DOFG1.yaml:10,21
+    assert torch.isfinite(od["obs"]).all()
