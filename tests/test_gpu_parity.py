@@ -356,3 +356,19 @@ def test_rlgames_adapter_drives_the_native_task(torch_cuda):
         total += rew
     assert obs_d["obs"].shape == (256, 80) and bool(torch.isfinite(total).all()) and int(done.sum()) >= 0
     assert int(venv.env.env.episode.sum()) >= 256          # 170-step episodes: everyone timed out once
+
+
+@pytest.mark.parametrize("variant,n", [("TT", 1000), ("TT", 40000), ("T4", 700)])
+def test_reduce_stats_matches_torch_sums(torch_cuda, variant, n):
+    """ppenv_reduce_stats (what TT:763-766 prints, on the device): the one-workgroup kernel (<= 32768 rows) and the
+    many-workgroup one give torch's sums; rows = agents * envs for the two-agent task."""
+    torch = torch_cuda
+    env = make_env(scene.build_config(variant, num_envs=n, seed=4))
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(70):
+        env.step(torch.rand(n * env.num_agents, 7, device="cuda", generator=gen) * 2 - 1)
+    s = env.reduce_stats().cpu().numpy()
+    want = [float(env.rew_buf.double().sum()), float(env.progress_buf.double().sum()), float(env.episode.double().sum()) * env.num_agents,
+            float(n * env.num_agents)]
+    np.testing.assert_allclose(s, want, rtol=1e-9, atol=1e-6)
+    env.close()
