@@ -34,6 +34,7 @@ namespace {
 
 constexpr int kBlock = 64;   // exactly one wave per workgroup: step_kernel relies on it (no barrier around its LDS tile)
 constexpr int kObsStride = PPENV_NUM_OBS + 1;   // +1 float: lanes write LDS rows bank-conflict-free
+constexpr int kMaxSplitSubsteps = 4;            // the multi-wave step kernels keep one LDS hand-off slot per substep boundary
 
 struct DevBuffers {
     float* obs;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
 // writes the 60 body-observation values; the ball wave computes reward, masked reset and the last 20 values;
 // then each flushes the obs columns it wrote and stores its half of the state.  Every hand-off is one-way (an
 // LDS sequence number the consumer polls: the producer never waits); the only s_barrier is the one after the
-// flags are initialised.  (q, qd) travel through two alternating LDS slots.
+// flags are initialised.  (q, qd) of substep boundary b travel through LDS slot b - 1 (one per boundary, never reused).
 struct NullVisitor {
     __device__ __forceinline__ void operator()(int, const M3&, V3, V3, V3) {}
 };
@@ -251,12 +252,46 @@ __device__ __forceinline__ void await(int* flag, int value) {
     }
 }
 
-// A = humanoids per env.  A = 1: two waves (arm, ball).  A = 2 (4-actor variant): three waves — one per arm, each
-// on its own base (K.site[arm]), and the ball wave, which sweeps both arms' collision geometry.
-template <class T, int A>
+// the parts of an arm's collision geometry that move with it: paddle centre / normal / their rates, then end points and
+// velocities of the link-attached shapes
+template <class T>
+struct MovingGeom {
+    static constexpr int count() {
+        int c = 12;
+        for (int s = 0; s < T::kShapes; s++) c += T::shape_link(s) >= 0 ? 12 : 0;
+        return c;
+    }
+    template <class F>
+    __device__ __forceinline__ static void each(ArmGeom<T::kShapes>& g, F&& f) {
+        int k = 0;
+        V3* head[4] = {&g.pc, &g.pn, &g.vpc, &g.pnd};
+#pragma unroll
+        for (int t = 0; t < 4; t++) { f(k, head[t]->x); f(k + 1, head[t]->y); f(k + 2, head[t]->z); k += 3; }
+#pragma unroll
+        for (int s = 0; s < T::kShapes; s++)
+            if (T::shape_link(s) >= 0) {
+                V3* v[4] = {&g.a[s], &g.b[s], &g.va[s], &g.vb[s]};
+#pragma unroll
+                for (int t = 0; t < 4; t++) { f(k, v[t]->x); f(k + 1, v[t]->y); f(k + 2, v[t]->z); k += 3; }
+            }
+    }
+};
+
+// A = humanoids per env, G = who sweeps the collision geometry.  <A=1, G=0>: two waves (arm, ball); the arm wave is the
+// critical path, so it stays in joint space and the ball wave runs the world-space FK sweep for the geometry itself.
+// <A=2, G=0>: the same with three waves, one per arm on its own base (K.site[arm]).  <A=2, G=1> (the 4-actor default): with
+// two humanoids to collide against the ball wave is the critical path (35k cycles against the arm waves' 21k), so each
+// arm wave's start-of-substep sweep is the world-space one and hands its geometry to the ball wave through two alternating
+// LDS slots; the ball wave is left with the contacts.  (Tried and dropped: separate geometry waves — five waves on four
+// SIMDs slow each other more than the hand-off saves.)
+template <class T, int A, int G>
 __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
+    constexpr int kGeo = MovingGeom<T>::count();
+    __shared__ float s_geom[G ? 2 : 1][G ? A : 1][G ? kGeo : 1][G ? kBlock : 1];   // geometry of boundary s in slot s & 1
+    __shared__ int s_gflag[A];                         // arm -> ball: boundaries whose geometry is in LDS
+    __shared__ int s_bflag;                            // ball -> arm: substeps the ball has finished (slot reuse)
     __shared__ float s_obs[A * kBlock * kObsStride];   // tile row = agent * kBlock + lane
-    __shared__ float s_q[2][A * 2 * ND][kBlock];       // (q, qd) at a substep boundary, two alternating slots
+    __shared__ float s_q[kMaxSplitSubsteps][A * 2 * ND][kBlock];   // (q, qd) at substep boundary b = 1 .. substeps, slot b - 1: never reused
     __shared__ float s_tau[A * ND][kBlock];            // drive torques of the last substep (dof_force)
     __shared__ float s_paddle[A * 3][kBlock];          // paddle position of the final state (the reward reads it)
     __shared__ int s_reset[kBlock];                    // the ball wave's reset decision, for the arm waves' dof stores
@@ -270,7 +305,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     const int nvalid = min(kBlock, n - base);
     const bool active = i < n;
     const int substeps = K.substeps;
-    if (threadIdx.x <= A) { if (threadIdx.x < A) s_flag[threadIdx.x] = 0; else s_flag_ball = 0; }
+    if (threadIdx.x <= A) { if (threadIdx.x < A) { s_flag[threadIdx.x] = 0; s_gflag[threadIdx.x] = 0; } else { s_flag_ball = 0; s_bflag = 0; } }
     __syncthreads();   // the only rendezvous of the launch: the flags are initialised
 
     if (wave < A) {
@@ -293,12 +328,24 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         }
         PP_STAMP_AT(1);
         for (int s = 0; s < substeps; s++) {
+            if (G) {
+                if (s >= 2) await(&s_bflag, s - 1);     // the ball is done with the slot's previous content (substep s - 2)
+                if (active) {
+                    ArmGeom<T::kShapes> gg;             // world-space sweep: velocity recursion + the collision geometry of boundary s
+                    GeomVisitor<T> gv(gg);
+                    fk_sweep<T>(S, q, qd, js, gv);
+                    MovingGeom<T>::each(gg, [&](int k, float& v) { s_geom[s & 1][arm][k][lane] = v; });
+                }
+                publish(&s_gflag[arm], s + 1);
+            }
             if (active) {
-                NullVisitor nv;   // velocity recursion only: the world transforms of this sweep are dead code
-                fk_sweep<T>(S, q, qd, js, nv);
+                if (!G) {
+                    NullVisitor nv;   // velocity recursion only: the world transforms of this sweep are dead code
+                    fk_sweep<T>(S, q, qd, js, nv);
+                }
                 arm_substep<T>(S, js, q, qd, target, K.h, tau);
 #pragma unroll
-                for (int d = 0; d < ND; d++) { s_q[(s + 1) & 1][arm * 2 * ND + d][lane] = q[d]; s_q[(s + 1) & 1][arm * 2 * ND + ND + d][lane] = qd[d]; }
+                for (int d = 0; d < ND; d++) { s_q[s][arm * 2 * ND + d][lane] = q[d]; s_q[s][arm * 2 * ND + ND + d][lane] = qd[d]; }
                 if (s + 1 == substeps) {
 #pragma unroll
                     for (int d = 0; d < ND; d++) s_tau[arm * ND + d][lane] = tau[d];
@@ -359,8 +406,10 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
 #pragma unroll
     for (int a = 0; a < A; a++) rew[a] = 0.f;
     if (active) {
+        if (!G) {
 #pragma unroll
-        for (int d = 0; d < A * ND; d++) { qs[d] = b.dof_pos[(size_t)d * n + i]; qds[d] = b.dof_vel[(size_t)d * n + i]; }
+            for (int d = 0; d < A * ND; d++) { qs[d] = b.dof_pos[(size_t)d * n + i]; qds[d] = b.dof_vel[(size_t)d * n + i]; }
+        }
         float bl[13];
 #pragma unroll
         for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
@@ -383,26 +432,34 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     }
     PP_STAMP_AT(17);
     for (int s = 0; s < substeps; s++) {
-        if (s > 0) {
+        if (G) {
+#pragma unroll
+            for (int a = 0; a < A; a++) await(&s_gflag[a], s + 1);   // the geometry waves have boundary s in LDS
+        } else if (s > 0) {
 #pragma unroll
             for (int a = 0; a < A; a++) await(&s_flag[a], s);   // the arm waves have published boundary s
             if (active) {
 #pragma unroll
                 for (int a = 0; a < A; a++)
 #pragma unroll
-                    for (int d = 0; d < ND; d++) { qs[a * ND + d] = s_q[s & 1][a * 2 * ND + d][lane]; qds[a * ND + d] = s_q[s & 1][a * 2 * ND + ND + d][lane]; }
+                    for (int d = 0; d < ND; d++) { qs[a * ND + d] = s_q[s - 1][a * 2 * ND + d][lane]; qds[a * ND + d] = s_q[s - 1][a * 2 * ND + ND + d][lane]; }
             }
         }
         PP_STAMP_AT(18 + 2 * s);
         if (active) {
 #pragma unroll
             for (int a = 0; a < A; a++) {
-                JointSave js[ND];        // dead: only the geometry (points + velocities) of this sweep is used
-                GeomVisitor<T> gv(g[a]);
-                fk_sweep<T>(K.site[a], &qs[a * ND], &qds[a * ND], js, gv);
+                if (G) {
+                    MovingGeom<T>::each(g[a], [&](int k, float& v) { v = s_geom[s & 1][a][k][lane]; });
+                } else {
+                    JointSave js[ND];        // dead: only the geometry (points + velocities) of this sweep is used
+                    GeomVisitor<T> gv(g[a]);
+                    fk_sweep<T>(K.site[a], &qs[a * ND], &qds[a * ND], js, gv);
+                }
             }
             ball_substep<T, A>(K, st.ball, g, bound);
         }
+        if (G) publish(&s_bflag, s + 1);
         PP_STAMP_AT(19 + 2 * s);
     }
 #pragma unroll
@@ -414,8 +471,8 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         for (int a = 0; a < A; a++) {
 #pragma unroll
             for (int d = 0; d < ND; d++) {
-                st.q[a * ND + d] = s_q[substeps & 1][a * 2 * ND + d][lane];
-                st.qd[a * ND + d] = s_q[substeps & 1][a * 2 * ND + ND + d][lane];
+                st.q[a * ND + d] = s_q[substeps - 1][a * 2 * ND + d][lane];
+                st.qd[a * ND + d] = s_q[substeps - 1][a * 2 * ND + ND + d][lane];
                 st.dof_force[a * ND + d] = s_tau[a * ND + d][lane];
             }
             static_body<false>(K.site[a], bodies[a * NB]);
@@ -752,6 +809,7 @@ bool validate(const ppenv_config* c) {
     if (c->num_envs <= 0) { set_err("num_envs must be positive"); return false; }
     if (c->variant < PPENV_VARIANT_T3 || c->variant > PPENV_VARIANT_T4) { set_err("unknown task variant"); return false; }
     if (c->num_humanoids != agents_of(c)) { set_err("num_humanoids must be 2 for PPENV_VARIANT_T4 and 1 otherwise"); return false; }
+    if (agents_of(c) == 2 && c->substeps > kMaxSplitSubsteps) { set_err("the 4-actor variant supports at most 4 substeps"); return false; }
     if (c->substeps < 1 || c->substeps > 16 || c->ball_substeps < 1 || c->ball_substeps > 64) { set_err("substeps / ball_substeps out of range"); return false; }
     if (!(c->dt > 0.f)) { set_err("dt must be positive"); return false; }
     if (!model_matches<ModelG1>(*c)) {
@@ -776,7 +834,7 @@ struct ppenv {
     void* arena;
     bool owns_arena;
     int serve_on;
-    int split;               // 1: step_kernel_split (two waves per 64 envs), 0: step_kernel
+    int split;               // 1: step_kernel_split (two waves per 64 envs; three for the 4-actor variant), 2: 4-actor with the arm waves sweeping the geometry, 0: step_kernel
     int agents;              // 1, or 2 for PPENV_VARIANT_T4
 };
 
@@ -817,7 +875,8 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
         // 65536 19.6 / 22.8, 131072 35.3 / 41.5): it needs 187 VGPRs (two waves per SIMD) against 256 + 79 AGPRs.
         const char* k = getenv("PPENV_STEP_KERNEL");
         e->split = k ? (strcmp(k, "fused") != 0) : 1;
-        if (e->agents == 2) e->split = 1;   // the 4-actor variant has the three-wave schedule only
+        if (cfg->substeps > kMaxSplitSubsteps) e->split = 0;   // one LDS hand-off slot per substep boundary
+        if (e->agents == 2) e->split = (k && strcmp(k, "split3") == 0) ? 1 : 2;   // 4-actor: arm waves sweep the geometry (default), or the ball wave
     }
     e->arena = nullptr;
     e->owns_arena = false;
@@ -885,11 +944,14 @@ int ppenv_config_of(ppenv* e, ppenv_config* out) {
 int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = use_device(e)) return rc;
-    if (e->agents == 2)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+    if (e->agents == 2 && e->split == 2)
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+                           actions_dev, e->serve_on);
+    else if (e->agents == 2)
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
                            actions_dev, e->serve_on);
     else if (e->split)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
                            actions_dev, e->serve_on);
     else
         hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,

@@ -120,12 +120,14 @@ class DevView:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1024, 200])
-def test_t4_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, n):
-    """The three-wave kernel (arm 1 / arm 2 / ball) vs the oracle, restarted from the oracle's state every step;
-    n = 200 leaves a ragged last workgroup."""
+@pytest.mark.parametrize("schedule,n", [("split", 1024), ("split", 200), ("split3", 200)])
+def test_t4_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, monkeypatch, schedule, n):
+    """The three-wave kernel (arm 1 / arm 2 / ball) in both hand-off forms — the arm waves sweep the collision geometry
+    (default), or the ball wave does from the published (q, qd) — vs the oracle, restarted from the oracle's state every
+    step; n = 200 leaves a ragged last workgroup."""
     torch = torch_cuda
     from isaacgym_amd.env import PPEnv
+    monkeypatch.setenv("PPENV_STEP_KERNEL", schedule)
     cfg = scene.build_config("T4", num_envs=n, seed=7)
     o = oracle_lib.OracleEnv(cfg, threads=8)
     env = PPEnv(scene.build_config("T4", num_envs=n, seed=7), device="cuda:0")

@@ -12,16 +12,18 @@ sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "gpurun_out", "libppenv_stamp.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only",
-                "-fPIC", "-shared", "-DPP_STAMP=1", "-o", lib, os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv.hip"), os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv_ta.hip")], check=True)
+                "-fPIC", "-shared", "-DPP_STAMP=1", "-o", lib, os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv.hip"), os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv_ta.hip"),
+                os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv_ta_sim.hip")], check=True)
 os.environ["PPENV_LIB"] = lib
 import torch  # noqa: E402
 from isaacgym_amd import _lib, scene  # noqa: E402
 from isaacgym_amd.env import PPEnv  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-env = PPEnv(scene.build_config("TT", num_envs=n, seed=0), device="cuda:0")
+variant = sys.argv[2] if len(sys.argv) > 2 else "TT"
+env = PPEnv(scene.build_config(variant, num_envs=n, seed=0), device="cuda:0")
 gen = torch.Generator(device="cuda").manual_seed(0)
-pool = [(torch.rand(n, 7, device="cuda", generator=gen) * 2 - 1) for _ in range(8)]
+pool = [(torch.rand(n * env.num_agents, 7, device="cuda", generator=gen) * 2 - 1) for _ in range(8)]
 for s in range(300):
     env.step(pool[s & 7])
 torch.cuda.synchronize()
@@ -31,7 +33,7 @@ buf = np.zeros(nb * 32, np.uint64)
 L.ppenv_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.ppenv_debug_read_stamps(buf.ctypes.data, buf.size) == 0
 t = buf.reshape(nb, 32).astype(np.int64)
-if os.environ.get("PPENV_STEP_KERNEL", "split" if n <= 32768 else "fused") == "fused":
+if os.environ.get("PPENV_STEP_KERNEL", "split") == "fused":
     names = {0: "start", 1: "loads done", 2: "FK0", 3: "arm substep 1", 4: "FK1", 5: "ball substep 1", 6: "arm substep 2", 7: "FK2 (+bodies)",
              8: "ball substep 2", 9: "reward/reset/obs", 10: "stores + obs flush"}
     tot = np.median(t[:, 10] - t[:, 0])
