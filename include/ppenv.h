@@ -405,6 +405,13 @@ void ppenv_ta_sim_destroy(ppenv_ta_sim* sim);
  * dof_states [N,27,2] are read and updated in place; rb_states [N,42,13], dof_force [N,27], pre_ball_vx [N] are written. */
 int ppenv_ta_simulate(ppenv_ta_sim* sim, int32_t num_envs, const float* actions_dev, float* root_states_dev, float* dof_states_dev,
                       float* rb_states_dev, float* dof_force_dev, float* pre_ball_vx_dev, void* stream);
+/* The whole VecTask step of the 27-DoF task in one launch (+ the count-flag clear): ppenv_ta_simulate followed by
+ * ppenv_ta_post_physics_step, with the task arithmetic running on the rigid-body kernel's LDS tiles.  Arguments as in
+ * those two entries; rb_states receives the pre-reset body states, root / dof states the post-reset ones (TA:1150-1160). */
+int ppenv_ta_step(ppenv_ta_sim* sim, const ppenv_ta_params* params, const float* actions_dev, const float* initial_rb_states_dev,
+                  float* root_states_dev, float* dof_states_dev, float* rb_states_dev, float* dof_force_dev, float* pre_ball_vx_dev,
+                  const float* reset_override_dev, uint32_t* flags_dev, uint32_t* episode_dev, int64_t* progress_dev, float* obs_dev,
+                  float* rew_dev, int64_t* reset_dev, uint32_t* scratch_any_reset_dev /* 1 word */, void* stream);
 /* rigid-body states of the current root / dof states without stepping (initial_rb_states of TA:1152; tests) */
 int ppenv_ta_forward_kinematics(ppenv_ta_sim* sim, int32_t num_envs, const float* root_states_dev, const float* dof_states_dev,
                                 float* rb_states_dev, void* stream);

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("PPENV_LIB", os.path.join(_PKG, "lib", "libppenv.so"))   # PPENV_LIB: profiling builds only
 SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip"), os.path.join(_PKG, "csrc", "ppenv_ta.hip"), os.path.join(_PKG, "csrc", "ppenv_ta_sim.hip")]
-HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1.h"), os.path.join(_PKG, "csrc", "ppenv_ta_device.h"),
+HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1.h"), os.path.join(_PKG, "csrc", "ppenv_ta_device.h"), os.path.join(_PKG, "csrc", "ppenv_ta_task.h"),
            os.path.join(ROOT, "include", "ppenv.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only", "-fPIC", "-shared"]
 
@@ -87,6 +87,7 @@ def lib():
     L.ppenv_ta_sim_destroy.argtypes = [vp]
     L.ppenv_ta_simulate.argtypes = [vp, C.c_int32] + [vp] * 7
     L.ppenv_ta_forward_kinematics.argtypes = [vp, C.c_int32] + [vp] * 4
+    L.ppenv_ta_step.argtypes = [vp, C.POINTER(scene.TAParams)] + [vp] * 16
     L.ppenv_state_bytes.restype = sz
     L.ppenv_state_bytes.argtypes = [vp]
     L.ppenv_get_state.argtypes = [vp, vp, sz]

@@ -15,12 +15,14 @@
 #include <new>
 
 #include "ppenv_ta_device.h"
+#include "ppenv_ta_task.h"
 
 using namespace pp;
 using namespace pp::ta;
 using std::min;
 
 void ppenv_set_error(const char* msg);   // ppenv.hip
+int ppenv_ta_clear_counts(int n, uint32_t* flags_dev, uint32_t* any_reset_dev, void* stream);   // ppenv_ta.hip
 
 namespace {
 constexpr int kTaLanes = 16;
@@ -183,10 +185,26 @@ __device__ __forceinline__ void write_link_rows(const TAConsts& C, const LinkC& 
         }
 }
 
-template <bool STEP>
+// what the fused launch needs beyond the rigid-body step: the task's parameters and per-env buffers (ppenv_ta_post_physics_step's)
+struct TaskArgs {
+    ppenv_ta_params p;
+    const float* initial_rb;
+    const float* reset_override;
+    uint32_t* flags;
+    uint32_t* episode;
+    long long* progress;
+    float* obs;
+    float* rew;
+    long long* reset;
+    uint32_t* any_reset;
+};
+
+// STEP = false: forward kinematics only.  FUSE = true: post_physics_step (reward, masked reset, 313-wide observation, TA:1145-1192)
+// in the same launch, on the LDS tiles, before anything goes to global memory.
+template <bool STEP, bool FUSE>
 __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restrict__ Cp, const TAScal P, const StepConsts K, int n, const float* __restrict__ actions,
                                                          float* root_states, float* dof_states, float* __restrict__ rb_states,
-                                                         float* __restrict__ dof_force, float* __restrict__ pre_vx) {
+                                                         float* __restrict__ dof_force, float* __restrict__ pre_vx, const TaskArgs task) {
     __shared__ LinkC s_link[NL];
     __shared__ float s_cpoint[PPENV_TA_MAX_CONTACTS][3];
     __shared__ float s_rec[kChainLen * kRec * 64];
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
     load_base(root, base);
     QuadRec rc{&s_rec[lane]};
     Ball ball;
+    float pre_vx_reg_out = 0.f;
     if (STEP) {
         float* bl = root + 26;
         ball.p = mk(bl[0], bl[1], bl[2]);
@@ -225,6 +244,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         ball.v = mk(bl[7], bl[8], bl[9]);
         ball.w = mk(bl[10], bl[11], bl[12]);
         if (live && role == 0) pre_vx[e] = ball.v.x;                                                               // TA:1143
+        pre_vx_reg_out = ball.v.x;
 
         for (int sub = 0; sub < P.substeps; sub++) {
             // ---- pass 1: kinematics + each link's own inertia / bias / contacts, base -> tip of this lane's limb
@@ -304,40 +324,21 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
             if (role == 3) ball_substep<ModelG1TA, 1>(K, ball, g, bound);
             __builtin_amdgcn_wave_barrier();                             // lane 2's waist dofs before every lane's next pass 1
         }
-        if (live) {
-            if (role == 0) {
-                root[0] = base.p.x; root[1] = base.p.y; root[2] = base.p.z;
-                for (int k = 0; k < 4; k++) root[3 + k] = base.quat[k];
-                root[7] = base.vw.x; root[8] = base.vw.y; root[9] = base.vw.z;
-                root[10] = base.ww.x; root[11] = base.ww.y; root[12] = base.ww.z;
-            }
-            if (role == 3) {
-                float* bl = root + 26;
-                bl[0] = ball.p.x; bl[1] = ball.p.y; bl[2] = ball.p.z;
-                for (int k = 0; k < 4; k++) bl[3 + k] = ball.quat[k];
-                bl[7] = ball.v.x; bl[8] = ball.v.y; bl[9] = ball.v.z; bl[10] = ball.w.x; bl[11] = ball.w.y; bl[12] = ball.w.z;
-            }
-        }
-        // dof_states [N,27,2] and dof_force [N,27] of the workgroup's envs are contiguous: the wave writes them out together
-        __builtin_amdgcn_wave_barrier();
-        const int nvalid = min(kQuadEnvs, n - blockIdx.x * kQuadEnvs);
-        float* dofs_out = dof_states + (size_t)blockIdx.x * kQuadEnvs * 2 * NDOF;
-        for (int t = lane; t < nvalid * 2 * NDOF; t += 64) {
-            const int env = t / (2 * NDOF), j = t - env * 2 * NDOF;
-            dofs_out[t] = (j & 1) ? s_qd[j >> 1][env] : s_q[j >> 1][env];
-        }
-        float* force_out = dof_force + (size_t)blockIdx.x * kQuadEnvs * NDOF;
-        for (int t = lane; t < nvalid * NDOF; t += 64) {
-            const int env = t / NDOF, j = t - env * NDOF;
-            force_out[t] = s_force[j][env];
-        }
     }
-    // ---- gym.refresh_rigid_body_state_tensor: every lane computes the rows of its limb (the waist rows: lane 2) into an LDS
-    // tile [16 envs][42 x 13] — the workgroup's rows are one contiguous 35 KB block of the tensor, written out coalesced
+    // ---- outputs.  Everything a workgroup writes is a contiguous block of its tensor (16 envs): it is assembled in LDS tiles
+    // (the link records are dead by now) and leaves coalesced.  Tiles: rigid_body_states [16][42 x 13], root_states [16][39],
+    // dof_states [16][54], dof_force [16][27] and, fused, the observation rows [16][313].
     __builtin_amdgcn_wave_barrier();
-    float* s_out = s_rec;                  // the link records are dead by now
+    constexpr int kRb = PPENV_NUM_BODIES * 13, kRoot = PPENV_NUM_ACTORS * 13, kDofs = 2 * NDOF;
+    float* t_rb = s_rec;
+    float* t_root = t_rb + kQuadEnvs * kRb;
+    float* t_dofs = t_root + kQuadEnvs * kRoot;
+    float* t_frc = t_dofs + kQuadEnvs * kDofs;
+    float* t_obs = t_frc + kQuadEnvs * NDOF;
+    float* t_pvx = t_obs + kQuadEnvs * PPENV_TA_NUM_OBS;
+    static_assert(kQuadEnvs * (kRb + kRoot + kDofs + NDOF + PPENV_TA_NUM_OBS + 1) <= kChainLen * kRec * 64, "output tiles exceed the record area");
     {
-        float* rb = s_out + es * (PPENV_NUM_BODIES * 13);
+        float* rb = t_rb + es * kRb;
         M3 Rw = quat_to_m3(base.quat);
         V3 pw = base.p, w = tmul(Rw, base.ww), v = tmul(Rw, base.vw);
         if (role == 0) write_link_rows(C, s_link[0], 0, Rw, pw, w, v, rb);
@@ -349,27 +350,56 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
             link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, E);
             if (!(role == 3 && k < 3)) write_link_rows(C, L, li, Rw, pw, w, v, rb);
         }
-        if (role == 1) {
-            const float* tr = root + 13;   // table row: untouched by the step
-            for (int k = 0; k < 13; k++) rb[40 * 13 + k] = tr[k];
+        float* tr = t_root + es * kRoot;
+        if (role == 0) {
+            const float br[13] = {base.p.x, base.p.y, base.p.z, base.quat[0], base.quat[1], base.quat[2], base.quat[3],
+                                  base.vw.x, base.vw.y, base.vw.z, base.ww.x, base.ww.y, base.ww.z};
+            for (int k = 0; k < 13; k++) tr[k] = br[k];
         }
+        if (role == 1) {
+            for (int k = 0; k < 13; k++) { float t = root[13 + k]; tr[13 + k] = t; rb[40 * 13 + k] = t; }   // table row: untouched by the step
+        }
+        if (STEP && role == 3) t_pvx[es] = pre_vx_reg_out;
         if (role == 3) {                   // ball row: this lane holds the stepped ball
+            float bl[13];
             if (STEP) {
-                const float bl[13] = {ball.p.x, ball.p.y, ball.p.z, ball.quat[0], ball.quat[1], ball.quat[2], ball.quat[3],
-                                      ball.v.x, ball.v.y, ball.v.z, ball.w.x, ball.w.y, ball.w.z};
-                for (int k = 0; k < 13; k++) rb[41 * 13 + k] = bl[k];
+                const float t[13] = {ball.p.x, ball.p.y, ball.p.z, ball.quat[0], ball.quat[1], ball.quat[2], ball.quat[3],
+                                     ball.v.x, ball.v.y, ball.v.z, ball.w.x, ball.w.y, ball.w.z};
+                for (int k = 0; k < 13; k++) bl[k] = t[k];
             } else {
-                for (int k = 0; k < 13; k++) rb[41 * 13 + k] = root[26 + k];
+                for (int k = 0; k < 13; k++) bl[k] = root[26 + k];
+            }
+            for (int k = 0; k < 13; k++) { tr[26 + k] = bl[k]; rb[41 * 13 + k] = bl[k]; }
+        }
+        if (STEP) {
+            for (int d = role; d < NDOF; d += 4) {
+                t_dofs[es * kDofs + 2 * d] = s_q[d][es];
+                t_dofs[es * kDofs + 2 * d + 1] = s_qd[d][es];
+                t_frc[es * NDOF + d] = s_force[d][es];
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
+    const int nv = min(kQuadEnvs, n - blockIdx.x * kQuadEnvs);
+    const size_t e0 = (size_t)blockIdx.x * kQuadEnvs;
+    // rigid_body_states are the PRE-reset ones (the reference refreshes them before reward / reset, TA:1150-1160)
     {
-        const int nv = min(kQuadEnvs, n - blockIdx.x * kQuadEnvs);
-        const int total2 = nv * (PPENV_NUM_BODIES * 13 / 2);                     // 546 floats per env = 273 float2
-        float2* dst = reinterpret_cast<float2*>(rb_states + (size_t)blockIdx.x * kQuadEnvs * PPENV_NUM_BODIES * 13);
-        const float2* src = reinterpret_cast<const float2*>(s_out);
-        for (int t = lane; t < total2; t += 64) dst[t] = src[t];
+        float2* dst = reinterpret_cast<float2*>(rb_states + e0 * kRb);
+        const float2* src = reinterpret_cast<const float2*>(t_rb);
+        for (int t = lane; t < nv * (kRb / 2); t += 64) dst[t] = src[t];
+    }
+    if (STEP) {
+        for (int t = lane; t < nv * NDOF; t += 64) dof_force[e0 * NDOF + t] = t_frc[t];
+        if (FUSE) {
+            if (live && role == 0)
+                tatask::ta_task_env(task.p, e, t_rb + es * kRb, task.initial_rb + (size_t)e * kRb, t_root + es * kRoot, t_dofs + es * kDofs, t_frc + es * NDOF,
+                                    t_pvx[es], task.reset_override ? task.reset_override + (size_t)e * 5 : nullptr, &task.flags[e], &task.episode[e],
+                                    &task.progress[e], t_obs + es * PPENV_TA_NUM_OBS, &task.rew[e], &task.reset[e], task.any_reset);
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < nv * PPENV_TA_NUM_OBS; t += 64) task.obs[e0 * PPENV_TA_NUM_OBS + t] = t_obs[t];
+        }
+        for (int t = lane; t < nv * kRoot; t += 64) root_states[e0 * kRoot + t] = t_root[t];
+        for (int t = lane; t < nv * kDofs; t += 64) dof_states[e0 * kDofs + t] = t_dofs[t];
     }
 }
 
@@ -441,13 +471,39 @@ int ppenv_ta_simulate(ppenv_ta_sim* s, int32_t n, const float* actions_dev, floa
         return PPENV_EINVAL;
     }
     if (s->quad)
-        hipLaunchKernelGGL(ta_sim_quad_kernel<true>, dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->K, n, actions_dev,
-                           root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev);
+        hipLaunchKernelGGL((ta_sim_quad_kernel<true, false>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->K, n, actions_dev,
+                           root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev, TaskArgs{});
     else
         hipLaunchKernelGGL(ta_sim_kernel<true>, dim3((n + kTaLanes - 1) / kTaLanes), dim3(kTaLanes), 0, (hipStream_t)stream, s->dev, s->K, n, actions_dev,
                            root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching ta_sim_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
+}
+
+int ppenv_ta_step(ppenv_ta_sim* s, const ppenv_ta_params* params, const float* actions_dev, const float* initial_rb_states_dev, float* root_states_dev,
+                  float* dof_states_dev, float* rb_states_dev, float* dof_force_dev, float* pre_ball_vx_dev, const float* reset_override_dev,
+                  uint32_t* flags_dev, uint32_t* episode_dev, int64_t* progress_dev, float* obs_dev, float* rew_dev, int64_t* reset_dev,
+                  uint32_t* scratch_any_reset_dev, void* stream) {
+    if (!s || !params || params->num_envs <= 0 || !actions_dev || !initial_rb_states_dev || !root_states_dev || !dof_states_dev || !rb_states_dev ||
+        !dof_force_dev || !pre_ball_vx_dev || !flags_dev || !episode_dev || !progress_dev || !obs_dev || !rew_dev || !reset_dev || !scratch_any_reset_dev) {
+        ppenv_set_error("ppenv_ta_step: NULL argument or num_envs <= 0");
+        return PPENV_EINVAL;
+    }
+    const int n = params->num_envs;
+    if (!s->quad) {   // another tree, or PPENV_TA_KERNEL=lane: the two launches
+        int rc = ppenv_ta_simulate(s, n, actions_dev, root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev, stream);
+        if (rc) return rc;
+        return ppenv_ta_post_physics_step(params, rb_states_dev, initial_rb_states_dev, root_states_dev, dof_states_dev, dof_force_dev, pre_ball_vx_dev,
+                                          reset_override_dev, flags_dev, episode_dev, progress_dev, obs_dev, rew_dev, reset_dev, scratch_any_reset_dev, stream);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch_any_reset_dev, 0, sizeof(uint32_t), st) != hipSuccess) { ppenv_set_error("hipMemsetAsync failed"); return PPENV_EHIP; }
+    TaskArgs t{*params, initial_rb_states_dev, reset_override_dev, flags_dev, episode_dev, (long long*)progress_dev, obs_dev, rew_dev, (long long*)reset_dev,
+               scratch_any_reset_dev};
+    hipLaunchKernelGGL((ta_sim_quad_kernel<true, true>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, st, s->dev, s->host.sc, s->K, n, actions_dev,
+                       root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev, t);
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching the fused 27-dof step failed"); return PPENV_EHIP; }
+    return ppenv_ta_clear_counts(n, flags_dev, scratch_any_reset_dev, stream);
 }
 
 int ppenv_ta_forward_kinematics(ppenv_ta_sim* s, int32_t n, const float* root_states_dev, const float* dof_states_dev, float* rb_states_dev,
@@ -457,9 +513,9 @@ int ppenv_ta_forward_kinematics(ppenv_ta_sim* s, int32_t n, const float* root_st
         return PPENV_EINVAL;
     }
     if (s->quad)
-        hipLaunchKernelGGL(ta_sim_quad_kernel<false>, dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->K, n,
+        hipLaunchKernelGGL((ta_sim_quad_kernel<false, false>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->K, n,
                            (const float*)nullptr, const_cast<float*>(root_states_dev), const_cast<float*>(dof_states_dev), rb_states_dev,
-                           (float*)nullptr, (float*)nullptr);
+                           (float*)nullptr, (float*)nullptr, TaskArgs{});
     else
         hipLaunchKernelGGL(ta_sim_kernel<false>, dim3((n + kTaLanes - 1) / kTaLanes), dim3(kTaLanes), 0, (hipStream_t)stream, s->dev, s->K, n,
                            (const float*)nullptr, const_cast<float*>(root_states_dev), const_cast<float*>(dof_states_dev), rb_states_dev,

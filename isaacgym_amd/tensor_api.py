@@ -87,6 +87,23 @@ class TASim:
         _lib.check(self.L.ppenv_ta_simulate(self.h, n, actions.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(), rb_states.data_ptr(),
                                             dof_force.data_ptr(), pre_ball_vx.data_ptr(), self._stream()))
 
+    def step(self, state, actions, initial_rb_states, root_states, dof_states, rb_states, dof_force, pre_ball_vx, reset_override=None):
+        """ppenv_ta_step: simulate + post_physics_step (on `state`: a TAState) in one launch."""
+        n = self.num_envs
+        for t, k in ((actions, n * 27), (initial_rb_states, n * 42 * 13), (root_states, n * 39), (dof_states, n * 54), (rb_states, n * 42 * 13),
+                     (dof_force, n * 27), (pre_ball_vx, n)):
+            self._check(t, k)
+        ov = None
+        if reset_override is not None:
+            ov = reset_override.to(self.device, torch.float32).reshape(n, 5).contiguous()
+        _lib.check(self.L.ppenv_ta_step(
+            self.h, C.byref(state.params), actions.data_ptr(), initial_rb_states.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(),
+            rb_states.data_ptr(), dof_force.data_ptr(), pre_ball_vx.data_ptr(), ov.data_ptr() if ov is not None else None, state.flags.data_ptr(),
+            state.episode.data_ptr(), state.progress_buf.data_ptr(), state.obs_buf.data_ptr(), state.rew_buf.data_ptr(), state.reset_buf.data_ptr(),
+            state._any_reset.data_ptr(), self._stream()))
+        if ov is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+
     def forward_kinematics(self, root_states, dof_states, rb_states):
         n = self.num_envs
         for t, k in ((root_states, n * 39), (dof_states, n * 54), (rb_states, n * 42 * 13)):
@@ -96,11 +113,12 @@ class TASim:
 
 class TAEnv:
     """HumanoidPingpongTiltNESSparse27DOF (tasks/humanoid_pingpong_3_actor_all_dof.py:65) as a native task: the tensors the
-    reference class wraps (TA:161-251) live here, `step` = pre_physics_step + simulate (ppenv_ta_simulate) + post_physics_step
-    (ppenv_ta_post_physics_step) — two launches and the tiny count-flag clear.  Surface: obs_buf [N,313], rew_buf, reset_buf,
-    progress_buf, 27 actions."""
+    reference class wraps (TA:161-251) live here, `step` = pre_physics_step + simulate + post_physics_step in one launch
+    (ppenv_ta_step) plus the tiny count-flag clear; `fused=False` keeps the two launches (ppenv_ta_simulate +
+    ppenv_ta_post_physics_step).  Surface: obs_buf [N,313], rew_buf, reset_buf, progress_buf, 27 actions."""
 
-    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_offset=0, env=None):
+    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_offset=0, env=None, fused=True):
+        self.fused = bool(fused)
         self.device = torch.device(device)
         n = self.num_envs = int(num_envs)
         self.num_obs, self.num_actions, self.num_agents = scene.TA_NUM_OBS, scene.TA_NUM_DOF, 1
@@ -124,8 +142,12 @@ class TAEnv:
     def step(self, actions):
         if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
-        self.sim.simulate(actions, self.root_states, self.dof_states, self.rb_states, self.dof_force_tensor, self.pre_ball_vx)
-        self.state.post_physics_step(self.rb_states, self.initial_rb_states, self.root_states, self.dof_states, self.dof_force_tensor, self.pre_ball_vx)
+        if self.fused:
+            self.sim.step(self.state, actions, self.initial_rb_states, self.root_states, self.dof_states, self.rb_states, self.dof_force_tensor,
+                          self.pre_ball_vx)
+        else:
+            self.sim.simulate(actions, self.root_states, self.dof_states, self.rb_states, self.dof_force_tensor, self.pre_ball_vx)
+            self.state.post_physics_step(self.rb_states, self.initial_rb_states, self.root_states, self.dof_states, self.dof_force_tensor, self.pre_ball_vx)
         return {"obs": self.obs_buf}, self.rew_buf, self.reset_buf, {}
 
     def close(self):

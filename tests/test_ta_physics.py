@@ -221,3 +221,26 @@ def test_ta_vec_task_surface():
     assert task.body_states.shape == (n, 42, 13) and task.dof_pos.shape == (n, 27)
     assert task.env.params.hit_table_reward == 3000.0 and task.env.params.max_episode_length == 160    # 27DOFG1.yaml:10,21
     assert torch.isfinite(od["obs"]).all()
+
+
+@pytest.mark.gpu
+def test_ta_fused_step_equals_the_two_launches():
+    """ppenv_ta_step (task arithmetic on the rigid-body kernel's LDS tiles) vs ppenv_ta_simulate + ppenv_ta_post_physics_step
+    (pinned to the reference's post_physics_step by post_physics_TA.npz): same tensors after every step, through resets."""
+    import torch
+    from isaacgym_amd.tensor_api import TAEnv
+    n = 1000   # ragged last workgroup
+    a_, b_ = TAEnv(n, device="cuda:0", seed=3, fused=True), TAEnv(n, device="cuda:0", seed=3, fused=False)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for t in range(170):     # past the 160-step time-out: every env resets once
+        a = torch.rand(n, 27, device="cuda", generator=gen) * 2 - 1
+        a_.step(a)
+        b_.step(a)
+        for name in ("reset_buf", "progress_buf"):
+            assert torch.equal(getattr(a_, name), getattr(b_, name)), (name, t)
+        assert torch.equal(a_.state.flags, b_.state.flags) and torch.equal(a_.state.episode, b_.state.episode), t
+        for name in ("obs_buf", "rew_buf", "root_states", "dof_states", "rb_states", "dof_force_tensor", "pre_ball_vx"):
+            x, y = getattr(a_, name), getattr(b_, name)
+            assert torch.allclose(x, y, rtol=1e-6, atol=1e-6), (name, t, float((x - y).abs().max()))
+    assert int(a_.state.episode.sum()) == n
+    a_.close(); b_.close()
