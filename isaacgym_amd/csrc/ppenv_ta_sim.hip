@@ -391,10 +391,13 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
     if (STEP) {
         for (int t = lane; t < nv * NDOF; t += 64) dof_force[e0 * NDOF + t] = t_frc[t];
         if (FUSE) {
-            if (live && role == 0)
-                tatask::ta_task_env(task.p, e, t_rb + es * kRb, task.initial_rb + (size_t)e * kRb, t_root + es * kRoot, t_dofs + es * kDofs, t_frc + es * NDOF,
-                                    t_pvx[es], task.reset_override ? task.reset_override + (size_t)e * 5 : nullptr, &task.flags[e], &task.episode[e],
-                                    &task.progress[e], t_obs + es * PPENV_TA_NUM_OBS, &task.rew[e], &task.reset[e], task.any_reset);
+            {   // the four lanes of the quad share the env's task arithmetic (lanes past the last env compute on env n - 1, store nothing)
+                const int ec = live ? e : n - 1;
+                tatask::ta_task_env<4>(task.p, ec, t_rb + es * kRb, task.initial_rb + (size_t)ec * kRb, t_root + es * kRoot, t_dofs + es * kDofs,
+                                       t_frc + es * NDOF, t_pvx[es], task.reset_override ? task.reset_override + (size_t)ec * 5 : nullptr, &task.flags[ec],
+                                       &task.episode[ec], &task.progress[ec], t_obs + es * PPENV_TA_NUM_OBS, &task.rew[ec], &task.reset[ec], task.any_reset,
+                                       role, live);
+            }
             __builtin_amdgcn_wave_barrier();
             for (int t = lane; t < nv * PPENV_TA_NUM_OBS; t += 64) task.obs[e0 * PPENV_TA_NUM_OBS + t] = t_obs[t];
         }

@@ -14,13 +14,32 @@ constexpr int TA_NBAL = PPENV_TA_NUM_BALANCE_BODIES;
 __device__ const int kTaObsIds[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};   // bodyStatesIdPingpong, 27DOF yaml:56
 __device__ const int kTaBalIds[TA_NBAL] = {0, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 27};   // yaml:57
 
+// sum over the NR lanes that share an env (NR = 4: the lanes of a quad, lane & 3 = role; every lane of the quad must call it)
+template <int NR>
+__device__ __forceinline__ float lanes_sum(float x) {
+    if (NR == 4) { x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); }
+    return x;
+}
+
 // i: env index local to `p` (keys the reset draws together with p.env_id_offset).  rb [42][13], irb [42][13] (initial body
 // states), root [3][13] and dofs [27][2] (updated in place on reset), force_row [27], ov_row: 5 reset values or null,
 // o: the 313-wide observation row.
+// NR lanes may share the env (NR = 1, or the 4 lanes of a quad with role = lane & 3): the 23-body sums and the observation
+// blocks are split over them, the scalar reward / reset logic is computed by every lane, and role 0 alone writes what is
+// per env.  `write` = false computes without storing (lanes past the last env still take part in the shuffles); when NR > 1
+// root / dofs must be memory all NR lanes see in program order (an LDS tile).
+template <int NR>
 __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, const float* rb, const float* irb, float* root, float* dofs,
                                             const float* force_row, float pvx, const float* ov_row, uint32_t* flags_i, uint32_t* episode_i,
-                                            long long* progress_i, float* o, float* rew_i, long long* reset_i, uint32_t* any_reset) {
+                                            long long* progress_i, float* o, float* rew_i, long long* reset_i, uint32_t* any_reset, int role,
+                                            bool write) {
+    const bool owner = write && role == 0;
     float* ball = root + 2 * 13;
+    float bs[13];                            // the ball row as this lane sees it (post-reset further down)
+#pragma unroll
+    for (int k = 0; k < 13; k++) bs[k] = ball[k];
+    const float root_x = root[0];
+    const uint32_t ep_in = *episode_i;
     float q[TA_ND], qd[TA_ND];
 #pragma unroll
     for (int d = 0; d < TA_ND; d++) { q[d] = dofs[2 * d]; qd[d] = dofs[2 * d + 1]; }
@@ -31,7 +50,7 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
 
     // ---- compute_imitation_reward TA:1313-1418 (is_g1)
     float pos_acc = 0.f, vel_acc = 0.f, norm_acc = 0.f;
-    for (int j = 0; j < TA_NBAL; j++) {
+    for (int j = role; j < TA_NBAL; j += NR) {
         const float* b = rb + kTaBalIds[j] * 13;
         const float* r = irb + kTaBalIds[j] * 13;
         float dp0 = r[0] - b[0], dp1 = r[1] - b[1], dp2 = r[2] - b[2];
@@ -41,6 +60,7 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
         float e0 = b[0] - r[0], e1 = b[1] - r[1], e2 = b[2] - r[2];
         norm_acc += sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
     }
+    pos_acc = lanes_sum<NR>(pos_acc); vel_acc = lanes_sum<NR>(vel_acc); norm_acc = lanes_sum<NR>(norm_acc);
     float r_body_pos = expf(-50.f * (pos_acc / (float)TA_NBAL));                // TA:1349-1351
     float r_body_vel = expf(-4.0f * (vel_acc / (float)TA_NBAL));                // TA:1354-1356
     float s22 = 0.f, s5 = 0.f, sv = 0.f;
@@ -59,7 +79,7 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
 
     // ---- compute_pingpong_reward_nv TA:1440-1690
     const float* paddle = rb + 39 * 13;
-    const float bx = ball[0], by = ball[1], bz = ball[2], vx = ball[7];
+    const float bx = bs[0], by = bs[1], bz = bs[2], vx = bs[7];
     const float pelvis_h = rb[2];
     if (has_fallen) f |= PPENV_TA_COUNT_FALL_DOWN;                              // TA:1525-1529
     const bool x_close = fabsf(bx - paddle[0]) < 0.2f;                          // TA:1544
@@ -74,7 +94,7 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
     if (hit_paddle) f |= PPENV_TA_COUNT_HIT_PADDLE;
     float vel_reward = (hit_paddle && !paddle_cond && !hum_die) ? p.alpha_velocity_reward * fabsf(vx) : 0.f;   // TA:1586-1590
     if (x_close) f |= PPENV_TA_FLAG_PADDLE_COND;                                // TA:1595
-    float time_penalty = (bx > root[0] && vx < 0.f) ? -0.01f * (float)prog : 0.f;   // TA:1602-1607
+    float time_penalty = (bx > root_x && vx < 0.f) ? -0.01f * (float)prog : 0.f;   // TA:1602-1607
     // compute_gradient_penalty TA:1245-1301
     const bool z_in = bz >= 0.82f && bz <= 0.83f && vx > 0.f;
     float ddx = bx - 2.5f, ddy = by - 0.0f;
@@ -104,9 +124,9 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
 
     // ---- _reset_idx TA:965-1028
     if (rst) {
-        atomicOr(any_reset, 1u);
-        const uint32_t ep = *episode_i + 1u;
-        *episode_i = ep;
+        if (owner) atomicOr(any_reset, 1u);
+        const uint32_t ep = ep_in + 1u;
+        if (owner) *episode_i = ep;
         float ov[5];
         if (ov_row) {
 #pragma unroll
@@ -132,28 +152,37 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
             ov[2] = -speed * ca * cz; ov[3] = speed * sa * cz; ov[4] = speed * sz;   // TA:370-375
         }
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
+        for (int k = 0; k < 7; k++) bs[k] = p.init_root[2][k];
 #pragma unroll
-            for (int k = 0; k < 7; k++) root[a * 13 + k] = p.init_root[a][k];
+        for (int k = 7; k < 13; k++) bs[k] = 0.f;
+        bs[1] = ov[0]; bs[2] = ov[1]; bs[7] = ov[2]; bs[8] = ov[3]; bs[9] = ov[4];
+        if (owner) {
 #pragma unroll
-            for (int k = 7; k < 13; k++) root[a * 13 + k] = 0.f;
+            for (int a = 0; a < 2; a++) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) root[a * 13 + k] = p.init_root[a][k];
+#pragma unroll
+                for (int k = 7; k < 13; k++) root[a * 13 + k] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 13; k++) ball[k] = bs[k];
         }
-        ball[1] = ov[0]; ball[2] = ov[1]; ball[7] = ov[2]; ball[8] = ov[3]; ball[9] = ov[4];
 #pragma unroll
         for (int d = 0; d < TA_ND; d++) {
             q[d] = p.init_dof_pos[d]; qd[d] = p.init_dof_vel[d];
-            dofs[2 * d] = q[d]; dofs[2 * d + 1] = qd[d];
+            if (owner) { dofs[2 * d] = q[d]; dofs[2 * d + 1] = qd[d]; }
         }
         prog = 0;
         f &= ~(PPENV_TA_FLAG_PADDLE_COND | PPENV_TA_FLAG_DIE_PENALTY_CALC | PPENV_TA_FLAG_HUMANOID_DIE_CALC | PPENV_TA_FLAG_HIT_TABLE_CALC);   // TA:1021-1024
     }
-    *progress_i = prog; *flags_i = f; *rew_i = reward; *reset_i = rst;
+    if (owner) { *progress_i = prog; *flags_i = f; *rew_i = reward; *reset_i = rst; }
 
     // ---- compute_observations TA:867-904 (body states pre-reset, dof / ball post-reset)
     float rq[4] = {rb[3], rb[4], rb[5], rb[6]}, hinv[4];
     heading_quat_inv(rq, hinv);
     const V3 rootp = mk(rb[0], rb[1], rb[2]);
-    for (int j = 0; j < NB; j++) {
+    if (!write) return;
+    for (int j = role; j < NB; j += NR) {
         const float* b = rb + kTaObsIds[j] * 13;
         V3 lp = heading_rotate(hinv, mk(b[0], b[1], b[2]) - rootp);
         V3 lv = heading_rotate(hinv, mk(b[7], b[8], b[9]));
@@ -161,12 +190,15 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
         o[30 + 3 * j] = lv.x; o[30 + 3 * j + 1] = lv.y; o[30 + 3 * j + 2] = lv.z;
     }
 #pragma unroll
-    for (int d = 0; d < TA_ND; d++) { o[60 + d] = q[d]; o[60 + TA_ND + d] = qd[d] * 0.1f; }
-    V3 lb = heading_rotate(hinv, mk(ball[0], ball[1], ball[2]) - rootp);
-    V3 lv = heading_rotate(hinv, mk(ball[7], ball[8], ball[9]));
-    o[114] = lb.x; o[115] = lb.y; o[116] = lb.z; o[117] = lv.x; o[118] = lv.y; o[119] = lv.z;
-    o[120] = lb.y + (lv.y / (-lv.x + 1e-6f)) * lb.x;                            // TA:1839
-    for (int j = 0; j < TA_NBAL; j++) {                                         // TA:1891-1927
+    for (int d = 0; d < TA_ND; d++)
+        if (NR == 1 || (d & (NR - 1)) == role) { o[60 + d] = q[d]; o[60 + TA_ND + d] = qd[d] * 0.1f; }
+    if (role == 0) {
+        V3 lb = heading_rotate(hinv, mk(bs[0], bs[1], bs[2]) - rootp);
+        V3 lv = heading_rotate(hinv, mk(bs[7], bs[8], bs[9]));
+        o[114] = lb.x; o[115] = lb.y; o[116] = lb.z; o[117] = lv.x; o[118] = lv.y; o[119] = lv.z;
+        o[120] = lb.y + (lv.y / (-lv.x + 1e-6f)) * lb.x;                        // TA:1839
+    }
+    for (int j = role; j < TA_NBAL; j += NR) {                                  // TA:1891-1927
         const float* b = rb + kTaBalIds[j] * 13;
         const float* r = irb + kTaBalIds[j] * 13;
         V3 t = heading_rotate(hinv, mk(r[0] - b[0], r[1] - b[1], r[2] - b[2]));
@@ -175,7 +207,8 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
         o[121 + 3 * TA_NBAL + 3 * j] = tv.x; o[122 + 3 * TA_NBAL + 3 * j] = tv.y; o[123 + 3 * TA_NBAL + 3 * j] = tv.z;
     }
 #pragma unroll
-    for (int d = 0; d < TA_ND; d++) { o[121 + 6 * TA_NBAL + d] = p.init_dof_pos[d]; o[121 + 6 * TA_NBAL + TA_ND + d] = p.init_dof_vel[d]; }
+    for (int d = 0; d < TA_ND; d++)
+        if (NR == 1 || (d & (NR - 1)) == role) { o[121 + 6 * TA_NBAL + d] = p.init_dof_pos[d]; o[121 + 6 * TA_NBAL + TA_ND + d] = p.init_dof_vel[d]; }
 }
 }  // namespace tatask
 }  // namespace pp
