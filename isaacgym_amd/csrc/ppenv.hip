@@ -231,6 +231,25 @@ __device__ __forceinline__ void flush_obs_cols(const float* s_obs, float* obs, i
     constexpr int per_row = (C1 - C0) / 4;
     const int total = nrows * per_row;
     typedef float f4v __attribute__((ext_vector_type(4)));
+    if (nrows == kBlock) {
+        // full workgroup (every one but a ragged last): the trip count is a constant, so all LDS reads of the flush are in
+        // flight before the first store instead of one read-wait-store round trip per iteration
+        f4v val[per_row];
+#pragma unroll
+        for (int it = 0; it < per_row; it++) {
+            const int k = it * kBlock + lane;
+            const int r = k / per_row, c = C0 + 4 * (k - r * per_row);
+            const float* src = &s_obs[(t0 + r) * kObsStride + c];
+            val[it] = f4v{src[0], src[1], src[2], src[3]};
+        }
+#pragma unroll
+        for (int it = 0; it < per_row; it++) {
+            const int k = it * kBlock + lane;
+            const int r = k / per_row, c = C0 + 4 * (k - r * per_row);
+            __builtin_nontemporal_store(val[it], reinterpret_cast<f4v*>(obs + ((g0 + (size_t)r * gstep) * PPENV_NUM_OBS + c)));
+        }
+        return;
+    }
     for (int k = lane; k < total; k += kBlock) {
         int r = k / per_row, c = C0 + 4 * (k - r * per_row);
         const float* src = &s_obs[(t0 + r) * kObsStride + c];
