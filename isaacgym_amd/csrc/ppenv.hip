@@ -306,6 +306,10 @@ struct MovingGeom {
 template <class T, int A, int G>
 __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
     constexpr int kGeo = MovingGeom<T>::count();
+    // Who writes dof_pos / dof_vel / dof_force.  With one humanoid the arm wave is the critical path and would sit waiting
+    // for the ball wave's reset decision just to pick between q and the initial pose: the ball wave, which has both, stores
+    // them instead.  With two humanoids the ball wave is the critical path and the arm waves keep the stores.
+    constexpr bool kBallStoresDofs = A == 1;
     __shared__ float s_geom[G ? 2 : 1][G ? A : 1][G ? kGeo : 1][G ? kBlock : 1];   // geometry of boundary s in slot s & 1
     __shared__ int s_gflag[A];                         // arm -> ball: boundaries whose geometry is in LDS
     __shared__ int s_bflag;                            // ball -> arm: substeps the ball has finished (slot reuse)
@@ -399,6 +403,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         PP_STAMP_AT(6);
         __builtin_amdgcn_wave_barrier();   // columns [0,60) of this agent's rows were written by this wave only: no rendezvous needed
         flush_obs_cols<0, 6 * NB>(s_obs, b.obs, arm * kBlock, nvalid, (size_t)base * A + arm, A, lane);
+        if (kBallStoresDofs) return;       // (A = 1) the ball wave holds the final dof state and the reset decision: it stores them
         await(&s_flag_ball, 1);            // the ball wave's reset decision
         PP_STAMP_AT(7);
         if (active) {
@@ -509,6 +514,14 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     for (int a = 0; a < A; a++)
         flush_obs_cols<6 * NB, PPENV_NUM_OBS>(s_obs, b.obs, a * kBlock, nvalid, (size_t)base * A + a, A, lane);
     if (active) {
+        if (kBallStoresDofs) {             // st.q / st.qd already show the reset state where the env reset (TN keeps its dof state)
+#pragma unroll
+            for (int d = 0; d < A * ND; d++) {
+                st_state(&b.dof_pos[(size_t)d * n + i], st.q[d]);
+                st_state(&b.dof_vel[(size_t)d * n + i], st.qd[d]);
+                st_state(&b.dof_force[(size_t)d * n + i], st.dof_force[d]);
+            }
+        }
         store_ball(b, n, i, st.ball);
         store_task<A>(b, n, i, st, rew, reset);
     }
