@@ -16,6 +16,12 @@ reference prints (mean reward, mean progress — TT:763-766 — and the episode 
 Inputs are synthetic and resident in HBM before the timed region: a pool of U(-1,1) action
 tensors from torch.Generator(seed 0).  Timing: W warm-up steps, barrier + synchronize, exactly K
 steps, synchronize + barrier; the max over ranks is used.  Rank 0 prints ONE JSON line.
+
+The steps of one PPO horizon (32 launches of the step kernel on the pool's action tensors) are
+captured once into a HIP graph and replayed: the launches are the same kernels on the same
+stream in the same order, the graph only removes the per-launch submission from the loop
+(rocprofv3's kernel trace shows the per-kernel duration drop from 12.6 to 11.8 us).  K steps =
+K // 32 replays + K % 32 eager launches; --no-graph launches every step eagerly.
 """
 import argparse
 import json
@@ -142,6 +148,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", default=VARIANT, choices=["TT", "TN", "T3", "T4", "TA"],
                     help="task variant; the headline workload is TT (BASELINE.json configs[2]), the others are parity-test cases")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph of one horizon")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL (default); gloo only to rehearse the rank logic on one GPU")
     args = ap.parse_args()
 
@@ -167,11 +174,6 @@ def main():
         sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible; one process per GPU is required")
     device = torch.device("cuda", local_rank % max(ndev, 1))   # the modulo only matters for the gloo rehearsal
     torch.cuda.set_device(device)
-    if world > 1:
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
 
     n = args.num_envs
     off, cnt = D.shard_range(n * world, rank, world)   # contiguous global env ids; trajectories do not depend on the split
@@ -181,18 +183,43 @@ def main():
         with torch.cuda.device(device):
             env = TAEnv(cnt, device=device, seed=0, env_id_offset=off)
         pool = [(torch.rand(n, 27, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
-        stats = None
     else:
         env = PPEnv(scene.build_config(args.variant, num_envs=cnt, seed=0, device_id=device.index, env_id_offset=off), device=device)
         pool = [(torch.rand(n * env.num_agents, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
-        stats = D.AsyncHorizonStats(env)   # what the reference prints every 40 steps (TT:763-766) + finished episodes
+
+    # The graph is captured BEFORE the process group exists: a capture fails if another thread of the process (the RCCL
+    # watchdog) touches the runtime while it is open.
+    graph = None
+    if not args.no_graph:
+        for s in range(HORIZON):           # lazy initialisation (streams, workspaces) must not happen inside the capture
+            env.step(pool[s & 7])
+        torch.cuda.synchronize(device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for s in range(HORIZON):       # HORIZON is a multiple of the pool size: the replayed sequence is the eager one
+                env.step(pool[s & 7])
+        torch.cuda.synchronize(device)
+
+    if world > 1:
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
+    # what the reference prints every 40 steps (TT:763-766) + finished episodes; all-reduced over the ranks
+    stats = D.AsyncHorizonStats(env) if args.variant != "TA" else None
 
     def horizon_stats():
         if stats is not None:
             stats.push()               # one reduction launch + one asynchronous 4-double all-reduce over RCCL
 
     def run(k):
-        for s in range(k):
+        done = 0
+        if graph is not None:
+            for _ in range(k // HORIZON):
+                graph.replay()
+                horizon_stats()
+            done = (k // HORIZON) * HORIZON
+        for s in range(done, k):
             env.step(pool[s & 7])
             if (s + 1) % HORIZON == 0:
                 horizon_stats()
@@ -220,10 +247,16 @@ def main():
         wall = float(t.item())
     # roofline: average duration of step_kernel alone — a region of back-to-back launches with nothing else on
     # the stream, bracketed by HIP events on the stream the kernel is launched on (torch's current stream)
-    kreg = min(args.steps, 500)
+    kreg = min(args.steps, 480)
+    if graph is not None:
+        kreg = max(HORIZON, (kreg // HORIZON) * HORIZON)
     ev0.record()
-    for s in range(kreg):
-        env.step(pool[s & 7])
+    if graph is not None:
+        for _ in range(kreg // HORIZON):
+            graph.replay()
+    else:
+        for s in range(kreg):
+            env.step(pool[s & 7])
     ev1.record()
     torch.cuda.synchronize(device)
     kernel_us = ev0.elapsed_time(ev1) * 1e3 / kreg
@@ -254,6 +287,7 @@ def main():
                                    "random U(-1,1) actions, 2 physics substeps per step, fused step kernel",
                        "variant": args.variant,
                        "num_envs_per_gpu": n, "global_envs": n * world, "horizon_stats_every": HORIZON,
+                       "launch": "eager" if graph is None else f"HIP graph of {HORIZON} steps, replayed",
                        "parallelism": f"env-shard x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(n) if args.variant == VARIANT else None, "kernel": kernel_name(args.variant), "avg_kernel_us": kernel_us,
