@@ -18,5 +18,5 @@ g++ $SAN -fPIC -shared -std=c++17 -ffp-contract=fast -fno-signed-zeros -ffinite-
 touch oracle/libppenv_oracle.so tests/csrc/libppenv_hostshim.so
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" \
-python -m pytest tests/test_oracle_golden.py tests/test_kernel_math_host.py tests/test_ta_golden.py tests/test_t4_golden.py \
+python -m pytest tests/test_oracle_golden.py tests/test_kernel_math_host.py tests/test_ta_golden.py tests/test_t4_golden.py tests/test_t4_fused.py tests/test_ta_physics.py \
     tests/test_host_logic.py -x -q -m "not gpu" -k "not layout and not exports"
