@@ -390,10 +390,10 @@ def build_config(variant, cfg=None, num_envs=None, seed=0, device_id=0, env_id_o
         jt.effort = spec["effort"]
         jt.vel_limit = spec["vel"]
         jt.armature = 0.0
-        parts = [(spec["mass"], spec["com"], np.diag(spec["inertia"]), np.eye(3))]
+        parts = [(spec["mass"], spec["com"], _spec_inertia(spec["inertia"]), np.eye(3))]
         if j == NUM_DOF - 1:
             hand_o = np.asarray(G1_HAND["xyz"])
-            parts.append((G1_HAND["mass"], hand_o + np.asarray(G1_HAND["com"]), np.diag(G1_HAND["inertia"]), np.eye(3)))
+            parts.append((G1_HAND["mass"], hand_o + np.asarray(G1_HAND["com"]), _spec_inertia(G1_HAND["inertia"]), np.eye(3)))
             pad_o = hand_o + np.asarray(PADDLE["xyz_from_hand"])
             m, r = PADDLE["mass"], PADDLE["radius"]
             n = np.asarray(PADDLE["normal"], dtype=np.float64)
@@ -639,8 +639,13 @@ def _mirror_arm(spec):
     return d
 
 
+def _spec_inertia(v):
+    """inertia entry of a spec: the diagonal (xx, yy, zz) or the 6-vector xx yy zz xy xz yz -> 3x3"""
+    return np.diag(v) if len(v) == 3 else _inertia_mat(v)
+
+
 def _diag_parts(spec, offset=(0.0, 0.0, 0.0)):
-    return (spec["mass"], np.asarray(offset) + np.asarray(spec.get("com", (0, 0, 0))), np.diag(spec.get("inertia", (0, 0, 0))), np.eye(3))
+    return (spec["mass"], np.asarray(offset) + np.asarray(spec.get("com", (0, 0, 0))), _spec_inertia(spec.get("inertia", (0, 0, 0))), np.eye(3))
 
 
 class TALink(C.Structure):
@@ -731,7 +736,14 @@ def build_ta_model():
         f.body, f.link = body, link
         _set(f.xyz, xyz)
         _set(f.rot, np.eye(3).reshape(-1))
-    contacts = [(6, p) for p in TA_FOOT["points"]] + [(12, p) for p in TA_FOOT["points"]] + TA_BODY_CONTACTS
+    fill_ta_contacts_and_limits(m)
+    return m
+
+
+def fill_ta_contacts_and_limits(m, contacts=None, bound=None):
+    """The parts of ppenv_ta_model that are not in a URDF: ground-contact points, contact / limit parameters of the physics
+    specification, the ball's broad-phase sphere.  contacts: [(link, point)], bound: (link, point); defaults are the G1 tree's."""
+    contacts = ([(6, p) for p in TA_FOOT["points"]] + [(12, p) for p in TA_FOOT["points"]] + TA_BODY_CONTACTS) if contacts is None else list(contacts)
     assert len(contacts) <= TA_MAX_CONTACTS
     m.num_contacts = len(contacts)
     for k, (link, pnt) in enumerate(contacts):
@@ -743,9 +755,24 @@ def build_ta_model():
     m.contact_fade_depth, m.contact_fade_force = TA_FOOT["fade_depth"], TA_FOOT["fade_force"]
     m.limit_stiffness, m.limit_damping, m.vel_limit_damping = TA_JOINT_LIMITS["stiffness"], TA_JOINT_LIMITS["damping"], TA_JOINT_LIMITS["vel_damping"]
     m.foot_friction = 0.5 * (1.0 + 0.5)      # PhysX average of plane 1.0 (TA yaml:78) and humanoid shapes 0.5 (TA:588)
-    m.bound_link = torso
-    _set(m.bound_center, right_arm[0]["xyz"])
+    link, pnt = (15, G1_RIGHT_ARM[0]["xyz"]) if bound is None else bound
+    m.bound_link = link
+    _set(m.bound_center, pnt)
     return m
+
+
+def use_arm_tables(arm_specs, hand=None, paddle=None):
+    """Replace the placeholder 7-dof chain tables (e.g. by isaacgym_amd.urdf.arm_specs of the real asset).  The compiled-in
+    model must then be regenerated (`python -m isaacgym_amd.modelgen`) and the library rebuilt: ppenv_create refuses a
+    config whose model differs from the compiled one."""
+    global G1_RIGHT_ARM, G1_HAND, PADDLE
+    if len(arm_specs) != NUM_DOF:
+        raise ValueError(f"the arm chain has {NUM_DOF} dofs")
+    G1_RIGHT_ARM = [dict(s) for s in arm_specs]
+    if hand is not None:
+        G1_HAND = dict(hand)
+    if paddle is not None:
+        PADDLE = dict(paddle)
 
 
 TASK_CFGS["TA"] = dict(

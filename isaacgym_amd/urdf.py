@@ -1,0 +1,315 @@
+"""URDF -> model tables: what replaces the UNVERIFIED placeholder data once the real assets exist.
+
+The reference loads `g1_29dof_rev_1_0_pingpong_fixed_except_right_arm.urdf` / `g1_27dof.urdf` from absolute paths on its
+author's machine (tasks/humanoid_pingpong_3_actor_tilt.py:415, tasks/humanoid_pingpong_3_actor_all_dof.py:470); neither file
+is in the reference.  The model data in `scene.py` are therefore recalled numbers.  This module reads a URDF (links with
+inertials, revolute / fixed joints with origins, axes and limits) and produces
+
+  * `arm_specs(robot, joint_names)`: the 7-dof chain tables in the format of `scene.G1_RIGHT_ARM` (feed `scene.use_arm_tables`,
+    then regenerate the compiled-in model with `python -m isaacgym_amd.modelgen` and rebuild),
+  * `ta_model(robot, dof_joint_names, body_names, ...)`: the 28-link tree of the 27-dof task as a `scene.TAModel` — welded
+    bodies (fixed joints) are merged into the link that carries them, exactly what `scene.build_ta_model` does by hand.
+
+`write_g1_urdf()` emits the placeholder model as a URDF; tests/golden/g1_27dof_placeholder.urdf is its output, and the tests
+check that parsing it reproduces the hand-built tables.  No real asset has been seen by this code.
+"""
+import math
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from . import scene
+
+
+class Link:
+    def __init__(self, name, mass=0.0, com=(0.0, 0.0, 0.0), com_rpy=(0.0, 0.0, 0.0), inertia=None):
+        self.name, self.mass = name, float(mass)
+        self.com = np.asarray(com, dtype=np.float64)
+        self.com_rot = scene.rpy_to_rot(*com_rpy)
+        self.inertia = np.zeros((3, 3)) if inertia is None else np.asarray(inertia, dtype=np.float64)   # about the com, inertial-frame axes
+
+
+class Joint:
+    def __init__(self, name, jtype, parent, child, xyz, rpy, axis, lower, upper, effort, velocity):
+        self.name, self.type, self.parent, self.child = name, jtype, parent, child
+        self.xyz, self.rpy = np.asarray(xyz, dtype=np.float64), tuple(float(v) for v in rpy)
+        self.axis = np.asarray(axis, dtype=np.float64)
+        self.lower, self.upper, self.effort, self.velocity = float(lower), float(upper), float(effort), float(velocity)
+
+
+class Robot:
+    def __init__(self, name, links, joints):
+        self.name, self.links, self.joints = name, links, joints
+        self.joint_of_child = {j.child: j for j in joints.values()}
+
+    def root(self):
+        children = set(self.joint_of_child)
+        roots = [n for n in self.links if n not in children]
+        if len(roots) != 1:
+            raise ValueError(f"URDF must have exactly one root link, found {roots}")
+        return roots[0]
+
+
+def _floats(text, n, default):
+    if text is None:
+        return tuple(default)
+    v = tuple(float(x) for x in text.split())
+    if len(v) != n:
+        raise ValueError(f"expected {n} numbers, got {text!r}")
+    return v
+
+
+def parse(text):
+    """URDF text -> Robot.  Only what the dynamics need: inertials, joint origins / axes / limits, the tree."""
+    root = ET.fromstring(text)
+    if root.tag != "robot":
+        raise ValueError("not a URDF: the root element is not <robot>")
+    links, joints = {}, {}
+    for e in root.findall("link"):
+        name = e.get("name")
+        inert = e.find("inertial")
+        if inert is None:
+            links[name] = Link(name)
+            continue
+        o = inert.find("origin")
+        com = _floats(o.get("xyz") if o is not None else None, 3, (0, 0, 0))
+        rpy = _floats(o.get("rpy") if o is not None else None, 3, (0, 0, 0))
+        mass = float(inert.find("mass").get("value"))
+        i = inert.find("inertia")
+        ixx, iyy, izz = (float(i.get(k, 0.0)) for k in ("ixx", "iyy", "izz"))
+        ixy, ixz, iyz = (float(i.get(k, 0.0)) for k in ("ixy", "ixz", "iyz"))
+        links[name] = Link(name, mass, com, rpy, [[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+    for e in root.findall("joint"):
+        name, jtype = e.get("name"), e.get("type")
+        if jtype not in ("revolute", "continuous", "fixed"):
+            raise ValueError(f"joint {name}: type {jtype!r} is not supported (revolute / continuous / fixed)")
+        o = e.find("origin")
+        xyz = _floats(o.get("xyz") if o is not None else None, 3, (0, 0, 0))
+        rpy = _floats(o.get("rpy") if o is not None else None, 3, (0, 0, 0))
+        ax = e.find("axis")
+        axis = _floats(ax.get("xyz") if ax is not None else None, 3, (1, 0, 0))
+        lim = e.find("limit")
+        lower = float(lim.get("lower", -math.pi)) if lim is not None else -math.pi
+        upper = float(lim.get("upper", math.pi)) if lim is not None else math.pi
+        effort = float(lim.get("effort", 0.0)) if lim is not None else 0.0
+        vel = float(lim.get("velocity", 0.0)) if lim is not None else 0.0
+        joints[name] = Joint(name, jtype, e.find("parent").get("link"), e.find("child").get("link"), xyz, rpy, axis, lower, upper, effort, vel)
+    for j in joints.values():
+        if j.parent not in links or j.child not in links:
+            raise ValueError(f"joint {j.name} names a link that does not exist")
+    return Robot(root.get("name", ""), links, joints)
+
+
+def load(path):
+    with open(path) as f:
+        return parse(f.read())
+
+
+def _axis_index(axis, name):
+    """The kernels take joints about a coordinate axis of the child frame (every G1 joint is one); a negative axis flips the
+    sign convention of q, which the tables do not carry."""
+    a = np.asarray(axis, dtype=np.float64)
+    k = int(np.argmax(np.abs(a)))
+    e = np.zeros(3)
+    e[k] = 1.0
+    if not np.allclose(a, e, atol=1e-9):
+        raise ValueError(f"joint {name}: axis {tuple(a)} is not +x, +y or +z of the child frame")
+    return k
+
+
+def _link_parts(link, offset=np.zeros(3), rot=np.eye(3)):
+    """(mass, com, I_com, R) of a link's inertial seen from a frame in which the link sits at `offset` / `rot`."""
+    if link.mass <= 0.0:
+        return None
+    return (link.mass, offset + rot @ link.com, link.inertia, rot @ link.com_rot)
+
+
+def arm_specs(robot, joint_names, body_index=None):
+    """The chain moved by `joint_names` (base -> tip) in the format of scene.G1_RIGHT_ARM.  `inertia` is the diagonal when the
+    link's inertia tensor is diagonal in the link axes, else the 6-vector xx yy zz xy xz yz."""
+    specs = []
+    for name in joint_names:
+        j = robot.joints[name]
+        if j.type == "fixed":
+            raise ValueError(f"joint {name} is fixed: a dof of the chain must be revolute")
+        link = robot.links[j.child]
+        inertia = link.com_rot @ link.inertia @ link.com_rot.T
+        off = [inertia[0, 1], inertia[0, 2], inertia[1, 2]]
+        inert = tuple(np.diag(inertia)) if np.allclose(off, 0.0, atol=1e-12) else tuple(np.diag(inertia)) + tuple(off)
+        specs.append(dict(name=j.child, body=(body_index or {}).get(j.child, -1), xyz=tuple(j.xyz), rpy=j.rpy, axis=_axis_index(j.axis, name),
+                          limits=(j.lower, j.upper), mass=link.mass, com=tuple(link.com), inertia=inert, effort=j.effort, vel=j.velocity))
+    return specs
+
+
+def ta_model(robot, dof_joint_names, body_names, gains=None, armature=None, contacts=None, bound=None):
+    """scene.TAModel of the 27-dof task from a URDF: link 0 = the root link, link k = the child of dof k's joint; every other
+    body is welded (through fixed joints) to one of them and is merged into it.  `body_names`: the 40 rigid-body names in Isaac
+    Gym's order (pingpong_note.txt:33).  Contacts / bound default to scene's (link indices of the G1 tree)."""
+    if len(dof_joint_names) != scene.TA_NUM_DOF or len(body_names) != scene.NUM_HUMANOID_BODIES:
+        raise ValueError("the 27-dof task has 27 dofs and 40 rigid bodies")
+    gains = list(scene.TA_P_GAINS) if gains is None else list(gains)
+    body_index = {n: i for i, n in enumerate(body_names)}
+    root = robot.root()
+    link_names = [root] + [robot.joints[n].child for n in dof_joint_names]
+    link_index = {n: i for i, n in enumerate(link_names)}
+
+    def carrier(name):
+        """(movable link index, offset, rotation) of a body: walk up through fixed joints."""
+        off, rot = np.zeros(3), np.eye(3)
+        while name not in link_index:
+            j = robot.joint_of_child[name]
+            if j.type != "fixed":
+                raise ValueError(f"link {name} hangs on movable joint {j.name}, which is not one of the 27 dofs")
+            r = scene.rpy_to_rot(*j.rpy)
+            off, rot = j.xyz + r @ off, r @ rot
+            name = j.parent
+        return link_index[name], off, rot
+
+    m = scene.TAModel()
+    merged = {i: [] for i in range(scene.TA_NUM_LINKS)}
+    fixed = []
+    for name in body_names:
+        if name in link_index:
+            p = _link_parts(robot.links[name])
+            if p is not None:
+                merged[link_index[name]].insert(0, p)
+        else:
+            li, off, rot = carrier(name)
+            p = _link_parts(robot.links[name], off, rot)
+            if p is not None:
+                merged[li].append(p)
+            fixed.append((body_index[name], li, off, rot))
+    if len(fixed) != scene.TA_NUM_FIXED:
+        raise ValueError(f"expected {scene.TA_NUM_FIXED} welded bodies, found {len(fixed)}")
+    for i, name in enumerate(link_names):
+        L = m.link[i]
+        if i == 0:
+            L.parent, L.axis, L.body = -1, 0, body_index[name]
+            scene._set(L.origin_xyz, (0, 0, 0))
+            scene._set(L.origin_rot, np.eye(3).reshape(-1))
+            L.lower = L.upper = L.kp = L.kd = L.effort = L.vel_limit = L.armature = 0.0
+        else:
+            j = robot.joints[dof_joint_names[i - 1]]
+            # the parent may be a welded body (e.g. the elbow link welded under the shoulder-roll link): fold its offset in
+            pi, poff, prot = carrier(j.parent)
+            if pi >= i:
+                raise ValueError("dof order must list parents before children")
+            L.parent, L.axis, L.body = pi, _axis_index(j.axis, j.name), body_index[name]
+            scene._set(L.origin_xyz, poff + prot @ j.xyz)
+            scene._set(L.origin_rot, (prot @ scene.rpy_to_rot(*j.rpy)).reshape(-1))
+            L.lower, L.upper = min(j.lower, j.upper), max(j.lower, j.upper)
+            L.kp, L.kd = gains[i - 1], gains[i - 1] / 40.0                      # TA:757-774
+            L.effort, L.vel_limit = j.effort, j.velocity
+            L.armature = scene.TA_ARMATURE if armature is None else armature
+        if not merged[i]:
+            raise ValueError(f"link {name} has no mass")
+        mass, com, inertia = scene.composite_inertial(merged[i])
+        L.mass = mass
+        scene._set(L.com, com)
+        scene._set(L.inertia, scene._inertia_vec(inertia))
+    for k, (body, li, off, rot) in enumerate(sorted(fixed, key=lambda t: t[0])):
+        f = m.fixed[k]
+        f.body, f.link = body, li
+        scene._set(f.xyz, off)
+        scene._set(f.rot, rot.reshape(-1))
+    scene.fill_ta_contacts_and_limits(m, contacts=contacts, bound=bound)
+    return m
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The placeholder model as a URDF (used to produce the test fixture; also documents what a real asset has to provide)
+G1_BODY_NAMES = ["pelvis", "imu_in_pelvis", "left_hip_pitch_link", "left_hip_roll_link", "left_hip_yaw_link", "left_knee_link",
+                 "left_ankle_pitch_link", "left_ankle_roll_link", "pelvis_contour_link", "right_hip_pitch_link", "right_hip_roll_link",
+                 "right_hip_yaw_link", "right_knee_link", "right_ankle_pitch_link", "right_ankle_roll_link", "waist_yaw_link", "waist_roll_link",
+                 "torso_link", "d435_link", "head_link", "imu_in_torso", "left_shoulder_pitch_link", "left_shoulder_roll_link",
+                 "left_shoulder_yaw_link", "left_elbow_link", "left_wrist_roll_link", "left_wrist_pitch_link", "left_wrist_yaw_link",
+                 "left_rubber_hand", "logo_link", "mid360_link", "right_shoulder_pitch_link", "right_shoulder_roll_link", "right_shoulder_yaw_link",
+                 "right_elbow_link", "right_wrist_roll_link", "right_wrist_pitch_link", "right_wrist_yaw_link", "right_rubber_hand",
+                 "pingpong_paddle"]   # tasks/pingpong_note.txt:33
+
+
+def _joint_name(link_name):
+    return link_name.replace("_link", "") + "_joint" if link_name.endswith("_link") else link_name + "_joint"
+
+
+def ta_dof_joint_names():
+    """The 27 dof joints in the order of TA:1303-1311 (left leg, right leg, waist, left arm, the five right-arm dofs)."""
+    legs = ["hip_pitch", "hip_roll", "hip_yaw", "knee", "ankle_pitch", "ankle_roll"]
+    arm = ["shoulder_pitch", "shoulder_roll", "shoulder_yaw", "elbow", "wrist_roll", "wrist_pitch", "wrist_yaw"]
+    names = [f"left_{n}_joint" for n in legs] + [f"right_{n}_joint" for n in legs] + ["waist_yaw_joint", "waist_roll_joint", "torso_joint"]
+    names += [f"left_{n}_joint" for n in arm] + [f"right_{n}_joint" for n in ("shoulder_pitch", "shoulder_roll", "wrist_roll", "wrist_pitch", "wrist_yaw")]
+    return names
+
+
+def write_g1_urdf(weld_right_elbow=True):
+    """The placeholder G1 + paddle of scene.py as URDF text.  weld_right_elbow: the 27-dof asset (right shoulder-yaw and elbow
+    fixed); False gives the 29-dof-style right arm the 7-dof tasks use."""
+    def fmt(v):
+        return " ".join(repr(float(x)) for x in v)
+    out = ['<?xml version="1.0"?>', '<robot name="g1_placeholder">']
+
+    def link(name, mass=0.0, com=(0, 0, 0), inertia=(0, 0, 0)):
+        if mass <= 0.0:
+            out.append(f'  <link name="{name}"/>')
+            return
+        i6 = tuple(float(x) for x in (tuple(inertia) + (0.0, 0.0, 0.0) if len(inertia) == 3 else tuple(inertia)))
+        out.append(f'  <link name="{name}"><inertial><origin xyz="{fmt(com)}" rpy="0 0 0"/><mass value="{float(mass)!r}"/>'
+                   f'<inertia ixx="{i6[0]!r}" iyy="{i6[1]!r}" izz="{i6[2]!r}" ixy="{i6[3]!r}" ixz="{i6[4]!r}" iyz="{i6[5]!r}"/></inertial></link>')
+
+    def joint(child, parent, xyz, rpy=(0, 0, 0), axis=None, limits=None, effort=0.0, vel=0.0, name=None):
+        name = name or _joint_name(child)
+        if axis is None:
+            out.append(f'  <joint name="{name}" type="fixed"><origin xyz="{fmt(xyz)}" rpy="{fmt(rpy)}"/><parent link="{parent}"/><child link="{child}"/></joint>')
+        else:
+            ax = ["1 0 0", "0 1 0", "0 0 1"][axis]
+            out.append(f'  <joint name="{name}" type="revolute"><origin xyz="{fmt(xyz)}" rpy="{fmt(rpy)}"/><parent link="{parent}"/><child link="{child}"/>'
+                       f'<axis xyz="{ax}"/><limit lower="{float(limits[0])!r}" upper="{float(limits[1])!r}" effort="{float(effort)!r}" velocity="{float(vel)!r}"/></joint>')
+
+    def chain(specs, parent, welded=()):
+        for k, s in enumerate(specs):
+            link(s["name"], s["mass"], s["com"], s["inertia"])
+            if k in welded:
+                joint(s["name"], parent, s["xyz"], s["rpy"])
+            else:
+                joint(s["name"], parent, s["xyz"], s["rpy"], s["axis"], s["limits"], s["effort"], s["vel"])
+            parent = s["name"]
+        return parent
+
+    P = scene.G1_PELVIS
+    link("pelvis", P["mass"], P["com"], P["inertia"])
+    for w in scene.G1_PELVIS_WELDED:
+        link(w["name"], w["mass"], w.get("com", (0, 0, 0)), w.get("inertia", (0, 0, 0)))
+        joint(w["name"], "pelvis", w["xyz"])
+    chain(scene._leg("left"), "pelvis")
+    chain(scene._leg("right"), "pelvis")
+    waist = [dict(s) for s in scene.G1_WAIST]
+    for s in waist[:2]:
+        link(s["name"], s["mass"], s["com"], s["inertia"])
+    joint("waist_yaw_link", "pelvis", waist[0]["xyz"], waist[0]["rpy"], waist[0]["axis"], waist[0]["limits"], waist[0]["effort"], waist[0]["vel"])
+    joint("waist_roll_link", "waist_yaw_link", waist[1]["xyz"], waist[1]["rpy"], waist[1]["axis"], waist[1]["limits"], waist[1]["effort"], waist[1]["vel"])
+    t = waist[2]
+    link("torso_link", t["mass"], t["com"], t["inertia"])
+    joint("torso_link", "waist_roll_link", t["xyz"], t["rpy"], t["axis"], t["limits"], t["effort"], t["vel"], name="torso_joint")
+    for w in scene.G1_TORSO_WELDED:
+        link(w["name"], w["mass"], w.get("com", (0, 0, 0)), w.get("inertia", (0, 0, 0)))
+        joint(w["name"], "torso_link", w["xyz"])
+    left = [scene._mirror_arm(s) for s in scene.G1_RIGHT_ARM]
+    tip = chain(left, "torso_link")
+    H = scene.G1_HAND
+    link("left_rubber_hand", H["mass"], (H["com"][0], -H["com"][1], H["com"][2]), H["inertia"])
+    joint("left_rubber_hand", tip, (H["xyz"][0], -H["xyz"][1], H["xyz"][2]))
+    tip = chain(scene.G1_RIGHT_ARM, "torso_link", welded=(2, 3) if weld_right_elbow else ())
+    link("right_rubber_hand", H["mass"], H["com"], H["inertia"])
+    joint("right_rubber_hand", tip, H["xyz"])
+    pd = scene.PADDLE
+    m, r, n = pd["mass"], pd["radius"], np.asarray(pd["normal"], dtype=np.float64)
+    i_disc = 0.25 * m * r * r * np.eye(3) + 0.25 * m * r * r * np.outer(n, n)
+    link("pingpong_paddle", m, (0, 0, 0), tuple(np.diag(i_disc)) + (i_disc[0, 1], i_disc[0, 2], i_disc[1, 2]))
+    joint("pingpong_paddle", "right_rubber_hand", pd["xyz_from_hand"])
+    out.append("</robot>")
+    return "\n".join(out) + "\n"
+
+
+if __name__ == "__main__":
+    import sys
+    sys.stdout.write(write_g1_urdf(weld_right_elbow="--29dof" not in sys.argv))
