@@ -214,15 +214,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
 struct NullVisitor {
     __device__ __forceinline__ void operator()(int, const M3&, V3, V3, V3) {}
 };
-// position of the last observed body (the paddle) only: a sweep with this visitor is the bare pose chain
-template <class T>
-struct PaddlePosVisitor {
-    V3 pos;
-    __device__ __forceinline__ void operator()(int i, const M3& Rw, V3 pw, V3, V3) {
-        if (i == ND - 1) pos = pw + mul(Rw, ld3(T::tip_frame(NB - 1).origin_xyz));
-    }
-};
-
 // obs tile -> obs_buf for the columns [C0, C1) (both multiples of 4) of `nrows` tile rows starting at tile row
 // `t0`, as float4.  Tile row t0 + r goes to obs_buf row `g0 + r * gstep` (the tile is [agent][lane], obs_buf rows
 // are A * env + agent).
@@ -379,21 +370,19 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         }
         // FK of the final state: paddle position for the reward, then the body block of the observation row,
         // obs[0:60] (TT:1696-1697) — it depends on the pre-reset body states only (TT:1039)
-        // The ball wave's task tail waits for the paddle position only: a bare pose-chain sweep publishes it first
-        // (~1k cycles earlier than the full sweep would), then the full sweep produces the ten observed bodies.
-        if (active) {
-            PaddlePosVisitor<T> pv;
-            fk_sweep<T>(S, q, qd, js, pv);
-            s_paddle[arm * 3 + 0][lane] = pv.pos.x; s_paddle[arm * 3 + 1][lane] = pv.pos.y; s_paddle[arm * 3 + 2][lane] = pv.pos.z;
-        }
-        publish(&s_flag[arm], substeps + 1);
+        // (a bare pose-chain sweep publishing the paddle position ~1k cycles before the full sweep was tried: no effect on the
+        // step time once the ball wave's substeps ended later than the full sweep, so there is one sweep)
+        BodyState bodies[NB];
         PP_STAMP_AT(5);
         if (active) {
-            BodyState bodies[NB];
             ArmGeom<T::kShapes> g;
             BodyVisitor<T, false> bv(g, bodies);
             fk_sweep<T>(S, q, qd, js, bv);
             static_body<false>(S, bodies[0]);
+            s_paddle[arm * 3 + 0][lane] = bodies[NB - 1].pos.x; s_paddle[arm * 3 + 1][lane] = bodies[NB - 1].pos.y; s_paddle[arm * 3 + 2][lane] = bodies[NB - 1].pos.z;
+        }
+        publish(&s_flag[arm], substeps + 1);
+        if (active) {
             V3 bpos[NB], bvel[NB];
 #pragma unroll
             for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
