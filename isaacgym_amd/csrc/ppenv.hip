@@ -309,6 +309,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     __shared__ float s_tau[A * ND][kBlock];            // drive torques of the last substep (dof_force)
     __shared__ float s_paddle[A * 3][kBlock];          // paddle position of the final state (the reward reads it)
     __shared__ int s_reset[kBlock];                    // the ball wave's reset decision, for the arm waves' dof stores
+    __shared__ float s_serve[3][kBlock];               // arm wave 0 -> ball: the serve of a possible reset (published with the paddle position)
     __shared__ int s_flag[A];                          // arm -> ball: boundaries published so far; substeps + 1 = paddle position too
     __shared__ int s_flag_ball;                        // ball -> arm: 1 once the reset decision is in s_reset
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -374,6 +375,14 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         // step time once the ball wave's substeps ended later than the full sweep, so there is one sweep)
         BodyState bodies[NB];
         PP_STAMP_AT(5);
+        if (arm == 0 && active) {
+            // The serve this env gets if it resets at the end of the step: the counter RNG is a pure function of (seed, env id,
+            // episode + 1).  The ball wave is the longer one, so the draw sits here, between this wave's last substep and its
+            // final sweep, and travels with the paddle position.
+            V3 sv = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
+                             : serve_velocity(K, (uint32_t)(K.env_id_offset + i), b.episode[i] + 1u);
+            s_serve[0][lane] = sv.x; s_serve[1][lane] = sv.y; s_serve[2][lane] = sv.z;
+        }
         if (active) {
             ArmGeom<T::kShapes> g;
             BodyVisitor<T, false> bv(g, bodies);
@@ -438,10 +447,6 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         pre_vx = st.ball.v.x;   // TT:1020
 #pragma unroll
         for (int a = 0; a < A; a++) { static_geometry<T>(K.site[a], g[a]); bound[a] = ld3(K.site[a].bound_center); }
-        // the serve this env gets if it resets at the end of the step: the counter RNG is a pure function of
-        // (seed, env id, episode + 1), so it can be drawn now, off the tail of the step
-        next_serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
-                              : serve_velocity(K, (uint32_t)(K.env_id_offset + i), st.episode + 1u);
     }
     PP_STAMP_AT(17);
     for (int s = 0; s < substeps; s++) {
@@ -492,6 +497,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
             bodies[a * NB + NB - 1].pos = mk(s_paddle[a * 3 + 0][lane], s_paddle[a * 3 + 1][lane], s_paddle[a * 3 + 2][lane]);
             stores[a].row = &s_obs[(a * kBlock + lane) * kObsStride];
         }
+        next_serve = mk(s_serve[0][lane], s_serve[1][lane], s_serve[2][lane]);   // drawn by arm wave 0
         post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, &next_serve, rew, reset, stores);
         s_reset[lane] = (int)reset;
     }
