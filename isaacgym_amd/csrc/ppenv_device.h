@@ -483,22 +483,18 @@ PP_HD void aba_solve(const ArmSite& S, JointSave* js, const float* qd, const flo
 }
 
 // PD drive (DOF_MODE_POS, TT:414,463) + one semi-implicit Euler substep of the arm.
-// Unsaturated joints are integrated implicitly in the PD terms (adds h Kd + h^2 Kp on
-// the joint-space inertia diagonal); a joint whose explicit PD torque exceeds the
-// effort limit gets the constant limit torque instead.
+// The PD terms are integrated implicitly (h Kd + h^2 Kp on the joint-space inertia diagonal) and the explicit part of the
+// torque is clamped to the effort limit: continuous at saturation, so a joint within rounding of the limit does not
+// change the step (an earlier draft switched to a constant torque without the implicit terms there).
 template <class T>
 PP_HD void arm_substep(const ArmSite& S, JointSave* js, float* q, float* qd, const float* target, float h, float* tau_drive) {
     float tau[ND], arm[ND], qdd[ND];
-    bool sat[ND];
 #pragma unroll
     for (int d = 0; d < ND; d++) {
         const JointDrive J = T::drive(d);
         float err = target[d] - q[d];
-        float t_exp = J.kp * err - J.kd * qd[d];
-        sat[d] = fabsf(t_exp) > J.effort;
-        float t_imp = J.kp * (err - h * qd[d]) - J.kd * qd[d];
-        tau[d] = sat[d] ? copysignf(J.effort, t_exp) : t_imp;
-        arm[d] = sat[d] ? J.armature : J.armature + h * J.kd + h * h * J.kp;
+        tau[d] = fminf(fmaxf(J.kp * (err - h * qd[d]) - J.kd * qd[d], -J.effort), J.effort);
+        arm[d] = J.armature + h * J.kd + h * h * J.kp;
     }
     aba_solve<T>(S, js, qd, tau, arm, qdd);
 #pragma unroll
@@ -506,9 +502,8 @@ PP_HD void arm_substep(const ArmSite& S, JointSave* js, float* q, float* qd, con
         const JointDrive J = T::drive(d);
         float err = target[d] - q[d];
         float vn = qd[d] + h * qdd[d];
-        // dof_force reports the drive torque within the actuator's limit: the implicit branch's end-of-substep value
-        // Kp(e - h qd+) - Kd qd+ can overshoot it when inertial coupling swings qd+ far from qd
-        tau_drive[d] = sat[d] ? tau[d] : fminf(fmaxf(J.kp * (err - h * vn) - J.kd * vn, -J.effort), J.effort);
+        // dof_force reports the drive torque at the end-of-substep velocity, within the actuator's limit
+        tau_drive[d] = fminf(fmaxf(J.kp * (err - h * vn) - J.kd * vn, -J.effort), J.effort);
         vn = fminf(fmaxf(vn, -J.vel_limit), J.vel_limit);
         float qn = q[d] + h * vn;
         if (qn > J.upper) { qn = J.upper; vn = fminf(vn, 0.f); }
@@ -600,12 +595,14 @@ PP_HD void contact_disc(const BallConsts& k, Ball& b, V3 cc, V3 nn, V3 uc, V3 nd
         s = -(tp - fabsf(hgt)) - k.r;
         closest = cc + nn * (sg * tp) + radial;
     } else {
-        float hc = clampf(hgt, -tp, tp);
-        float rc = fminf(rr, R);
-        V3 rdir = rr > 1e-12f ? radial * (rc * rcp_fast(rr)) : mk(0, 0, 0);
-        closest = cc + nn * hc + rdir;
-        V3 diff = b.p - closest;
-        float d2 = dot(diff, diff);
+        // ball centre minus closest point, split into its axial and radial parts: formed as `b.p - closest` the
+        // radial part of a centre over the face (rr < R) is rounding noise instead of exactly zero, and a ball pressed
+        // 2 cm into the blade (centre 0.1 mm above the face) then gets a normal that is off by 1e-3
+        float dh = hgt - clampf(hgt, -tp, tp);
+        float er = fmaxf(rr - R, 0.f);
+        V3 diff = nn * dh + (er > 0.f ? radial * (er * rcp_fast(rr)) : mk(0, 0, 0));
+        closest = b.p - diff;
+        float d2 = dh * dh + er * er;
         float inv = d2 > 1e-24f ? rsq_fast(d2) : 0.f;
         n = d2 > 1e-24f ? diff * inv : nn;
         s = d2 * inv - k.r;

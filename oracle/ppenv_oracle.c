@@ -734,21 +734,18 @@ static void step_env(ppo_env* e, int i, const float* actions) {
     arm_forward_kinematics(c, q, qd, &k0);
     for (int s = 0; s < c->substeps; s++) {
         double tau[ND], arm_eff[ND], qdd[ND];
-        int sat[ND];
-        for (int d = 0; d < ND; d++) {
+        for (int d = 0; d < ND; d++) {   /* implicit PD, explicit part clamped to the effort limit (continuous at saturation) */
             const ppenv_joint* j = &c->joint[d];
             double err = target[d] - q[d];
-            double t_exp = j->kp * err - j->kd * qd[d];
-            sat[d] = fabs(t_exp) > j->effort;
-            if (sat[d]) { tau[d] = t_exp > 0 ? j->effort : -j->effort; arm_eff[d] = j->armature; }
-            else { tau[d] = j->kp * (err - h * qd[d]) - j->kd * qd[d]; arm_eff[d] = j->armature + h * j->kd + h * h * j->kp; }
+            tau[d] = clampd(j->kp * (err - h * qd[d]) - j->kd * qd[d], -j->effort, j->effort);
+            arm_eff[d] = j->armature + h * j->kd + h * h * j->kp;
         }
         arm_forward_dynamics(c, &k0, qd, tau, arm_eff, qdd);
         for (int d = 0; d < ND; d++) {
             const ppenv_joint* j = &c->joint[d];
             double err = target[d] - q[d];
             double v_new = qd[d] + h * qdd[d];
-            tau_drive[d] = sat[d] ? tau[d] : clampd(j->kp * (err - h * v_new) - j->kd * v_new, -j->effort, j->effort);   /* reported within the limit */
+            tau_drive[d] = clampd(j->kp * (err - h * v_new) - j->kd * v_new, -j->effort, j->effort);   /* reported within the limit */
             v_new = clampd(v_new, -j->vel_limit, j->vel_limit);
             double q_new = q[d] + h * v_new;
             if (q_new > j->upper) { q_new = j->upper; if (v_new > 0) v_new = 0; }
@@ -1246,22 +1243,19 @@ static void step_env_t4(ppo_env* e, int i, const float* actions) {
         arm_geom g[2];
         for (int a = 0; a < 2; a++) {
             double tau[ND], arm_eff[ND], qdd[ND];
-            int sat[ND];
             arm_geometry_s(c, a == 0 ? c->shape : c->shape2, &k0[a], &g[a]);   /* pose and velocities at the start of the substep */
             for (int d = 0; d < ND; d++) {
                 const ppenv_joint* j = &c->joint[d];
                 double err = target[a][d] - q[a][d];
-                double t_exp = j->kp * err - j->kd * qd[a][d];
-                sat[d] = fabs(t_exp) > j->effort;
-                if (sat[d]) { tau[d] = t_exp > 0 ? j->effort : -j->effort; arm_eff[d] = j->armature; }
-                else { tau[d] = j->kp * (err - h * qd[a][d]) - j->kd * qd[a][d]; arm_eff[d] = j->armature + h * j->kd + h * h * j->kp; }
+                tau[d] = clampd(j->kp * (err - h * qd[a][d]) - j->kd * qd[a][d], -j->effort, j->effort);
+                arm_eff[d] = j->armature + h * j->kd + h * h * j->kp;
             }
             arm_forward_dynamics_b(c, base_of(c, a), &k0[a], qd[a], tau, arm_eff, qdd);
             for (int d = 0; d < ND; d++) {
                 const ppenv_joint* j = &c->joint[d];
                 double err = target[a][d] - q[a][d];
                 double v_new = qd[a][d] + h * qdd[d];
-                tau_drive[a][d] = sat[d] ? tau[d] : clampd(j->kp * (err - h * v_new) - j->kd * v_new, -j->effort, j->effort);
+                tau_drive[a][d] = clampd(j->kp * (err - h * v_new) - j->kd * v_new, -j->effort, j->effort);
                 v_new = clampd(v_new, -j->vel_limit, j->vel_limit);
                 double q_new = q[a][d] + h * v_new;
                 if (q_new > j->upper) { q_new = j->upper; if (v_new > 0) v_new = 0; }

@@ -54,7 +54,7 @@ SCALES = {
     "dof_vel": 37.0,      # rad/s, velocity limit
     "dof_force": 25.0,    # N m, effort limit
     "ball_pos": 3.0,      # m
-    "ball_quat": 1.0,
+    "ball_quat": 4.0,     # the step rotates the ball by |w| dt <= 500 rad/s / 60 Hz = 8 rad: q moves by half of that, and an rtol error in w shows in q at that scale
     "ball_vel": 10.0,     # m/s
     "ball_spin": 500.0,   # rad/s: surface speed / radius = 10 m/s / 0.02 m, i.e. the same bound as ball_vel
 }
@@ -93,16 +93,16 @@ def reward_atol(config):
 class SensitivityProbe:
     """Finds the envs whose step sits on a discontinuity of the physics specification.
 
-    The specification has hard switches (drive saturation `|tau_exp| > effort`, contact activation `s < contact_offset`,
-    the bounce threshold): when an env lands within fp32 rounding of one, the fp64 oracle and the fp32 kernel may take
-    different branches and legitimately differ by far more than rtol 1e-4 (seen on the GPU: one env in ~2e6 joint-steps,
-    reproduced identically by all three kernel schedules).  The probe steps a second oracle from the same state with the
+    The specification has hard switches (contact activation `s < contact_offset`, the bounce threshold, the limit
+    clamps): when an env lands within fp32 rounding of one, the fp64 oracle and the fp32 kernel may take different
+    branches and legitimately differ by far more than rtol 1e-4 (reproduced identically by all kernel schedules).  The probe steps a second oracle from the same state with the
     continuous inputs jittered by a few 1e-6 relative; an env whose *oracle* result moves by more than the parity tolerance
     under that jitter is excluded from the continuous comparison of that step (integer outputs are still compared for all
     envs that the jitter leaves unchanged)."""
 
     def __init__(self, oracle_lib, config, rel=4e-6, seed=99):
         self.o2 = oracle_lib.OracleEnv(config, threads=8)
+        self.rew_atol = reward_atol(config)
         self.rel = rel
         self.rng = np.random.default_rng(seed)
 
@@ -125,6 +125,9 @@ class SensitivityProbe:
                 a, b = o2.ball[rows], o_after.ball[rows]
                 bad |= (np.abs(a - b) > 0.3 * (RTOL * SCALES[name] + RTOL * np.abs(b))).any(axis=0)
             A = o2.num_agents
+            # the reward reads the pre-reset ball velocity, which the state of an env that reset this step no longer shows
+            drew = np.abs(o2.rew_buf - o_after.rew_buf) > 0.3 * (self.rew_atol + RTOL * np.abs(o_after.rew_buf))
+            bad |= drew.reshape(n, A).any(axis=1)
             bad |= (o2.reset_buf.reshape(n, A) != o_after.reset_buf.reshape(n, A)).any(axis=1)
             bad |= (o2.flags.reshape(A, n) != o_after.flags.reshape(A, n)).any(axis=0)
         return bad

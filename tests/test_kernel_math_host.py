@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import shim_binding as sb
-from helpers import RTOL, assert_close, assert_state_close, obs_atol, reward_atol
+from helpers import RTOL, SensitivityProbe, assert_close, assert_state_close, mask_envs, obs_atol, reward_atol
 from isaacgym_amd import scene
 
 
@@ -40,22 +40,28 @@ def test_single_step_parity_vs_oracle(oracle_lib, variant):
     s = sb.ShimEnv(cfg)
     rng = np.random.default_rng(1)
     oa, ra = obs_atol(), reward_atol(cfg)
-    resets = 0
+    resets = skipped = 0
     steps = 180 if variant == "TN" else 120   # TN only ever resets on its 170-step time-out (TN:1317)
+    probe = SensitivityProbe(oracle_lib, cfg)
     for t in range(steps):
         actions = rng.uniform(-1.2, 1.2, (n, 7)).astype(np.float32)   # beyond +-1: exercises clipActions
         s.copy_state_from(o)
+        st = o.get_state()
         o.step(actions)
         s.step(actions)
-        np.testing.assert_array_equal(s.reset_buf, o.reset_buf, err_msg=f"reset step {t}")
-        np.testing.assert_array_equal(s.progress_buf, o.progress_buf, err_msg=f"progress step {t}")
-        np.testing.assert_array_equal(s.flags, o.flags, err_msg=f"flags step {t}")
-        np.testing.assert_array_equal(s.episode, o.episode, err_msg=f"episode step {t}")
-        assert_state_close(s, o, f"step {t}")
-        assert_close(s.obs_buf, o.obs_buf, f"obs step {t}", atol=oa)
-        assert_close(s.rew_buf, o.rew_buf, f"rew step {t}", atol=ra)
+        keep = ~probe.sensitive(st, actions, o)   # envs within rounding of a contact switch this step (helpers.SensitivityProbe)
+        skipped += int((~keep).sum())
+        sm, om = mask_envs(s, keep), mask_envs(o, keep)
+        np.testing.assert_array_equal(sm.reset_buf, om.reset_buf, err_msg=f"reset step {t}")
+        np.testing.assert_array_equal(sm.progress_buf, om.progress_buf, err_msg=f"progress step {t}")
+        np.testing.assert_array_equal(sm.flags, om.flags, err_msg=f"flags step {t}")
+        np.testing.assert_array_equal(sm.episode, om.episode, err_msg=f"episode step {t}")
+        assert_state_close(sm, om, f"step {t}")
+        assert_close(sm.obs_buf, om.obs_buf, f"obs step {t}", atol=oa)
+        assert_close(sm.rew_buf, om.rew_buf, f"rew step {t}", atol=ra)
         resets += int(o.reset_buf.sum())
     assert resets > 100
+    assert skipped <= 0.01 * n * steps, skipped
 
 
 def test_gentle_policy_single_step_is_tight(oracle_lib):
@@ -75,7 +81,9 @@ def test_gentle_policy_single_step_is_tight(oracle_lib):
         assert_close(s.dof_pos, o.dof_pos, "dof_pos", atol=1e-5)
         assert_close(s.dof_vel, o.dof_vel, "dof_vel", atol=1e-4)
         assert_close(s.ball[0:3], o.ball[0:3], "ball pos", atol=1e-5)
-        assert_close(s.ball[7:10], o.ball[7:10], "ball vel", atol=5e-4)   # a ball leaving the arm: impulse = difference of large velocities
+        # a ball on the table's edge: the normal is (centre - edge) / 0.02 m, so the 1.2e-7 m quantum of an fp32 x ~ 1.4 m
+        # turns into 1e-5 of normal and, at 8 m/s, 2e-4 m/s of rebound velocity
+        assert_close(s.ball[7:10], o.ball[7:10], "ball vel", atol=5e-4)
         oa = np.full(80, 1e-4)
         oa[77:80] = 5e-4   # ball velocity columns (TT:1660), as above
         assert_close(s.obs_buf, o.obs_buf, "obs", atol=oa)
