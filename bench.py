@@ -21,7 +21,7 @@ The steps of one PPO horizon (32 launches of the step kernel on the pool's actio
 captured once into a HIP graph and replayed: the launches are the same kernels on the same
 stream in the same order, the graph only removes the per-launch submission from the loop
 (rocprofv3's kernel trace shows the per-kernel duration drop from 12.6 to 11.8 us).  K steps =
-K // 32 replays + K % 32 eager launches; --no-graph launches every step eagerly.
+K // 32 replays + one replay of a (K % 32)-step graph; --no-graph launches every step eagerly.
 """
 import argparse
 import json
@@ -189,16 +189,21 @@ def main():
 
     # The graph is captured BEFORE the process group exists: a capture fails if another thread of the process (the RCCL
     # watchdog) touches the runtime while it is open.
-    graph = None
+    graphs = {}
     if not args.no_graph:
         for s in range(HORIZON):           # lazy initialisation (streams, workspaces) must not happen inside the capture
             env.step(pool[s & 7])
         torch.cuda.synchronize(device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            for s in range(HORIZON):       # HORIZON is a multiple of the pool size: the replayed sequence is the eager one
-                env.step(pool[s & 7])
+        # one graph per launch-sequence length in use: the horizon, and what --warmup / --steps leave over after whole horizons
+        # (a driver that asks for fewer steps than a horizon still gets device-paced launches)
+        for length in sorted({HORIZON, args.warmup % HORIZON, args.steps % HORIZON} - {0}):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for s in range(length):    # HORIZON is a multiple of the pool size: every replayed sequence is the eager one
+                    env.step(pool[s & 7])
+            graphs[length] = g
         torch.cuda.synchronize(device)
+    graph = graphs.get(HORIZON)
 
     if world > 1:
         if args.dist_backend == "nccl":
@@ -219,6 +224,9 @@ def main():
                 graph.replay()
                 horizon_stats()
             done = (k // HORIZON) * HORIZON
+            if k - done in graphs:
+                graphs[k - done].replay()
+                done = k
         for s in range(done, k):
             env.step(pool[s & 7])
             if (s + 1) % HORIZON == 0:
