@@ -475,6 +475,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
                     fk_sweep<T>(K.site[a], &qs[a * ND], &qds[a * ND], js, gv);
                 }
             }
+            PP_STAMP_AT(25);
             ball_substep<T, A>(K, st.ball, g, bound);
         }
         if (G) publish(&s_bflag, s + 1);

@@ -653,8 +653,10 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> 
             float rr = sqrtf(dot(hl, hl)) + T::shape(s).radius + reach;
             sr2[arm][s] = rr * rr;
         }
+    PP_STAMP_AT(26);
     for (int m = 0; m < M; m++) {
         const float t = (float)m * hb;   // time since the start of the substep
+        PP_STAMP_AT(27 + (m & 3));
         b.v.z += gdv;
         b.w = b.w * damp;
         contact_resolve(k, b, mk(0, 0, 1), b.p.z - ground_z - k.r, mk(0, 0, 0), ground_e, ground_mu);
@@ -695,6 +697,7 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> 
         }
         b.p = madd(b.p, b.v, hb);
     }
+    PP_STAMP_AT(31);
     // orientation: q <- normalize(q + h/2 (w,0) (x) q), xyzw
     float wx = b.w.x, wy = b.w.y, wz = b.w.z, x = b.quat[0], y = b.quat[1], z = b.quat[2], w = b.quat[3];
     float kq = 0.5f * h;

@@ -2,6 +2,7 @@
 // tasks/humanoid_pingpong_3_actor_all_dof.py ("TA") TA:1145-1192 on caller-supplied simulator tensors.
 // One lane per env; every op is fp32 in the reference's operation order (IEEE division / sqrt / expf).
 // The per-env arithmetic is ppenv_ta_task.h (shared with the fused step of ppenv_ta_sim.hip).
+#undef PP_STAMP   // the phase stamps of diagnostic builds belong to ppenv.hip's kernels
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

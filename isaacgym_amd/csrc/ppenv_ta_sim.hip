@@ -6,6 +6,7 @@
 // uniform across the wave, so the model tables in global memory are read with scalar loads.  The simulation state is the
 // caller's Isaac-Gym-layout tensors (AoS, ~0.7 KB per env in and 2.9 KB out): the step is bound by its ~1e5 dependent fp32
 // operations per env, not by these bytes.
+#undef PP_STAMP   // the phase stamps of diagnostic builds belong to ppenv.hip's kernels
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

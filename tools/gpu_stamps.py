@@ -10,10 +10,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "gpurun_out", "libppenv_stamp.so")
+SRC = os.environ.get("PPENV_STAMP_SRC", os.path.join(ROOT, "isaacgym_amd", "csrc"))   # another source tree to stamp (A/B of two builds)
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only",
-                "-fPIC", "-shared", "-DPP_STAMP=1", "-o", lib, os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv.hip"), os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv_ta.hip"),
-                os.path.join(ROOT, "isaacgym_amd", "csrc", "ppenv_ta_sim.hip")], check=True)
+                "-fPIC", "-shared", "-DPP_STAMP=1", "-I", os.path.join(ROOT, "include"), "-o", lib, os.path.join(SRC, "ppenv.hip"), os.path.join(SRC, "ppenv_ta.hip"),
+                os.path.join(SRC, "ppenv_ta_sim.hip")], check=True)
 os.environ["PPENV_LIB"] = lib
 import torch  # noqa: E402
 from isaacgym_amd import _lib, scene  # noqa: E402
@@ -49,6 +50,19 @@ else:
             21: "ball: FK + substep 2", 22: "ball: wait final + reward/reset/obs tail", 23: "ball: final barrier wait", 24: "ball: flush + stores"}
     tot = np.median(t[:, 24] - t0)
     print(f"N={n}: median workgroup span (first stamp -> last stamp): {tot:.0f} shader cycles")
+    span = t[:, 24] - t0
+    print("  span percentiles 0/10/50/90/99/100: " + " ".join(f"{np.percentile(span, q):.0f}" for q in (0, 10, 50, 90, 99, 100)))
+    print(f"  first workgroup start -> last workgroup end: {t[:, 24].max() - t0.min():.0f} cycles; start spread {t0.max() - t0.min():.0f}")
+    for a, b, nm in ((2, 1, "arm substep 1"), (4, 2, "arm substep 2"), (19, 18, "ball FK + substep 1"), (21, 20, "ball FK + substep 2"), (22, 21, "ball tail")):
+        d = t[:, a] - t[:, b]
+        print(f"  {nm:22s} percentiles 0/50/90/100: " + " ".join(f"{np.percentile(d, q):.0f}" for q in (0, 50, 90, 100)))
+    # inside the LAST ball substep (slots 25..31: FK done, contact tables built, micro-steps 0..3 start, loop end)
+    order = np.argsort(t[:, 21] - t[:, 20])
+    groups = (("median 10 %", order[int(0.45 * nb):int(0.55 * nb)]), ("slowest 2 %", order[-max(1, nb // 50):]))
+    inner = ((25, 20, "wait + FK sweep"), (26, 25, "per-substep shape tables"), (28, 27, "micro-step 0"), (29, 28, "micro-step 1"), (30, 29, "micro-step 2"),
+             (31, 30, "micro-step 3"), (21, 31, "quaternion + publish"))
+    for gname, idx in groups:
+        print(f"  last ball substep, {gname}: " + ", ".join(f"{nm} {np.median(t[idx, a] - t[idx, b]):.0f}" for a, b, nm in inner))
     for k, name in arm.items():
         prev = t[:, k - 1] if k != 4 else t[:, 2]
         print(f"  {name:34s} {np.median(t[:, k] - prev):8.0f} cycles   (ends at {np.median(t[:, k] - t0):6.0f})")
