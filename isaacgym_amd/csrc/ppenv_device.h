@@ -659,9 +659,14 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> 
         PP_STAMP_AT(27 + (m & 3));
         b.v.z += gdv;
         b.w = b.w * damp;
-        contact_resolve(k, b, mk(0, 0, 1), b.p.z - ground_z - k.r, mk(0, 0, 0), ground_e, ground_mu);
-        contact_box(k, b, table);
-        contact_box(k, b, net);
+#ifndef PP_BALL_SKIP
+#define PP_BALL_SKIP 0      // profiling builds only (tools/gpu_stamps.py): bit 0 paddle, 1 link shapes, 2 table + net, 3 ground
+#endif
+        if (!(PP_BALL_SKIP & 8)) contact_resolve(k, b, mk(0, 0, 1), b.p.z - ground_z - k.r, mk(0, 0, 0), ground_e, ground_mu);
+        if (!(PP_BALL_SKIP & 4)) {
+            contact_box(k, b, table);
+            contact_box(k, b, net);
+        }
 #pragma unroll
         for (int arm = 0; arm < A; arm++) {
             const ArmGeom<T::kShapes>& ga = g[arm];
@@ -677,7 +682,7 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> 
                 // wave then pays ~10 instructions per shape instead of the full closest-point code.
                 V3 cc = madd(ga.pc, ga.vpc, t);
                 V3 dpc = b.p - cc;
-                if (dot(dpc, dpc) < pad_r2) {
+                if (!(PP_BALL_SKIP & 1) && dot(dpc, dpc) < pad_r2) {
                     V3 nn = madd(ga.pn, ga.pnd, t);
                     nn = nn * rsq_fast(dot(nn, nn));
                     contact_disc(k, b, cc, nn, ga.vpc, ga.pnd, P.radius, P.half_thickness, pad_e, pad_mu);
@@ -685,7 +690,7 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> 
 #pragma unroll
                 for (int s = 0; s < T::kShapes; s++) {
                     V3 dsc = b.p - madd(sc0[arm][s], svc[arm][s], t);
-                    if (dot(dsc, dsc) < sr2[arm][s]) {
+                    if (!(PP_BALL_SKIP & 2) && dot(dsc, dsc) < sr2[arm][s]) {
                         const float radius = T::shape(s).radius, e = K.shape_e[s], mu = K.shape_mu[s];
                         if (T::shape_link(s) < 0)
                             contact_capsule(k, b, ga.a[s], ga.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
