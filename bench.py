@@ -157,7 +157,14 @@ def main():
     from isaacgym_amd import distributed as D
     from isaacgym_amd.env import PPEnv
 
-    _lib.lib()   # fail loudly when the HIP extension is missing
+    if not os.path.exists(_lib.LIB_PATH):      # a checkout without the built library (it is git-ignored): local rank 0 compiles it, the others wait
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            _lib.build()
+        else:
+            t_end = time.time() + 900
+            while not os.path.exists(_lib.LIB_PATH) and time.time() < t_end:
+                time.sleep(1.0)
+    _lib.lib()   # fail loudly when the HIP extension is missing (there is no CPU path)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -38,10 +38,14 @@ def build(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + SOURCES
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"          # built aside and renamed: another process never sees half a library
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + SOURCES
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise PPEnvError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stderr[-4000:])
+    os.replace(tmp, LIB_PATH)
     if verbose:
         print(" ".join(cmd))
     return LIB_PATH
