@@ -327,7 +327,9 @@ typedef struct ppenv_ta_params {
  *   reset_override [N,5] = ball y, z, vx, vy, vz to use at resets instead of the RNG, or NULL;
  *   flags, episode [N] u32 and progress [N] i64 are read-modify-write; obs [N,313], rew [N], reset [N] i64 out.
  * As in the reference, the diagnostic count flags of ALL envs are cleared whenever any env resets
- * (TA:1162-1166); this is the only cross-env effect and is done by a second small launch. */
+ * (TA:1162-1166); this is the only cross-env effect and is done by a second small launch.
+ * scratch_any_reset: one word the caller zeroes ONCE, before the first call; every call leaves it zero again (the
+ * clearing launch resets it, which saves a memset per step). */
 int ppenv_ta_post_physics_step(const ppenv_ta_params* params, const float* rb_states_dev, const float* initial_rb_states_dev,
                                float* root_states_dev, float* dof_states_dev, const float* dof_force_dev,
                                const float* pre_ball_vx_dev, const float* reset_override_dev, uint32_t* flags_dev,

@@ -501,7 +501,6 @@ int ppenv_ta_step(ppenv_ta_sim* s, const ppenv_ta_params* params, const float* a
                                           reset_override_dev, flags_dev, episode_dev, progress_dev, obs_dev, rew_dev, reset_dev, scratch_any_reset_dev, stream);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(scratch_any_reset_dev, 0, sizeof(uint32_t), st) != hipSuccess) { ppenv_set_error("hipMemsetAsync failed"); return PPENV_EHIP; }
     TaskArgs t{*params, initial_rb_states_dev, reset_override_dev, flags_dev, episode_dev, (long long*)progress_dev, obs_dev, rew_dev, (long long*)reset_dev,
                scratch_any_reset_dev};
     hipLaunchKernelGGL((ta_sim_quad_kernel<true, true>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, st, s->dev, s->host.sc, s->K, n, actions_dev,
