@@ -41,7 +41,7 @@ void run(const char* name, int blocks) {
 }
 
 int main() {
-    for (int blocks : {1, 256}) {
+    for (int blocks : {1, 256, 512, 1024}) {   // 1, 2, 4 waves per CU on a 256-CU part (each wave on a SIMD of its own up to 1024)
         run<0>("straight-line 4096 x v_fmac_f32_e32 (4 B each, 16 KB)", blocks);
         run<1>("straight-line 4096 x v_fma_f32 (8 B each, 32 KB)", blocks);
         run<2>("straight-line 4096 x v_fmaak_f32 literal (8 B each)", blocks);
