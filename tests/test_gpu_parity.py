@@ -96,7 +96,7 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant)
     env.close()
 
 
-@pytest.mark.parametrize("schedule,n", [("split", 1000), ("fused", 1000), ("fused", 130), ("split", 63)])
+@pytest.mark.parametrize("schedule,n", [("split", 1000), ("fused", 1000), ("fused", 130), ("split", 63), ("split", 1), ("fused", 1)])
 def test_both_schedules_on_ragged_sizes(torch_cuda, oracle_lib, monkeypatch, schedule, n):
     """The two-wave and the one-wave step kernels run the same arithmetic; sizes that are not a multiple of 64."""
     torch = torch_cuda
