@@ -1,5 +1,9 @@
-// Micro-benchmark: cycles per dependent / independent v_fma_f32 for one wave alone on a SIMD, with all 64 lanes active,
-// with only the low 32 active, and with only 16 active.  Build + run: hipcc --offload-arch=gfx950 -O3 valu_issue.hip -o valu_issue && ./valu_issue
+// Micro-benchmark: cycles per fp32 VALU operation for ONE wave alone on a SIMD (dependent chain, 4 / 8 / 16 independent chains; all 64,
+// the low 32 or the low 16 lanes active), and with 256 .. 2048 waves on the chip.
+// Built with plain -O3 the independent chains are SLP-packed into v_pk_fma_f32 (check with -S): the figures for >= 2 chains are then
+// per fp32 OPERATION, i.e. half the issue interval of the packed instruction (~4.3 cycles).  Built with -fno-slp-vectorize they are
+// per instruction.  tools/micro/ifetch.hip pins the encodings with inline assembly.
+//   hipcc --offload-arch=gfx950 -O3 valu_issue.hip -o valu_issue && ./valu_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
