@@ -181,6 +181,51 @@ PP_HD S3 rot_sym(const M3& e, const S3& s) {
 }
 PP_HD void add_sym(S3& a, const S3& b) { a.xx += b.xx; a.yy += b.yy; a.zz += b.zz; a.xy += b.xy; a.xz += b.xz; a.yz += b.yz; }
 
+// ---- two at a time.  A lone wave issues one VALU instruction per ~4-5 cycles whatever its width (tools/micro/valu_issue.hip,
+// ifetch.hip), and v_pk_{mul,add,fma}_f32 carries two fp32 operations in that slot, with either half of an operand broadcast for
+// free.  Wherever the step applies one operator to two independent operands (the same rotation to the angular and the linear
+// half of a spatial vector, to the two symmetric blocks of an articulated inertia, to the two ends of a capsule) the pair is
+// written as a 2-vector so that the compiler emits the packed instruction.  The arithmetic per element is the scalar code's.
+typedef float f2 __attribute__((vector_size(8)));
+struct V3p { f2 x, y, z; };                   // two 3-vectors
+struct S3p { f2 xx, yy, zz, xy, xz, yz; };    // two symmetric 3x3
+PP_HD f2 pk(float a, float b) { f2 r; r[0] = a; r[1] = b; return r; }   // (not `{a, b}`: with a struct field for `a` clang loads a 2-vector from its address)
+PP_HD V3p pk(V3 a, V3 b) { V3p r = {pk(a.x, b.x), pk(a.y, b.y), pk(a.z, b.z)}; return r; }
+PP_HD S3p pk(S3 a, S3 b) { S3p r = {pk(a.xx, b.xx), pk(a.yy, b.yy), pk(a.zz, b.zz), pk(a.xy, b.xy), pk(a.xz, b.xz), pk(a.yz, b.yz)}; return r; }
+PP_HD V3 lo(V3p a) { return mk(a.x[0], a.y[0], a.z[0]); }
+PP_HD V3 hi(V3p a) { return mk(a.x[1], a.y[1], a.z[1]); }
+PP_HD S3 lo(S3p a) { S3 r = {a.xx[0], a.yy[0], a.zz[0], a.xy[0], a.xz[0], a.yz[0]}; return r; }
+PP_HD S3 hi(S3p a) { S3 r = {a.xx[1], a.yy[1], a.zz[1], a.xy[1], a.xz[1], a.yz[1]}; return r; }
+PP_HD V3p operator+(V3p a, V3p b) { V3p r = {a.x + b.x, a.y + b.y, a.z + b.z}; return r; }
+PP_HD V3p operator*(V3p a, float s) { V3p r = {a.x * s, a.y * s, a.z * s}; return r; }
+PP_HD f2 dot(V3 a, V3p b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PP_HD f2 dot(V3p a, V3p b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PP_HD V3p cross(V3 a, V3p b) { V3p r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; return r; }
+PP_HD V3p cross(V3p a, V3 b) { V3p r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; return r; }
+PP_HD V3p mul(const M3& a, V3p v) { V3p r = {dot(row(a, 0), v), dot(row(a, 1), v), dot(row(a, 2), v)}; return r; }
+PP_HD V3p tmul(const M3& a, V3p v) { V3p r = {dot(col(a, 0), v), dot(col(a, 1), v), dot(col(a, 2), v)}; return r; }
+PP_HD V3p mul(const S3p& s, V3p v) {   // element by element: (s.lo v.lo, s.hi v.hi)
+    V3p r = {s.xx * v.x + s.xy * v.y + s.xz * v.z, s.xy * v.x + s.yy * v.y + s.yz * v.z, s.xz * v.x + s.yz * v.y + s.zz * v.z};
+    return r;
+}
+PP_HD void sym_rank1_sub(S3p& s, V3p u, float k) {
+    V3p uk = u * k;
+    s.xx -= u.x * uk.x; s.yy -= u.y * uk.y; s.zz -= u.z * uk.z;
+    s.xy -= u.x * uk.y; s.xz -= u.x * uk.z; s.yz -= u.y * uk.z;
+}
+PP_HD S3p rot_sym(const M3& e, const S3p& s) {   // E S E^T of both
+    const f2 S[9] = {s.xx, s.xy, s.xz, s.xy, s.yy, s.yz, s.xz, s.yz, s.zz};
+    f2 t[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[3 * i + j] = e.m[3 * i] * S[j] + e.m[3 * i + 1] * S[3 + j] + e.m[3 * i + 2] * S[6 + j];
+    S3p r;
+    r.xx = t[0] * e.m[0] + t[1] * e.m[1] + t[2] * e.m[2]; r.yy = t[3] * e.m[3] + t[4] * e.m[4] + t[5] * e.m[5]; r.zz = t[6] * e.m[6] + t[7] * e.m[7] + t[8] * e.m[8];
+    r.xy = t[0] * e.m[3] + t[1] * e.m[4] + t[2] * e.m[5]; r.xz = t[0] * e.m[6] + t[1] * e.m[7] + t[2] * e.m[8]; r.yz = t[3] * e.m[6] + t[4] * e.m[7] + t[5] * e.m[8];
+    return r;
+}
+
 // E(q) = origin_rot * Rot(axis, q): child coordinates -> parent coordinates
 template <int AX>
 PP_HD M3 joint_rot(const float* r0, float c, float s) {

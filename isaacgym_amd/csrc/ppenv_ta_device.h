@@ -96,8 +96,9 @@ PP_HD ArtI link_dynamics(const TAScal& C, const LinkC& L, const float (*cpoint)[
     const float m = L.mass;
     V3 h_ang = mul(A, w) + cross(mc, v);
     V3 h_lin = v * m - cross(mc, w);
-    V3 pn = cross(w, h_ang) + cross(v, h_lin);
-    V3 pf = cross(w, h_lin);
+    const V3p wxh = cross(w, pk(h_ang, h_lin));             // pairs that take the same operator are packed (ppenv_device.h, V3p / S3p)
+    V3 pn = lo(wxh) + cross(v, h_lin);
+    V3 pf = hi(wxh);
     V3 gb = mk(Rw.m[6], Rw.m[7], Rw.m[8]) * C.gravity_z;   // R^T (0, 0, g)
     pn = pn - cross(mc, gb);
     pf = pf - gb * m;
@@ -150,7 +151,8 @@ PP_HD void link_kinematics(const LinkC& L, float q, float qd, M3& Rw, V3& pw, V3
     const int ax = L.axis;
     E = joint_rot_rt(L.R0, ax, c, s);
     V3 r = ld3(L.r);
-    V3 wn = tmul(E, w), vn = tmul(E, v + cross(w, r));
+    const V3p wv = tmul(E, pk(w, v + cross(w, r)));
+    V3 wn = lo(wv), vn = hi(wv);
     if (ax == 0) wn.x += qd; else if (ax == 1) wn.y += qd; else wn.z += qd;
     pw = pw + mul(Rw, r);
     Rw = mul(Rw, E);
@@ -192,32 +194,34 @@ PP_HD void inward_step(const TAScal& C, const LinkC& L, ArtI& I, V3 w, V3 v, con
     float dinv = rcp_fast(symdiag(A, ax) + arm);
     float u = tau - comp(I.pn, ax);
     jo.ua = ua; jo.ub = ub; jo.dinv = dinv; jo.u = u;
-    sym_rank1_sub(A, ua, dinv);
-    sym_rank1_sub(D, ub, dinv);
+    S3p AD = pk(A, D);
+    const V3p uab = pk(ua, ub);
+    sym_rank1_sub(AD, uab, dinv);
     V3 uad = ua * dinv;
     for (int r = 0; r < 3; r++) {
         float k = comp(uad, r);
         B.m[3 * r] -= k * ub.x; B.m[3 * r + 1] -= k * ub.y; B.m[3 * r + 2] -= k * ub.z;
     }
     V3 e = unit(ax);
-    V3 cw = cross(w, e) * qd, cv = cross(v, e) * qd;
+    const V3p c = cross(pk(w, v), e) * qd;                  // c = v x S qd, angular and linear half
+    V3 cw = lo(c), cv = hi(c);
     float ud = u * dinv;
-    V3 pan = I.pn + mul(A, cw) + mul(B, cv) + ua * ud;
-    V3 paf = I.pf + tmul(B, cw) + mul(D, cv) + ub * ud;
+    const V3p pa = pk(I.pn, I.pf) + mul(AD, c) + pk(mul(B, cv), tmul(B, cw)) + uab * ud;   // p + I^a c + U u / D
     V3 r = ld3(L.r);
-    S3 Ar = rot_sym(E, A), Dr = rot_sym(E, D);
+    const S3p ADr = rot_sym(E, AD);
+    const S3 Ar = lo(ADr), Dr = hi(ADr);
     M3 Br = mul_t(mul(E, B), E);
-    V3 nr = mul(E, pan), fr = mul(E, paf);
+    const V3p nfr = mul(E, pa);
+    V3 nr = lo(nfr), fr = hi(nfr);
     M3 Dm = from_sym(Dr);
     M3 Bp;
     for (int j = 0; j < 3; j++) {
         V3 x = cross(r, col(Dm, j));
         Bp.m[j] = Br.m[j] + x.x; Bp.m[3 + j] = Br.m[3 + j] + x.y; Bp.m[6 + j] = Br.m[6 + j] + x.z;
     }
-    V3 wp0 = cross(r, row(Bp, 0)), wp1 = cross(r, row(Bp, 1)), wp2 = cross(r, row(Bp, 2));
-    V3 wb0 = cross(r, row(Br, 0)), wb1 = cross(r, row(Br, 1)), wb2 = cross(r, row(Br, 2));
-    S3 Ap = {Ar.xx + wp0.x + wb0.x, Ar.yy + wp1.y + wb1.y, Ar.zz + wp2.z + wb2.z,
-             Ar.xy + wp1.x + wb0.y, Ar.xz + wp2.x + wb0.z, Ar.yz + wp2.y + wb1.z};
+    const V3p w0 = cross(r, pk(row(Bp, 0), row(Br, 0))), w1 = cross(r, pk(row(Bp, 1), row(Br, 1))), w2 = cross(r, pk(row(Bp, 2), row(Br, 2)));
+    S3 Ap = {Ar.xx + w0.x[0] + w0.x[1], Ar.yy + w1.y[0] + w1.y[1], Ar.zz + w2.z[0] + w2.z[1],
+             Ar.xy + w1.x[0] + w0.y[1], Ar.xz + w2.x[0] + w0.z[1], Ar.yz + w2.y[0] + w1.z[1]};
     I.A = Ap; I.B = Bp; I.D = Dr;
     I.pn = nr + cross(r, fr); I.pf = fr;
 }
@@ -228,9 +232,10 @@ PP_HD void outward_step(const TAScal& C, const LinkC& L, const M3& E, V3 w, V3 v
                         float target, float& q, float& qd, float& force) {
     const int ax = L.axis;
     V3 r = ld3(L.r), e = unit(ax);
-    V3 aw2 = tmul(E, aw) + cross(w, e) * qd;
-    V3 av2 = tmul(E, av + cross(aw, r)) + cross(v, e) * qd;
-    float qdd = (jo.u - dot(jo.ua, aw2) - dot(jo.ub, av2)) * jo.dinv;
+    const V3p a2 = tmul(E, pk(aw, av + cross(aw, r))) + cross(pk(w, v), e) * qd;   // (angular, linear)
+    V3 aw2 = lo(a2), av2 = hi(a2);
+    const f2 ud = dot(pk(jo.ua, jo.ub), a2);
+    float qdd = (jo.u - ud[0] - ud[1]) * jo.dinv;
     if (ax == 0) aw2.x += qdd; else if (ax == 1) aw2.y += qdd; else aw2.z += qdd;
     aw = aw2; av = av2;
     float err = target - q;

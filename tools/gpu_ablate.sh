@@ -2,7 +2,7 @@
 # Ablation timing (profiling only): full kernel vs pieces compiled out.
 set -o pipefail
 mkdir -p gpurun_out/ablate
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-signed-zeros -ffinite-math-only -fPIC -shared"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -disable-vector-combine -fno-signed-zeros -ffinite-math-only -fPIC -shared"
 for a in 0 1 2 3; do
   hipcc $FL -DPP_ABLATE=$a -o gpurun_out/ablate/lib$a.so isaacgym_amd/csrc/ppenv.hip || exit 1
   for n in 16384 65536; do

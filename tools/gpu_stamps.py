@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "gpurun_out", "libppenv_stamp.so")
 SRC = os.environ.get("PPENV_STAMP_SRC", os.path.join(ROOT, "isaacgym_amd", "csrc"))   # another source tree to stamp (A/B of two builds)
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only",
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-fno-signed-zeros", "-ffinite-math-only",
                 "-fPIC", "-shared", "-DPP_STAMP=1", *os.environ.get("PPENV_STAMP_DEFS", "").split(), "-I", os.path.join(ROOT, "include"), "-o", lib, os.path.join(SRC, "ppenv.hip"), os.path.join(SRC, "ppenv_ta.hip"),
                 os.path.join(SRC, "ppenv_ta_sim.hip")], check=True)
 os.environ["PPENV_LIB"] = lib

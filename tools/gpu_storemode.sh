@@ -2,7 +2,7 @@
 # profiling: how the state stores leave the CU (PP_STORE_MODE 0 plain / 1 non-temporal / 2 system scope)
 set -o pipefail
 mkdir -p gpurun_out/sm
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-signed-zeros -ffinite-math-only -fPIC -shared"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -disable-vector-combine -fno-signed-zeros -ffinite-math-only -fPIC -shared"
 for m in 0 1 2; do
   hipcc $FL -DPP_STORE_MODE=$m -o gpurun_out/sm/lib$m.so isaacgym_amd/csrc/ppenv.hip isaacgym_amd/csrc/ppenv_ta.hip || exit 1
   for n in 16384 65536; do
