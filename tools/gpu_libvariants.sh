@@ -3,7 +3,7 @@
 set -o pipefail
 mkdir -p gpurun_out
 for lib in build_variants/libppenv_*.so; do
-  for spec in "TT 16384" "TT 65536" "T4 8192" "TA 4096"; do
+  for spec in ${SPECS:-"TT 16384" "TT 65536" "T4 8192" "TA 4096"}; do
     set -- $spec
     PPENV_LIB=$PWD/$lib timeout -k 10 300 python bench.py --steps 1024 --warmup 128 --no-cpu-baseline --variant $1 --num-envs $2 > gpurun_out/bench_lv.json 2> gpurun_out/bench_lv.err || { tail -20 gpurun_out/bench_lv.err; exit 1; }
     python - "$lib" "$1" "$2" <<'PY'
