@@ -20,16 +20,17 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 seeds = [int(a) for a in sys.argv[2:]] or [21, 22, 23]
 ob.build()
 tot = bad = 0
-for variant in ("TT", "T3", "TN"):
+for variant in ("TT", "T3", "TN", "T4"):
     for seed in seeds:
         n = 2048
+        A = 2 if variant == "T4" else 1
         cfg = scene.build_config(variant, num_envs=n, seed=seed)
         o = ob.OracleEnv(cfg, threads=16)
         env = PPEnv(scene.build_config(variant, num_envs=n, seed=seed), device="cuda:0")
         probe = SensitivityProbe(ob, cfg)
         rng = np.random.default_rng(seed)
         for t in range(steps):
-            a = rng.uniform(-1.2, 1.2, (n, 7)).astype(np.float32)
+            a = rng.uniform(-1.2, 1.2, (n * A, 7)).astype(np.float32)
             st = o.get_state()
             env.set_state(st)
             o.step(a)
@@ -44,8 +45,9 @@ for variant in ("TT", "T3", "TN"):
                 if m.any():
                     bad += int(m.sum())
                     print(variant, seed, t, name, np.nonzero(m)[0][:5], float(np.abs(g - w)[:, m].max()), flush=True)
-            m = (np.abs(got["rew_buf"] - o.rew_buf) > probe.rew_atol + RTOL * np.abs(o.rew_buf)) & keep
-            m |= (got["reset_buf"] != o.reset_buf) & keep
+            rows = np.repeat(keep, A)
+            m = (np.abs(got["rew_buf"] - o.rew_buf) > A * probe.rew_atol + RTOL * np.abs(o.rew_buf)) & rows   # the power term sums A * 7 dofs
+            m |= (got["reset_buf"] != o.reset_buf) & rows
             if m.any():
                 bad += int(m.sum())
                 print(variant, seed, t, "rew/reset", np.nonzero(m)[0][:5], flush=True)
