@@ -22,7 +22,7 @@ constexpr int NDOF = PPENV_TA_NUM_DOF;
 // ---- constants of the tree, derived once on the host (make_ta_consts) and read from global memory by the kernels
 struct LinkC {
     int32_t parent, axis, body, cfirst, ccount;            // contacts [cfirst, cfirst + ccount) sit on this link
-    int32_t geo_mask, pad_[2];                              // bit s: ball-collision shape s rides on this link; bit 6 paddle; bit 7 bound centre
+    int32_t geo_mask, ffirst, fcount;                       // bit s: ball-collision shape s rides on this link; bit 6 paddle; bit 7 bound centre.  Welded bodies [ffirst, ffirst + fcount) of `fixed` ride on it
     float r[3], R0[9];                                      // child frame in the parent frame at q = 0
     float mass, mc[3], Io[6];                               // m, m * com, inertia about the link ORIGIN (xx yy zz xy xz yz)
     float lo, hi, kp, kd, effort, vlim, armature;
@@ -464,9 +464,20 @@ inline bool make_ta_consts(const ppenv_config& scene, const ppenv_ta_model& m, T
     for (int f = 0; f < PPENV_TA_NUM_FIXED; f++) {
         const ppenv_ta_fixed& s = m.fixed[f];
         if (s.link < 0 || s.link >= NL || s.body < 0 || s.body >= PPENV_NUM_HUMANOID_BODIES) { *why = "welded body: link / body index out of range"; return false; }
-        C.fixed[f].body = s.body; C.fixed[f].link = s.link;
-        for (int k = 0; k < 3; k++) C.fixed[f].xyz[k] = s.xyz[k];
-        for (int k = 0; k < 9; k++) C.fixed[f].rot[k] = s.rot[k];
+    }
+    int nf = 0;   // sorted by link, like the contact points: a link visits only the bodies welded to it
+    for (int i = 0; i < NL; i++) {
+        C.link[i].ffirst = nf;
+        for (int f = 0; f < PPENV_TA_NUM_FIXED; f++) {
+            const ppenv_ta_fixed& s = m.fixed[f];
+            if (s.link != i) continue;
+            C.fixed[nf].body = s.body; C.fixed[nf].link = s.link;
+            C.fixed[nf].pad_[0] = C.fixed[nf].pad_[1] = 0;
+            for (int k = 0; k < 3; k++) C.fixed[nf].xyz[k] = s.xyz[k];
+            for (int k = 0; k < 9; k++) C.fixed[nf].rot[k] = s.rot[k];
+            nf++;
+        }
+        C.link[i].fcount = nf - C.link[i].ffirst;
     }
     C.sc.num_contacts = m.num_contacts; C.sc.paddle_link = scene.paddle_link; C.sc.bound_link = m.bound_link; C.sc.num_shapes = scene.num_shapes;
     if (C.sc.paddle_link < 0 || C.sc.paddle_link >= NL || C.sc.bound_link < 0 || C.sc.bound_link >= NL) { *why = "paddle_link / bound_link out of range"; return false; }

@@ -175,15 +175,17 @@ __device__ __forceinline__ void write_row(float* row, const M3& R, V3 p, V3 lin,
     row[7] = lin.x; row[8] = lin.y; row[9] = lin.z; row[10] = ang.x; row[11] = ang.y; row[12] = ang.z;
 }
 // rows of link `li` and of the bodies welded to it
-__device__ __forceinline__ void write_link_rows(const TAConsts& C, const LinkC& L, int li, const M3& Rw, V3 pw, V3 w, V3 v, float* rb) {
+// (`fixed`: the table in LDS, sorted by link.  Scanning all twelve entries of the global table for every link cost the output section
+// 120 scalar loads, each waited for in turn.)
+__device__ __forceinline__ void write_link_rows(const FixedC* fixed, const LinkC& L, const M3& Rw, V3 pw, V3 w, V3 v, float* rb) {
     V3 ang = mul(Rw, w);
     write_row(rb + L.body * 13, Rw, pw, mul(Rw, v), ang);
-    for (int f = 0; f < PPENV_TA_NUM_FIXED; f++)
-        if (C.fixed[f].link == li) {
-            V3 p, vel;
-            point_of(Rw, pw, w, v, ld3(C.fixed[f].xyz), p, vel);
-            write_row(rb + C.fixed[f].body * 13, mul(Rw, ldm(C.fixed[f].rot)), p, vel, ang);
-        }
+    for (int f = L.ffirst; f < L.ffirst + L.fcount; f++) {
+        const FixedC F = fixed[f];
+        V3 p, vel;
+        point_of(Rw, pw, w, v, ld3(F.xyz), p, vel);
+        write_row(rb + F.body * 13, mul(Rw, ldm(F.rot)), p, vel, ang);
+    }
 }
 
 // what the fused launch needs beyond the rigid-body step: the task's parameters and per-env buffers (ppenv_ta_post_physics_step's)
@@ -203,11 +205,16 @@ struct TaskArgs {
 // STEP = false: forward kinematics only.  FUSE = true: post_physics_step (reward, masked reset, 313-wide observation, TA:1145-1192)
 // in the same launch, on the LDS tiles, before anything goes to global memory.
 template <bool STEP, bool FUSE>
-__global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restrict__ Cp, const TAScal P, const StepConsts K, int n, const float* __restrict__ actions,
+__global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restrict__ Cp, const TAScal P, const StepConsts* __restrict__ Kp, int n, const float* __restrict__ actions,
                                                          float* root_states, float* dof_states, float* __restrict__ rb_states,
                                                          float* __restrict__ dof_force, float* __restrict__ pre_vx, const TaskArgs task) {
     __shared__ LinkC s_link[NL];
     __shared__ float s_cpoint[PPENV_TA_MAX_CONTACTS][3];
+    __shared__ FixedC s_fixed[PPENV_TA_NUM_FIXED];
+    // The scene constants of the ball's contact code (1.3 KB).  As a by-value kernel argument they sat in SGPRs for the whole launch and, with the
+    // model scalars, overflowed them: 209 spilled SGPRs and 1.9k v_readlane in the listing.  Only the ball lane reads them, once per substep.
+    __shared__ StepConsts s_K;
+    __shared__ ppenv_ta_params s_tp;   // the task's parameters (100 dwords, read once at the end of the launch), likewise
     __shared__ float s_rec[kChainLen * kRec * 64];
     __shared__ float s_q[NDOF][kQuadEnvs], s_qd[NDOF][kQuadEnvs], s_target[NDOF][kQuadEnvs], s_force[NDOF][kQuadEnvs];
     const TAConsts& C = *Cp;
@@ -219,6 +226,17 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_link);
         for (int t = lane; t < (int)(sizeof(LinkC) * NL / 4); t += 64) dst[t] = src[t];
         for (int t = lane; t < PPENV_TA_MAX_CONTACTS * 3; t += 64) (&s_cpoint[0][0])[t] = (&C.cpoint[0][0])[t];
+        for (int t = lane; t < (int)(sizeof(FixedC) * PPENV_TA_NUM_FIXED / 4); t += 64) reinterpret_cast<uint32_t*>(s_fixed)[t] = reinterpret_cast<const uint32_t*>(C.fixed)[t];
+        if (FUSE) {
+            const uint32_t* ps = reinterpret_cast<const uint32_t*>(&task.p);   // a lane-indexed read of the kernel-argument block
+            uint32_t* pd = reinterpret_cast<uint32_t*>(&s_tp);
+            for (int t = lane; t < (int)(sizeof(ppenv_ta_params) / 4); t += 64) pd[t] = ps[t];
+        }
+        if (STEP) {
+            const uint32_t* ks = reinterpret_cast<const uint32_t*>(Kp);
+            uint32_t* kd = reinterpret_cast<uint32_t*>(&s_K);
+            for (int t = lane; t < (int)(sizeof(StepConsts) / 4); t += 64) kd[t] = ks[t];
+        }
     }
     float* root = root_states + (size_t)(live ? e : 0) * 39;
     float* dofs = dof_states + (size_t)(live ? e : 0) * 2 * NDOF;
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 }
             }
             integrate_base_regs(P, R0, w0, v0, base, alpha, a);
-            if (role == 3) ball_substep<ModelG1TA, 1>(K, ball, g, bound);
+            if (role == 3) ball_substep<ModelG1TA, 1>(s_K, ball, g, bound);
             __builtin_amdgcn_wave_barrier();                             // lane 2's waist dofs before every lane's next pass 1
         }
     }
@@ -342,14 +360,14 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         float* rb = t_rb + es * kRb;
         M3 Rw = quat_to_m3(base.quat);
         V3 pw = base.p, w = tmul(Rw, base.ww), v = tmul(Rw, base.vw);
-        if (role == 0) write_link_rows(C, s_link[0], 0, Rw, pw, w, v, rb);
+        if (role == 0) write_link_rows(s_fixed, s_link[0], Rw, pw, w, v, rb);
         for (int k = 0; k < kChainLen; k++) {
             const int li = chain_link(role, k);
             if (li < 0) continue;
             const LinkC L = s_link[li];
             M3 E;
             link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, E);
-            if (!(role == 3 && k < 3)) write_link_rows(C, L, li, Rw, pw, w, v, rb);
+            if (!(role == 3 && k < 3)) write_link_rows(s_fixed, L, Rw, pw, w, v, rb);
         }
         float* tr = t_root + es * kRoot;
         if (role == 0) {
@@ -394,7 +412,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         if (FUSE) {
             {   // the four lanes of the quad share the env's task arithmetic (lanes past the last env compute on env n - 1, store nothing)
                 const int ec = live ? e : n - 1;
-                tatask::ta_task_env<4>(task.p, ec, t_rb + es * kRb, task.initial_rb + (size_t)ec * kRb, t_root + es * kRoot, t_dofs + es * kDofs,
+                tatask::ta_task_env<4>(s_tp, ec, t_rb + es * kRb, task.initial_rb + (size_t)ec * kRb, t_root + es * kRoot, t_dofs + es * kDofs,
                                        t_frc + es * NDOF, t_pvx[es], task.reset_override ? task.reset_override + (size_t)ec * 5 : nullptr, &task.flags[ec],
                                        &task.episode[ec], &task.progress[ec], t_obs + es * PPENV_TA_NUM_OBS, &task.rew[ec], &task.reset[ec], task.any_reset,
                                        role, live);
@@ -420,6 +438,7 @@ struct ppenv_ta_sim {
     TAConsts host;
     TAConsts* dev;
     StepConsts K;
+    StepConsts* devK;      // the same in device memory (the quad kernel stages it in LDS)
     int device;
     int quad;     // 1: ta_sim_quad_kernel (four lanes per env), 0: ta_sim_kernel (one lane per env; any tree)
 };
@@ -442,18 +461,23 @@ int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, 
     }
     s->K = make_step_consts(*scene);
     s->dev = nullptr;
+    s->devK = nullptr;
     {   // PPENV_TA_KERNEL=lane|quad forces a mapping (same arithmetic; the quad kernel needs the G1 tree)
         const char* k = getenv("PPENV_TA_KERNEL");
         s->quad = quad_topology(s->host) && !(k && strcmp(k, "lane") == 0);
     }
-    if (hipGetDevice(&s->device) != hipSuccess || hipMalloc((void**)&s->dev, sizeof(TAConsts)) != hipSuccess) {
+    if (hipGetDevice(&s->device) != hipSuccess || hipMalloc((void**)&s->dev, sizeof(TAConsts)) != hipSuccess ||
+        hipMalloc((void**)&s->devK, sizeof(StepConsts)) != hipSuccess) {
         ppenv_set_error("ppenv_ta_sim_create: hipMalloc of the model constants failed");
+        if (s->dev) (void)hipFree(s->dev);
         delete s;
         return PPENV_EHIP;
     }
     // pageable host source: the copy is staged before the call returns, the struct may be reused by the caller
-    if (hipMemcpyAsync(s->dev, &s->host, sizeof(TAConsts), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+    if (hipMemcpyAsync(s->dev, &s->host, sizeof(TAConsts), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+        hipMemcpyAsync(s->devK, &s->K, sizeof(StepConsts), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
         (void)hipFree(s->dev);
+        (void)hipFree(s->devK);
         delete s;
         ppenv_set_error("ppenv_ta_sim_create: uploading the model constants failed");
         return PPENV_EHIP;
@@ -465,6 +489,7 @@ int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, 
 void ppenv_ta_sim_destroy(ppenv_ta_sim* s) {
     if (!s) return;
     if (s->dev) (void)hipFree(s->dev);
+    if (s->devK) (void)hipFree(s->devK);
     delete s;
 }
 
@@ -475,7 +500,7 @@ int ppenv_ta_simulate(ppenv_ta_sim* s, int32_t n, const float* actions_dev, floa
         return PPENV_EINVAL;
     }
     if (s->quad)
-        hipLaunchKernelGGL((ta_sim_quad_kernel<true, false>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->K, n, actions_dev,
+        hipLaunchKernelGGL((ta_sim_quad_kernel<true, false>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->devK, n, actions_dev,
                            root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev, TaskArgs{});
     else
         hipLaunchKernelGGL(ta_sim_kernel<true>, dim3((n + kTaLanes - 1) / kTaLanes), dim3(kTaLanes), 0, (hipStream_t)stream, s->dev, s->K, n, actions_dev,
@@ -503,7 +528,7 @@ int ppenv_ta_step(ppenv_ta_sim* s, const ppenv_ta_params* params, const float* a
     hipStream_t st = (hipStream_t)stream;
     TaskArgs t{*params, initial_rb_states_dev, reset_override_dev, flags_dev, episode_dev, (long long*)progress_dev, obs_dev, rew_dev, (long long*)reset_dev,
                scratch_any_reset_dev};
-    hipLaunchKernelGGL((ta_sim_quad_kernel<true, true>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, st, s->dev, s->host.sc, s->K, n, actions_dev,
+    hipLaunchKernelGGL((ta_sim_quad_kernel<true, true>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, st, s->dev, s->host.sc, s->devK, n, actions_dev,
                        root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev, t);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching the fused 27-dof step failed"); return PPENV_EHIP; }
     return ppenv_ta_clear_counts(n, flags_dev, scratch_any_reset_dev, stream);
@@ -516,7 +541,7 @@ int ppenv_ta_forward_kinematics(ppenv_ta_sim* s, int32_t n, const float* root_st
         return PPENV_EINVAL;
     }
     if (s->quad)
-        hipLaunchKernelGGL((ta_sim_quad_kernel<false, false>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->K, n,
+        hipLaunchKernelGGL((ta_sim_quad_kernel<false, false>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->devK, n,
                            (const float*)nullptr, const_cast<float*>(root_states_dev), const_cast<float*>(dof_states_dev), rb_states_dev,
                            (float*)nullptr, (float*)nullptr, TaskArgs{});
     else

@@ -26,7 +26,7 @@ for name in ("sq1","sq2"):
     acc = collections.defaultdict(list)
     for f in glob.glob(f"gpurun_out/pmc_ta/{name}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "ta_sim_quad_kernel<true>" in row["Kernel_Name"]:
+            if "ta_sim_quad_kernel<true" in row["Kernel_Name"]:
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k,v in sorted(acc.items()):
         print(f"{name} {k:24s} n={len(v)} mean per dispatch {sum(v)/len(v):14.1f}   per wave {sum(v)/len(v)/256:10.1f}")
