@@ -247,21 +247,22 @@ PP_HD void quat_to_rot(const float q[4], float r[9]) {
 }
 // rotation matrix -> xyzw quaternion with w >= 0
 PP_HD void rot_to_quat(const M3& r, float q[4]) {
-    float tr = r.m[0] + r.m[4] + r.m[8];
-    float x, y, z, w;
-    if (tr > 0.f) {
-        float s = sqrtf(tr + 1.0f) * 2.f;
-        w = 0.25f * s; x = (r.m[7] - r.m[5]) / s; y = (r.m[2] - r.m[6]) / s; z = (r.m[3] - r.m[1]) / s;
-    } else if (r.m[0] > r.m[4] && r.m[0] > r.m[8]) {
-        float s = sqrtf(1.0f + r.m[0] - r.m[4] - r.m[8]) * 2.f;
-        w = (r.m[7] - r.m[5]) / s; x = 0.25f * s; y = (r.m[1] + r.m[3]) / s; z = (r.m[2] + r.m[6]) / s;
-    } else if (r.m[4] > r.m[8]) {
-        float s = sqrtf(1.0f + r.m[4] - r.m[0] - r.m[8]) * 2.f;
-        w = (r.m[2] - r.m[6]) / s; x = (r.m[1] + r.m[3]) / s; y = 0.25f * s; z = (r.m[5] + r.m[7]) / s;
-    } else {
-        float s = sqrtf(1.0f + r.m[8] - r.m[0] - r.m[4]) * 2.f;
-        w = (r.m[3] - r.m[1]) / s; x = (r.m[2] + r.m[6]) / s; y = (r.m[5] + r.m[7]) / s; z = 0.25f * s;
-    }
+    // Shepperd's four cases (pivot on the trace or on the largest diagonal entry) written with selects: lanes of a wave pick different
+    // cases, and as branches each lane paid for all four (a square root and three divisions apiece).
+    const float tr = r.m[0] + r.m[4] + r.m[8];
+    const bool c0 = tr > 0.f;
+    const bool c1 = !c0 && r.m[0] > r.m[4] && r.m[0] > r.m[8];
+    const bool c2 = !c0 && !c1 && r.m[4] > r.m[8];
+    const bool c3 = !c0 && !c1 && !c2;
+    const float piv = c1 ? r.m[0] : (c2 ? r.m[4] : r.m[8]);
+    const float s = sqrtf(1.0f + (c0 ? tr : 2.f * piv - tr)) * 2.f;      // 1 + m_pp - (the other two) = 1 + 2 m_pp - tr
+    const float inv = 1.0f / s, big = 0.25f * s;
+    const float d0 = r.m[7] - r.m[5], d1 = r.m[2] - r.m[6], d2 = r.m[3] - r.m[1];
+    const float a0 = r.m[1] + r.m[3], a1 = r.m[2] + r.m[6], a2 = r.m[5] + r.m[7];
+    float w = c0 ? big : inv * (c1 ? d0 : (c2 ? d1 : d2));
+    float x = c1 ? big : inv * (c0 ? d0 : (c2 ? a0 : a1));
+    float y = c2 ? big : inv * (c0 ? d1 : (c1 ? a0 : a2));
+    float z = c3 ? big : inv * (c0 ? d2 : (c1 ? a1 : a2));
     if (w < 0.f) { x = -x; y = -y; z = -z; w = -w; }
     q[0] = x; q[1] = y; q[2] = z; q[3] = w;
 }

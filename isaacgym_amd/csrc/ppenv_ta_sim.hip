@@ -26,6 +26,21 @@ void ppenv_set_error(const char* msg);   // ppenv.hip
 int ppenv_ta_clear_counts(int n, uint32_t* flags_dev, uint32_t* any_reset_dev, void* stream);   // ppenv_ta.hip
 
 namespace {
+// Diagnostic builds only (-DTA_STAMP, tools/gpu_ta_stamps.py): shader-clock stamps of the quad kernel's phases, lane 0 of each workgroup.
+#if defined(TA_STAMP)
+__device__ unsigned long long ta_stamp_buf[4096 * 32];
+#define TA_STAMP_AT(k)                                                                     \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long t_;                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) ta_stamp_buf[blockIdx.x * 32 + (k)] = t_; \
+    } while (0)
+#else
+#define TA_STAMP_AT(k) do { } while (0)
+#endif
+
 constexpr int kTaLanes = 16;
 
 struct LdsStore {
@@ -188,6 +203,25 @@ __device__ __forceinline__ void write_link_rows(const FixedC* fixed, const LinkC
     }
 }
 
+// LDS tile -> its contiguous block of a tensor.  A full workgroup's tile (FLOATS per workgroup, a multiple of 4, 16-byte aligned on both
+// sides) goes as float4 with a constant trip count, so that several LDS reads are in flight before the first store; a ragged last
+// workgroup copies its `valid` floats one by one.
+template <int FLOATS>
+__device__ __forceinline__ void copy_tile(float* __restrict__ dst, const float* __restrict__ src, int valid, int lane) {
+    static_assert(FLOATS % 4 == 0, "tile size");
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    if (valid == FLOATS) {
+        constexpr int kVec = FLOATS / 4, kTrips = (kVec + 63) / 64;
+#pragma unroll 6
+        for (int it = 0; it < kTrips; it++) {
+            const int k = it * 64 + lane;
+            if (kVec % 64 == 0 || k < kVec) reinterpret_cast<f4v*>(dst)[k] = reinterpret_cast<const f4v*>(src)[k];
+        }
+        return;
+    }
+    for (int t = lane; t < valid; t += 64) dst[t] = src[t];
+}
+
 // what the fused launch needs beyond the rigid-body step: the task's parameters and per-env buffers (ppenv_ta_post_physics_step's)
 struct TaskArgs {
     ppenv_ta_params p;
@@ -215,7 +249,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
     // model scalars, overflowed them: 209 spilled SGPRs and 1.9k v_readlane in the listing.  Only the ball lane reads them, once per substep.
     __shared__ StepConsts s_K;
     __shared__ ppenv_ta_params s_tp;   // the task's parameters (100 dwords, read once at the end of the launch), likewise
-    __shared__ float s_rec[kChainLen * kRec * 64];
+    __shared__ __attribute__((aligned(16))) float s_rec[kChainLen * kRec * 64];   // later the output tiles, read back as float4
     __shared__ float s_q[NDOF][kQuadEnvs], s_qd[NDOF][kQuadEnvs], s_target[NDOF][kQuadEnvs], s_force[NDOF][kQuadEnvs];
     const TAConsts& C = *Cp;
     const int lane = threadIdx.x, role = lane & 3, es = lane >> 2;
@@ -250,10 +284,12 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
             s_force[d][es] = 0.f;
         }
     }
+    TA_STAMP_AT(0);
     __syncthreads();   // one wave: orders the LDS fills above against the reads below
     BaseState base;
     load_base(root, base);
     QuadRec rc{&s_rec[lane]};
+    TA_STAMP_AT(1);
     Ball ball;
     float pre_vx_reg_out = 0.f;
     if (STEP) {
@@ -288,6 +324,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 rec_store_art(rc, k, link_dynamics(P, L, s_cpoint, Rw, pw, w, v));
                 capture_geometry(P, L.geo_mask, Rw, pw, w, v, g[0], bound[0]);   // complete on the right-arm lane (pelvis, torso, right arm)
             }
+            TA_STAMP_AT(2 + 5 * (sub & 1));
             // ---- pass 2: articulated inertias tip -> base; the arms meet at the torso, everything at the pelvis
             ArtI acc = art_zero();
             for (int k = kChainLen - 1; k >= 0; k--) {
@@ -311,6 +348,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 rc(k, R_JO + 6) = jo.dinv; rc(k, R_JO + 7) = jo.u;
                 acc = I;
             }
+            TA_STAMP_AT(3 + 5 * (sub & 1));
             if (role == 3) acc = art_zero();                             // its waist chain duplicates lane 2's
             {
                 ArtI t = art_shfl_xor(acc, 1);
@@ -321,6 +359,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
             add_art(I0, acc);
             V3 alpha, a;
             solve_base_art(I0, alpha, a);
+            TA_STAMP_AT(4 + 5 * (sub & 1));
             // ---- pass 3: accelerations base -> tip, joints integrated on the way
             V3 aw = alpha, av = a;
             for (int k = 0; k < kChainLen; k++) {
@@ -340,7 +379,9 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 }
             }
             integrate_base_regs(P, R0, w0, v0, base, alpha, a);
+            TA_STAMP_AT(5 + 5 * (sub & 1));
             if (role == 3) ball_substep<ModelG1TA, 1>(s_K, ball, g, bound);
+            TA_STAMP_AT(6 + 5 * (sub & 1));
             __builtin_amdgcn_wave_barrier();                             // lane 2's waist dofs before every lane's next pass 1
         }
     }
@@ -399,16 +440,14 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         }
     }
     __builtin_amdgcn_wave_barrier();
+    TA_STAMP_AT(12);
     const int nv = min(kQuadEnvs, n - blockIdx.x * kQuadEnvs);
     const size_t e0 = (size_t)blockIdx.x * kQuadEnvs;
     // rigid_body_states are the PRE-reset ones (the reference refreshes them before reward / reset, TA:1150-1160)
-    {
-        float2* dst = reinterpret_cast<float2*>(rb_states + e0 * kRb);
-        const float2* src = reinterpret_cast<const float2*>(t_rb);
-        for (int t = lane; t < nv * (kRb / 2); t += 64) dst[t] = src[t];
-    }
+    copy_tile<kQuadEnvs * kRb>(rb_states + e0 * kRb, t_rb, nv * kRb, lane);
+    TA_STAMP_AT(13);
     if (STEP) {
-        for (int t = lane; t < nv * NDOF; t += 64) dof_force[e0 * NDOF + t] = t_frc[t];
+        copy_tile<kQuadEnvs * NDOF>(dof_force + e0 * NDOF, t_frc, nv * NDOF, lane);
         if (FUSE) {
             {   // the four lanes of the quad share the env's task arithmetic (lanes past the last env compute on env n - 1, store nothing)
                 const int ec = live ? e : n - 1;
@@ -418,11 +457,13 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                                        role, live);
             }
             __builtin_amdgcn_wave_barrier();
-            for (int t = lane; t < nv * PPENV_TA_NUM_OBS; t += 64) task.obs[e0 * PPENV_TA_NUM_OBS + t] = t_obs[t];
+            TA_STAMP_AT(14);
+            copy_tile<kQuadEnvs * PPENV_TA_NUM_OBS>(task.obs + e0 * PPENV_TA_NUM_OBS, t_obs, nv * PPENV_TA_NUM_OBS, lane);
         }
-        for (int t = lane; t < nv * kRoot; t += 64) root_states[e0 * kRoot + t] = t_root[t];
-        for (int t = lane; t < nv * kDofs; t += 64) dof_states[e0 * kDofs + t] = t_dofs[t];
+        copy_tile<kQuadEnvs * kRoot>(root_states + e0 * kRoot, t_root, nv * kRoot, lane);
+        copy_tile<kQuadEnvs * kDofs>(dof_states + e0 * kDofs, t_dofs, nv * kDofs, lane);
     }
+    TA_STAMP_AT(15);
 }
 
 // does the model have the tree the quad kernel's chains are written for?
@@ -444,6 +485,13 @@ struct ppenv_ta_sim {
 };
 
 extern "C" {
+
+#if defined(TA_STAMP)
+int ppenv_ta_debug_read_stamps(unsigned long long* dst, size_t count) {
+    if (hipDeviceSynchronize() != hipSuccess) return PPENV_EHIP;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ta_stamp_buf), count * sizeof(unsigned long long)) == hipSuccess ? 0 : PPENV_EHIP;
+}
+#endif
 
 int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, void* stream, ppenv_ta_sim** out) {
     if (!scene || !model || !out) { ppenv_set_error("ppenv_ta_sim_create: NULL argument"); return PPENV_EINVAL; }
