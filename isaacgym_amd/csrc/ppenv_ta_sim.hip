@@ -118,8 +118,11 @@ __global__ __launch_bounds__(kTaLanes) void ta_sim_kernel(const TAConsts* __rest
 // tree runs on ta_sim_kernel).
 constexpr int kQuadEnvs = 16;      // envs per 64-lane workgroup
 constexpr int kChainLen = 10;
-constexpr int kRec = 42;           // E9 w3 v3 | A6 B9 D6 pn3 pf3  (later: ua3 ub3 dinv u over the A.. slots)
-constexpr int R_E = 0, R_W = 9, R_V = 12, R_ART = 15, R_JO = 15;
+// A link's record is contiguous per lane, 44 floats = eleven 16-byte groups: E9 w3 | v3 - | A6 B9 D6 pn3 pf3 - (later ua3 ub3 dinv u over the
+// A.. slots), so that the compiler reads and writes it as ds_*_b128 (a lane stride of 44 floats is conflict-free for 128-bit accesses:
+// eight lanes x four banks cover the 32 banks once).  Field-major storage needed one ds_read_b32 and its address per value.
+constexpr int kRec = 44;
+constexpr int R_E = 0, R_W = 9, R_V = 12, R_ART = 16, R_JO = 16;
 // link at position k of role r's chain (-1 past its end):  0: 1..6   1: 7..12   2: 13..22   3: 13 14 15 23..27
 // (arithmetic, not a table: a per-lane table read would be a vector memory load in every loop iteration)
 __device__ __forceinline__ int chain_link(int role, int k) {
@@ -130,14 +133,19 @@ __device__ __forceinline__ int chain_link(int role, int k) {
 constexpr int kHubPos = 2;         // chain position of the torso on the two arm lanes: the arms merge before it is processed
 
 struct QuadRec {
-    float* col;   // &s_rec[0][0][lane]
-    __device__ __forceinline__ float& operator()(int k, int f) { return col[(k * kRec + f) * 64]; }
+    float* col;   // &s_rec[0][lane][0]
+    __device__ __forceinline__ float& operator()(int k, int f) { return col[k * (kRec * 64) + f]; }
 };
+typedef float f4v __attribute__((ext_vector_type(4)));
+// whole 16-byte groups of a record
+__device__ __forceinline__ void rec_store4(QuadRec& rc, int k, int f, float a, float b, float c, float d) {
+    *reinterpret_cast<f4v*>(&rc(k, f)) = f4v{a, b, c, d};
+}
 __device__ __forceinline__ void rec_store_art(QuadRec& rc, int k, const ArtI& I) {
-    const float v[27] = {I.A.xx, I.A.yy, I.A.zz, I.A.xy, I.A.xz, I.A.yz, I.B.m[0], I.B.m[1], I.B.m[2], I.B.m[3], I.B.m[4], I.B.m[5], I.B.m[6], I.B.m[7], I.B.m[8],
-                         I.D.xx, I.D.yy, I.D.zz, I.D.xy, I.D.xz, I.D.yz, I.pn.x, I.pn.y, I.pn.z, I.pf.x, I.pf.y, I.pf.z};
+    const float v[28] = {I.A.xx, I.A.yy, I.A.zz, I.A.xy, I.A.xz, I.A.yz, I.B.m[0], I.B.m[1], I.B.m[2], I.B.m[3], I.B.m[4], I.B.m[5], I.B.m[6], I.B.m[7], I.B.m[8],
+                         I.D.xx, I.D.yy, I.D.zz, I.D.xy, I.D.xz, I.D.yz, I.pn.x, I.pn.y, I.pn.z, I.pf.x, I.pf.y, I.pf.z, 0.f};
 #pragma unroll
-    for (int t = 0; t < 27; t++) rc(k, R_ART + t) = v[t];
+    for (int t = 0; t < 28; t += 4) rec_store4(rc, k, R_ART + t, v[t], v[t + 1], v[t + 2], v[t + 3]);
 }
 __device__ __forceinline__ ArtI rec_load_art(QuadRec& rc, int k) {
     float v[27];
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
     __syncthreads();   // one wave: orders the LDS fills above against the reads below
     BaseState base;
     load_base(root, base);
-    QuadRec rc{&s_rec[lane]};
+    QuadRec rc{&s_rec[lane * kRec]};
     TA_STAMP_AT(1);
     Ball ball;
     float pre_vx_reg_out = 0.f;
@@ -317,10 +325,10 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 const LinkC L = s_link[li];   // by value: plain LDS reads into registers
                 M3 E;
                 link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, E);
-#pragma unroll
-                for (int t = 0; t < 9; t++) rc(k, R_E + t) = E.m[t];
-                rc(k, R_W) = w.x; rc(k, R_W + 1) = w.y; rc(k, R_W + 2) = w.z;
-                rc(k, R_V) = v.x; rc(k, R_V + 1) = v.y; rc(k, R_V + 2) = v.z;
+                rec_store4(rc, k, 0, E.m[0], E.m[1], E.m[2], E.m[3]);
+                rec_store4(rc, k, 4, E.m[4], E.m[5], E.m[6], E.m[7]);
+                rec_store4(rc, k, 8, E.m[8], w.x, w.y, w.z);
+                rec_store4(rc, k, 12, v.x, v.y, v.z, 0.f);
                 rec_store_art(rc, k, link_dynamics(P, L, s_cpoint, Rw, pw, w, v));
                 capture_geometry(P, L.geo_mask, Rw, pw, w, v, g[0], bound[0]);   // complete on the right-arm lane (pelvis, torso, right arm)
             }
@@ -343,9 +351,8 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
                 for (int t = 0; t < 9; t++) E.m[t] = rc(k, R_E + t);
                 inward_step(P, L, I, mk(rc(k, R_W), rc(k, R_W + 1), rc(k, R_W + 2)), mk(rc(k, R_V), rc(k, R_V + 1), rc(k, R_V + 2)), E,
                             s_q[li - 1][es], s_qd[li - 1][es], s_target[li - 1][es], jo);
-                rc(k, R_JO) = jo.ua.x; rc(k, R_JO + 1) = jo.ua.y; rc(k, R_JO + 2) = jo.ua.z;
-                rc(k, R_JO + 3) = jo.ub.x; rc(k, R_JO + 4) = jo.ub.y; rc(k, R_JO + 5) = jo.ub.z;
-                rc(k, R_JO + 6) = jo.dinv; rc(k, R_JO + 7) = jo.u;
+                rec_store4(rc, k, R_JO, jo.ua.x, jo.ua.y, jo.ua.z, jo.ub.x);
+                rec_store4(rc, k, R_JO + 4, jo.ub.y, jo.ub.z, jo.dinv, jo.u);
                 acc = I;
             }
             TA_STAMP_AT(3 + 5 * (sub & 1));
