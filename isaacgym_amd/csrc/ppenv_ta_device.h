@@ -20,13 +20,15 @@ constexpr int NL = PPENV_TA_NUM_LINKS;
 constexpr int NDOF = PPENV_TA_NUM_DOF;
 
 // ---- constants of the tree, derived once on the host (make_ta_consts) and read from global memory by the kernels
-struct LinkC {
+struct alignas(16) LinkC {                                 // 40 dwords: the quad kernel reads it from LDS in 16-byte pieces
     int32_t parent, axis, body, cfirst, ccount;            // contacts [cfirst, cfirst + ccount) sit on this link
     int32_t geo_mask, ffirst, fcount;                       // bit s: ball-collision shape s rides on this link; bit 6 paddle; bit 7 bound centre.  Welded bodies [ffirst, ffirst + fcount) of `fixed` ride on it
     float r[3], R0[9];                                      // child frame in the parent frame at q = 0
     float mass, mc[3], Io[6];                               // m, m * com, inertia about the link ORIGIN (xx yy zz xy xz yz)
     float lo, hi, kp, kd, effort, vlim, armature;
+    float pad_[3];
 };
+static_assert(sizeof(LinkC) == 160, "LinkC layout");
 struct FixedC { int32_t body, link, pad_[2]; float xyz[3], rot[9]; };
 // the scalars and small tables: ~70 dwords, small enough to travel by value in a kernel argument
 struct TAScal {
