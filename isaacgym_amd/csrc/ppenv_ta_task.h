@@ -11,8 +11,18 @@ namespace pp {
 namespace tatask {
 constexpr int TA_ND = PPENV_TA_NUM_DOF;
 constexpr int TA_NBAL = PPENV_TA_NUM_BALANCE_BODIES;
-__device__ const int kTaObsIds[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};   // bodyStatesIdPingpong, 27DOF yaml:56
-__device__ const int kTaBalIds[TA_NBAL] = {0, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 27};   // yaml:57
+constexpr int kTaObsIdTable[NB] = {0, 31, 32, 33, 34, 35, 36, 37, 38, 39};   // bodyStatesIdPingpong, 27DOF yaml:56
+constexpr int kTaBalIdTable[TA_NBAL] = {0, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 25, 26, 27};   // yaml:57
+// The two id lists as arithmetic: with the bodies split over the lanes of a quad the index is a run-time value, and a table in
+// memory made every body wait for a global load of its id before its state could be fetched.
+__host__ __device__ constexpr int ta_obs_id(int j) { return j == 0 ? 0 : 30 + j; }
+__host__ __device__ constexpr int ta_bal_id(int j) { return j + (j >= 1 ? 1 : 0) + (j >= 7 ? 1 : 0) + (j >= 16 ? 3 : 0); }
+constexpr bool ta_id_formulas_match() {
+    for (int j = 0; j < NB; j++) if (ta_obs_id(j) != kTaObsIdTable[j]) return false;
+    for (int j = 0; j < TA_NBAL; j++) if (ta_bal_id(j) != kTaBalIdTable[j]) return false;
+    return true;
+}
+static_assert(ta_id_formulas_match(), "body id lists");
 
 // sum over the NR lanes that share an env (NR = 4: the lanes of a quad, lane & 3 = role; every lane of the quad must call it)
 template <int NR>
@@ -51,8 +61,8 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
     // ---- compute_imitation_reward TA:1313-1418 (is_g1)
     float pos_acc = 0.f, vel_acc = 0.f, norm_acc = 0.f;
     for (int j = role; j < TA_NBAL; j += NR) {
-        const float* b = rb + kTaBalIds[j] * 13;
-        const float* r = irb + kTaBalIds[j] * 13;
+        const float* b = rb + ta_bal_id(j) * 13;
+        const float* r = irb + ta_bal_id(j) * 13;
         float dp0 = r[0] - b[0], dp1 = r[1] - b[1], dp2 = r[2] - b[2];
         float dv0 = r[7] - b[7], dv1 = r[8] - b[8], dv2 = r[9] - b[9];
         pos_acc += (dp0 * dp0 + dp1 * dp1 + dp2 * dp2) / 3.0f;
@@ -183,7 +193,7 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
     const V3 rootp = mk(rb[0], rb[1], rb[2]);
     if (!write) return;
     for (int j = role; j < NB; j += NR) {
-        const float* b = rb + kTaObsIds[j] * 13;
+        const float* b = rb + ta_obs_id(j) * 13;
         V3 lp = heading_rotate(hinv, mk(b[0], b[1], b[2]) - rootp);
         V3 lv = heading_rotate(hinv, mk(b[7], b[8], b[9]));
         o[3 * j] = lp.x; o[3 * j + 1] = lp.y; o[3 * j + 2] = lp.z;
@@ -199,8 +209,8 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
         o[120] = lb.y + (lv.y / (-lv.x + 1e-6f)) * lb.x;                        // TA:1839
     }
     for (int j = role; j < TA_NBAL; j += NR) {                                  // TA:1891-1927
-        const float* b = rb + kTaBalIds[j] * 13;
-        const float* r = irb + kTaBalIds[j] * 13;
+        const float* b = rb + ta_bal_id(j) * 13;
+        const float* r = irb + ta_bal_id(j) * 13;
         V3 t = heading_rotate(hinv, mk(r[0] - b[0], r[1] - b[1], r[2] - b[2]));
         V3 tv = heading_rotate(hinv, mk(r[7] - b[7], r[8] - b[8], r[9] - b[9]));
         o[121 + 3 * j] = t.x * 10.f; o[122 + 3 * j] = t.y * 10.f; o[123 + 3 * j] = t.z * 10.f;
