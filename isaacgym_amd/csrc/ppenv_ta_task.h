@@ -60,15 +60,40 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
 
     // ---- compute_imitation_reward TA:1313-1418 (is_g1)
     float pos_acc = 0.f, vel_acc = 0.f, norm_acc = 0.f;
-    for (int j = role; j < TA_NBAL; j += NR) {
-        const float* b = rb + ta_bal_id(j) * 13;
-        const float* r = irb + ta_bal_id(j) * 13;
-        float dp0 = r[0] - b[0], dp1 = r[1] - b[1], dp2 = r[2] - b[2];
-        float dv0 = r[7] - b[7], dv1 = r[8] - b[8], dv2 = r[9] - b[9];
-        pos_acc += (dp0 * dp0 + dp1 * dp1 + dp2 * dp2) / 3.0f;
-        vel_acc += (dv0 * dv0 + dv1 * dv1 + dv2 * dv2) / 3.0f;
-        float e0 = b[0] - r[0], e1 = b[1] - r[1], e2 = b[2] - r[2];
-        norm_acc += sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+    // With the bodies split over NR lanes each lane's share (initial minus current position and velocity of its <= 6 bodies) is fetched in one
+    // batch with a constant trip count and kept for the imitation observations further down: as a run-time loop every body waited for its own
+    // loads of the initial state from global memory, and did so twice.
+    constexpr int kMine = NR > 1 ? (TA_NBAL + NR - 1) / NR : 1;
+    float dpv[kMine][6];
+    if (NR > 1) {
+#pragma unroll
+        for (int t = 0; t < kMine; t++) {
+            const int j = role + t * NR;
+            const int id = ta_bal_id(j < TA_NBAL ? j : 0);
+            const float* b = rb + id * 13;
+            const float* r = irb + id * 13;
+            dpv[t][0] = r[0] - b[0]; dpv[t][1] = r[1] - b[1]; dpv[t][2] = r[2] - b[2];
+            dpv[t][3] = r[7] - b[7]; dpv[t][4] = r[8] - b[8]; dpv[t][5] = r[9] - b[9];
+        }
+#pragma unroll
+        for (int t = 0; t < kMine; t++) {
+            if (role + t * NR >= TA_NBAL) continue;
+            const float dp0 = dpv[t][0], dp1 = dpv[t][1], dp2 = dpv[t][2], dv0 = dpv[t][3], dv1 = dpv[t][4], dv2 = dpv[t][5];
+            pos_acc += (dp0 * dp0 + dp1 * dp1 + dp2 * dp2) / 3.0f;
+            vel_acc += (dv0 * dv0 + dv1 * dv1 + dv2 * dv2) / 3.0f;
+            norm_acc += sqrtf(dp0 * dp0 + dp1 * dp1 + dp2 * dp2);   // |b - r| = |r - b|, the same products
+        }
+    } else {
+        for (int j = role; j < TA_NBAL; j += NR) {
+            const float* b = rb + ta_bal_id(j) * 13;
+            const float* r = irb + ta_bal_id(j) * 13;
+            float dp0 = r[0] - b[0], dp1 = r[1] - b[1], dp2 = r[2] - b[2];
+            float dv0 = r[7] - b[7], dv1 = r[8] - b[8], dv2 = r[9] - b[9];
+            pos_acc += (dp0 * dp0 + dp1 * dp1 + dp2 * dp2) / 3.0f;
+            vel_acc += (dv0 * dv0 + dv1 * dv1 + dv2 * dv2) / 3.0f;
+            float e0 = b[0] - r[0], e1 = b[1] - r[1], e2 = b[2] - r[2];
+            norm_acc += sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        }
     }
     pos_acc = lanes_sum<NR>(pos_acc); vel_acc = lanes_sum<NR>(vel_acc); norm_acc = lanes_sum<NR>(norm_acc);
     float r_body_pos = expf(-50.f * (pos_acc / (float)TA_NBAL));                // TA:1349-1351
@@ -208,13 +233,25 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
         o[114] = lb.x; o[115] = lb.y; o[116] = lb.z; o[117] = lv.x; o[118] = lv.y; o[119] = lv.z;
         o[120] = lb.y + (lv.y / (-lv.x + 1e-6f)) * lb.x;                        // TA:1839
     }
-    for (int j = role; j < TA_NBAL; j += NR) {                                  // TA:1891-1927
-        const float* b = rb + ta_bal_id(j) * 13;
-        const float* r = irb + ta_bal_id(j) * 13;
-        V3 t = heading_rotate(hinv, mk(r[0] - b[0], r[1] - b[1], r[2] - b[2]));
-        V3 tv = heading_rotate(hinv, mk(r[7] - b[7], r[8] - b[8], r[9] - b[9]));
-        o[121 + 3 * j] = t.x * 10.f; o[122 + 3 * j] = t.y * 10.f; o[123 + 3 * j] = t.z * 10.f;
-        o[121 + 3 * TA_NBAL + 3 * j] = tv.x; o[122 + 3 * TA_NBAL + 3 * j] = tv.y; o[123 + 3 * TA_NBAL + 3 * j] = tv.z;
+    if (NR > 1) {                                                               // TA:1891-1927, from the differences kept above
+#pragma unroll
+        for (int tt = 0; tt < kMine; tt++) {
+            const int j = role + tt * NR;
+            if (j >= TA_NBAL) continue;
+            V3 t = heading_rotate(hinv, mk(dpv[tt][0], dpv[tt][1], dpv[tt][2]));
+            V3 tv = heading_rotate(hinv, mk(dpv[tt][3], dpv[tt][4], dpv[tt][5]));
+            o[121 + 3 * j] = t.x * 10.f; o[122 + 3 * j] = t.y * 10.f; o[123 + 3 * j] = t.z * 10.f;
+            o[121 + 3 * TA_NBAL + 3 * j] = tv.x; o[122 + 3 * TA_NBAL + 3 * j] = tv.y; o[123 + 3 * TA_NBAL + 3 * j] = tv.z;
+        }
+    } else {
+        for (int j = role; j < TA_NBAL; j += NR) {                              // TA:1891-1927
+            const float* b = rb + ta_bal_id(j) * 13;
+            const float* r = irb + ta_bal_id(j) * 13;
+            V3 t = heading_rotate(hinv, mk(r[0] - b[0], r[1] - b[1], r[2] - b[2]));
+            V3 tv = heading_rotate(hinv, mk(r[7] - b[7], r[8] - b[8], r[9] - b[9]));
+            o[121 + 3 * j] = t.x * 10.f; o[122 + 3 * j] = t.y * 10.f; o[123 + 3 * j] = t.z * 10.f;
+            o[121 + 3 * TA_NBAL + 3 * j] = tv.x; o[122 + 3 * TA_NBAL + 3 * j] = tv.y; o[123 + 3 * TA_NBAL + 3 * j] = tv.z;
+        }
     }
 #pragma unroll
     for (int d = 0; d < TA_ND; d++)
