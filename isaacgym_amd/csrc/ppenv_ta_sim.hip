@@ -408,6 +408,11 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         float* rb = t_rb + es * kRb;
         M3 Rw = quat_to_m3(base.quat);
         V3 pw = base.p, w = tmul(Rw, base.ww), v = tmul(Rw, base.vw);
+        float table_row[13];               // untouched by the step; fetched here so that the chain loop below hides the latency
+        if (role == 1) {
+#pragma unroll
+            for (int k = 0; k < 13; k++) table_row[k] = root[13 + k];
+        }
         if (role == 0) write_link_rows(s_fixed, s_link[0], Rw, pw, w, v, rb);
         for (int k = 0; k < kChainLen; k++) {
             const int li = chain_link(role, k);
@@ -417,6 +422,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
             link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, E);
             if (!(role == 3 && k < 3)) write_link_rows(s_fixed, L, Rw, pw, w, v, rb);
         }
+        TA_STAMP_AT(16);
         float* tr = t_root + es * kRoot;
         if (role == 0) {
             const float br[13] = {base.p.x, base.p.y, base.p.z, base.quat[0], base.quat[1], base.quat[2], base.quat[3],
@@ -424,7 +430,8 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
             for (int k = 0; k < 13; k++) tr[k] = br[k];
         }
         if (role == 1) {
-            for (int k = 0; k < 13; k++) { float t = root[13 + k]; tr[13 + k] = t; rb[40 * 13 + k] = t; }   // table row: untouched by the step
+#pragma unroll
+            for (int k = 0; k < 13; k++) { tr[13 + k] = table_row[k]; rb[40 * 13 + k] = table_row[k]; }
         }
         if (STEP && role == 3) t_pvx[es] = pre_vx_reg_out;
         if (role == 3) {                   // ball row: this lane holds the stepped ball
@@ -439,10 +446,14 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
             for (int k = 0; k < 13; k++) { tr[26 + k] = bl[k]; rb[41 * 13 + k] = bl[k]; }
         }
         if (STEP) {
-            for (int d = role; d < NDOF; d += 4) {
-                t_dofs[es * kDofs + 2 * d] = s_q[d][es];
-                t_dofs[es * kDofs + 2 * d + 1] = s_qd[d][es];
-                t_frc[es * NDOF + d] = s_force[d][es];
+#pragma unroll
+            for (int t = 0; t < (NDOF + 3) / 4; t++) {     // constant trip count: the LDS reads of all seven rounds are in flight together
+                const int d = role + 4 * t;
+                if (d < NDOF) {
+                    t_dofs[es * kDofs + 2 * d] = s_q[d][es];
+                    t_dofs[es * kDofs + 2 * d + 1] = s_qd[d][es];
+                    t_frc[es * NDOF + d] = s_force[d][es];
+                }
             }
         }
     }

@@ -35,7 +35,7 @@ t = buf.reshape(nb, 32).astype(np.int64)
 names = [(1, 0, "table copies + barrier + base load"), (2, 1, "substep 1: pass 1 (kinematics, link dynamics, contacts)"), (3, 2, "substep 1: pass 2 (articulated inertias)"),
          (4, 3, "substep 1: hub merge + base solve"), (5, 4, "substep 1: pass 3 (accelerations, integration)"), (6, 5, "substep 1: ball (one lane per quad)"),
          (7, 6, "substep 2: pass 1"), (8, 7, "substep 2: pass 2"), (9, 8, "substep 2: hub merge + base solve"), (10, 9, "substep 2: pass 3"), (11, 10, "substep 2: ball"),
-         (12, 11, "output rows into the LDS tiles (FK of the final state, quaternions)"), (13, 12, "rigid-body tile -> HBM"), (14, 13, "task arithmetic (reward, reset, 313 obs)"),
+         (16, 11, "output: FK of the final state + link rows (quaternions) into the LDS tile"), (12, 16, "output: root / table / ball rows, dof tiles"), (13, 12, "rigid-body tile -> HBM"), (14, 13, "task arithmetic (reward, reset, 313 obs)"),
          (15, 14, "obs / root / dof tiles -> HBM")]
 tot = t[:, 15] - t[:, 0]
 print(f"N={n}: workgroup span after the table copies, percentiles 0/50/90/100: " + " ".join(f"{np.percentile(tot, q):.0f}" for q in (0, 50, 90, 100)))
