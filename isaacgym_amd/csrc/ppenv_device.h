@@ -256,7 +256,7 @@ PP_HD void rot_to_quat(const M3& r, float q[4]) {
     const bool c3 = !c0 && !c1 && !c2;
     const float piv = c1 ? r.m[0] : (c2 ? r.m[4] : r.m[8]);
     const float s = sqrtf(1.0f + (c0 ? tr : 2.f * piv - tr)) * 2.f;      // 1 + m_pp - (the other two) = 1 + 2 m_pp - tr
-    const float inv = 1.0f / s, big = 0.25f * s;
+    const float inv = rcp_fast(s), big = 0.25f * s;   // v_rcp_f32: one ulp, against ten instructions for the IEEE quotient
     const float d0 = r.m[7] - r.m[5], d1 = r.m[2] - r.m[6], d2 = r.m[3] - r.m[1];
     const float a0 = r.m[1] + r.m[3], a1 = r.m[2] + r.m[6], a2 = r.m[5] + r.m[7];
     float w = c0 ? big : inv * (c1 ? d0 : (c2 ? d1 : d2));

@@ -201,8 +201,9 @@ __device__ __forceinline__ void write_row(float* row, const M3& R, V3 p, V3 lin,
 // (`fixed`: the table in LDS, sorted by link.  Scanning all twelve entries of the global table for every link cost the output section
 // 120 scalar loads, each waited for in turn.)
 __device__ __forceinline__ void write_link_rows(const FixedC* fixed, const LinkC& L, const M3& Rw, V3 pw, V3 w, V3 v, float* rb) {
-    V3 ang = mul(Rw, w);
-    write_row(rb + L.body * 13, Rw, pw, mul(Rw, v), ang);
+    const V3p la = mul(Rw, pk(v, w));        // (linear, angular) velocity in world axes
+    const V3 ang = hi(la);
+    write_row(rb + L.body * 13, Rw, pw, lo(la), ang);
     for (int f = L.ffirst; f < L.ffirst + L.fcount; f++) {
         const FixedC F = fixed[f];
         V3 p, vel;
