@@ -198,17 +198,33 @@ __device__ __forceinline__ void write_row(float* row, const M3& R, V3 p, V3 lin,
     row[7] = lin.x; row[8] = lin.y; row[9] = lin.z; row[10] = ang.x; row[11] = ang.y; row[12] = ang.z;
 }
 // rows of link `li` and of the bodies welded to it
-// (`fixed`: the table in LDS, sorted by link.  Scanning all twelve entries of the global table for every link cost the output section
-// 120 scalar loads, each waited for in turn.)
-__device__ __forceinline__ void write_link_rows(const FixedC* fixed, const LinkC& L, const M3& Rw, V3 pw, V3 w, V3 v, float* rb) {
+// The row of link L; a link that carries welded bodies also leaves its pose and twist in `pose` (20 floats per link): the welded bodies get
+// their rows afterwards, three per lane (write_welded_rows).  Done inside this loop they ran one at a time — five on the torso alone —
+// while the other lanes of the wave waited.
+constexpr int kPoseStride = 20;
+__device__ __forceinline__ void write_link_rows(float* pose, const LinkC& L, int li, const M3& Rw, V3 pw, V3 w, V3 v, float* rb) {
     const V3p la = mul(Rw, pk(v, w));        // (linear, angular) velocity in world axes
-    const V3 ang = hi(la);
-    write_row(rb + L.body * 13, Rw, pw, lo(la), ang);
-    for (int f = L.ffirst; f < L.ffirst + L.fcount; f++) {
-        const FixedC F = fixed[f];
+    write_row(rb + L.body * 13, Rw, pw, lo(la), hi(la));
+    if (L.fcount > 0) {
+        float* ps = pose + li * kPoseStride;
+#pragma unroll
+        for (int t = 0; t < 9; t++) ps[t] = Rw.m[t];
+        ps[9] = pw.x; ps[10] = pw.y; ps[11] = pw.z; ps[12] = w.x; ps[13] = w.y; ps[14] = w.z; ps[15] = v.x; ps[16] = v.y; ps[17] = v.z;
+    }
+}
+__device__ __forceinline__ void write_welded_rows(const FixedC* fixed, const float* pose, int role, float* rb) {
+    static_assert(PPENV_TA_NUM_FIXED % 4 == 0, "welded bodies are dealt out to the four lanes of a quad");
+#pragma unroll
+    for (int t = 0; t < PPENV_TA_NUM_FIXED / 4; t++) {
+        const FixedC F = fixed[role + 4 * t];
+        const float* ps = pose + F.link * kPoseStride;
+        M3 Rw;
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rw.m[k] = ps[k];
+        const V3 pw = mk(ps[9], ps[10], ps[11]), w = mk(ps[12], ps[13], ps[14]), v = mk(ps[15], ps[16], ps[17]);
         V3 p, vel;
         point_of(Rw, pw, w, v, ld3(F.xyz), p, vel);
-        write_row(rb + F.body * 13, mul(Rw, ldm(F.rot)), p, vel, ang);
+        write_row(rb + F.body * 13, mul(Rw, ldm(F.rot)), p, vel, mul(Rw, w));
     }
 }
 
@@ -404,7 +420,8 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
     float* t_frc = t_dofs + kQuadEnvs * kDofs;
     float* t_obs = t_frc + kQuadEnvs * NDOF;
     float* t_pvx = t_obs + kQuadEnvs * PPENV_TA_NUM_OBS;
-    static_assert(kQuadEnvs * (kRb + kRoot + kDofs + NDOF + PPENV_TA_NUM_OBS + 1) <= kChainLen * kRec * 64, "output tiles exceed the record area");
+    float* t_pose = t_pvx + kQuadEnvs;   // [16][NL][20]: pose and twist of the links that carry welded bodies
+    static_assert(kQuadEnvs * (kRb + kRoot + kDofs + NDOF + PPENV_TA_NUM_OBS + 1 + NL * kPoseStride) <= kChainLen * kRec * 64, "output tiles exceed the record area");
     {
         float* rb = t_rb + es * kRb;
         M3 Rw = quat_to_m3(base.quat);
@@ -414,15 +431,18 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
 #pragma unroll
             for (int k = 0; k < 13; k++) table_row[k] = root[13 + k];
         }
-        if (role == 0) write_link_rows(s_fixed, s_link[0], Rw, pw, w, v, rb);
+        float* pose = t_pose + es * (NL * kPoseStride);
+        if (role == 0) write_link_rows(pose, s_link[0], 0, Rw, pw, w, v, rb);
         for (int k = 0; k < kChainLen; k++) {
             const int li = chain_link(role, k);
             if (li < 0) continue;
             const LinkC L = s_link[li];
             M3 E;
             link_kinematics(L, s_q[li - 1][es], s_qd[li - 1][es], Rw, pw, w, v, E);
-            if (!(role == 3 && k < 3)) write_link_rows(s_fixed, L, Rw, pw, w, v, rb);
+            if (!(role == 3 && k < 3)) write_link_rows(pose, L, li, Rw, pw, w, v, rb);
         }
+        __builtin_amdgcn_wave_barrier();   // the poses above (written by other lanes of the quad) before the welded rows
+        write_welded_rows(s_fixed, pose, role, rb);
         TA_STAMP_AT(16);
         float* tr = t_root + es * kRoot;
         if (role == 0) {
