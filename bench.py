@@ -44,6 +44,8 @@ HORIZON = 32
 # 27-dof ("~2.0 KB"): R 444 + W 1596 (obs 1252)
 ALGO_BYTES = {"TT": 608, "TN": 608, "T3": 608, "T4": 1088, "TA": 2040}
 ALGO_BYTES_PER_ENV_STEP = ALGO_BYTES["TT"]
+PREWARM = 512
+ROOFLINE_WARM, ROOFLINE_LAUNCHES, ROOFLINE_REGIONS = 256, 480, 5   # multiples of HORIZON; fixed, whatever --steps is
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -139,6 +141,73 @@ def kernel_name(variant):
     return "step_kernel_split<ModelG1, 1, 0>" if split else "step_kernel<ModelG1>"
 
 
+def launch_ranks(n, argv):
+    """Start `n` rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), wait for all,
+    print rank 0's stdout (the ONE JSON line) and return the worst return code.  Runs before anything imports torch."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0's stdout is drained by a thread so that a chatty child can never block on a full pipe while we poll
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    worst = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and worst == 0:
+                worst = rc
+        if worst != 0:                      # one rank failed: the others would wait at a barrier for ever
+            for p in live:
+                p.kill()                    # exactly the processes started above
+            for p in live:
+                p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = b"".join(chunks)
+    for line in out0.decode(errors="replace").splitlines():      # the JSON line to stdout; library chatter (gloo prints there) to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+    return worst
+
+
+def rehearse(args):
+    """The rank logic of main() without an env or a GPU (gloo): rendezvous, barrier, all-reduce(MAX) of a timing, one line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    fail = os.environ.get("PPENV_BENCH_REHEARSE_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        return 3                                   # a rank that dies before the rendezvous (test of the parent's clean-up)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "max_over_ranks": float(t.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,8 +218,23 @@ def main():
     ap.add_argument("--variant", default=VARIANT, choices=["TT", "TN", "T3", "T4", "TA"],
                     help="task variant; the headline workload is TT (BASELINE.json configs[2]), the others are parity-test cases")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph of one horizon")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="CPU rehearsal of the rank plumbing only (launch, rendezvous, barrier, max-over-ranks, rank-0 line): no env is "
+                         "created and nothing is measured; used by tests/test_bench_launch.py")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm launches before the W warm-up steps")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL (default); gloo only to rehearse the rank logic on one GPU")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # `python bench.py --gpus N` as invoked: this parent touches neither torch nor the GPU; it starts one fresh child process
+        # per rank with the launcher's environment (what `python -m torch.distributed.run --nproc-per-node N` would set), relays
+        # rank 0's JSON line and exits with the worst child's return code.  (A process that has initialised the GPU must never be
+        # replaced by another program; children are started, not exec'ed.)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    if args.rehearse:
+        sys.exit(rehearse(args))
 
     import torch
     from isaacgym_amd import _lib, scene
@@ -165,13 +249,10 @@ def main():
             while not os.path.exists(_lib.LIB_PATH) and time.time() < t_end:
                 time.sleep(1.0)
     _lib.lib()   # fail loudly when the HIP extension is missing (there is no CPU path)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a torch.distributed launch with {args.gpus} ranks (see module docstring)")
-        args.gpus = world
+    args.gpus = world                          # under a launcher the world size is authoritative
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -239,6 +320,15 @@ def main():
             if (s + 1) % HORIZON == 0:
                 horizon_stats()
 
+    if not args.no_prewarm:
+        # Setup, like the graph capture above: PREWARM launches so that a short run (the driver's --steps 20 --warmup 5 is one
+        # 0.3 ms graph replay) is not a measurement of the clock ramp.  Not counted in `warmup`; the W warm-up steps follow.
+        for _ in range(PREWARM // HORIZON):
+            if graph is not None:
+                graph.replay()
+            else:
+                run(HORIZON)
+        torch.cuda.synchronize(device)
     run(args.warmup)
     torch.cuda.synchronize(device)
     if dist is not None:
@@ -260,21 +350,27 @@ def main():
         t = torch.tensor([wall], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    # roofline: average duration of step_kernel alone — a region of back-to-back launches with nothing else on
-    # the stream, bracketed by HIP events on the stream the kernel is launched on (torch's current stream)
-    kreg = min(args.steps, 480)
-    if graph is not None:
-        kreg = max(HORIZON, (kreg // HORIZON) * HORIZON)
-    ev0.record()
-    if graph is not None:
-        for _ in range(kreg // HORIZON):
-            graph.replay()
-    else:
-        for s in range(kreg):
-            env.step(pool[s & 7])
-    ev1.record()
+    # roofline: average duration of the step kernel alone — regions of back-to-back launches with nothing else on the stream,
+    # bracketed by HIP events on the stream the kernel is launched on (torch's current stream).  The region does not depend on
+    # --steps / --warmup: ROOFLINE_WARM launches to settle the clocks, then ROOFLINE_REGIONS regions of ROOFLINE_LAUNCHES
+    # launches each; the median region is reported (profiles/*_kernel_stats.csv is the same command under rocprofv3).
+    def region(k):
+        if graph is not None:
+            for _ in range(k // HORIZON):
+                graph.replay()
+        else:
+            for s in range(k):
+                env.step(pool[s & 7])
+    region(ROOFLINE_WARM)
     torch.cuda.synchronize(device)
-    kernel_us = ev0.elapsed_time(ev1) * 1e3 / kreg
+    region_us = []
+    for _ in range(ROOFLINE_REGIONS):
+        ev0.record()
+        region(ROOFLINE_LAUNCHES)
+        ev1.record()
+        torch.cuda.synchronize(device)
+        region_us.append(ev0.elapsed_time(ev1) * 1e3 / ROOFLINE_LAUNCHES)
+    kernel_us = sorted(region_us)[len(region_us) // 2]
     horizon_stats()
     if stats is not None:
         final_stats = stats.latest().cpu().tolist()
@@ -302,10 +398,12 @@ def main():
                                    "random U(-1,1) actions, 2 physics substeps per step, fused step kernel",
                        "variant": args.variant,
                        "num_envs_per_gpu": n, "global_envs": n * world, "horizon_stats_every": HORIZON,
+                       "prewarm_launches": 0 if args.no_prewarm else PREWARM,
                        "launch": "eager" if graph is None else f"HIP graph of {HORIZON} steps, replayed",
                        "parallelism": f"env-shard x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(n) if args.variant == VARIANT else None, "kernel": kernel_name(args.variant), "avg_kernel_us": kernel_us,
+                         "traffic": pmc_traffic(n) if args.variant == VARIANT else None, "kernel": kernel_name(args.variant), "avg_kernel_us": kernel_us, "region_us": region_us,
+                         "region": f"{ROOFLINE_REGIONS} x {ROOFLINE_LAUNCHES} launches after {ROOFLINE_WARM} (median)",
                          "timed_region_us_per_step": dev_ms * 1e3 / args.steps,
                          "algorithmic_bytes_per_launch": algo_bytes * n},
             "episode_stats": {"mean_reward_last_step": final_stats[0], "mean_progress": final_stats[1],
