@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PPENV_ABI_VERSION 2
+#define PPENV_ABI_VERSION 3
 
 struct ppenv; /* opaque handle */
 typedef struct ppenv ppenv;
@@ -51,6 +51,11 @@ typedef struct ppenv ppenv;
 #define PPENV_ENOMEM (-2)   /* allocation failed */
 #define PPENV_EHIP (-3)     /* a HIP runtime call failed */
 #define PPENV_ESTATE (-4)   /* blob size / version mismatch in get/set_state */
+#define PPENV_EDEVICE (-5)  /* a step kernel reported a fault (see ppenv_status): the handle's state is no longer valid */
+
+/* Bits of the per-handle device status word (ppenv_status).  Zero = healthy. */
+#define PPENV_STATUS_HANDOFF_TIMEOUT 1u  /* a wave of the multi-wave step kernel gave up waiting for its partner wave's
+                                            LDS hand-off; that workgroup's envs were NOT stored for that step */
 
 /* Task variants (reward / reset semantics). */
 enum {
@@ -247,6 +252,29 @@ int ppenv_step(struct ppenv* env, const float* actions_dev, void* stream);
  * observations (VecTask.reset()). */
 int ppenv_reset_all(struct ppenv* env, void* stream);
 
+/* reset_idx(env_ids) -> _reset_idx (TT:809-812, 847-906): the listed envs (local ids, int64 like the reference's
+ * `reset_buf.nonzero()` result, TT:1034; duplicates are harmless) go back to the initial state with the serve of their next
+ * episode (TN keeps the dof state, TN:888-901), progress 0, flags initial; every other env is untouched.  The reference
+ * leaves obs_buf alone there (compute_observations runs later in its post_physics_step); with refresh_obs != 0 the rows of
+ * the listed envs are rewritten with the observation of the reset state, so that a caller outside a step sees it. */
+int ppenv_reset_idx(struct ppenv* env, const int64_t* env_ids_dev, int32_t count, int refresh_obs, void* stream);
+
+/* pre_physics_step alone (TT:1002-1014): the PD position targets the step hands to the simulator — what the reference
+ * passes to gym.set_dof_position_target_tensor — for actions [A*N, 7] (clamped to +-clipActions first, as upstream
+ * VecTask.step does).  pd_tar_dev [A*N, 7].  The same device function the fused step uses; exists so that the mapping can
+ * be pinned to the reference's own pre_physics_step (tests/golden/pre_physics.npz). */
+int ppenv_pd_targets(struct ppenv* env, const float* actions_dev, float* pd_tar_dev, void* stream);
+
+/* generate_random_speed_for_ball of the handle's variant (TT:296-323, T3:289-305, TN:301-328, T4:299-326) on explicit draws:
+ * draws_dev [M,3] = (speed, tilt degrees, tilt_z degrees) in the reference's draw order -> vel_dev [M,3].  The same device
+ * function the reset path feeds from its counter RNG; pinned to the reference functions by tests/golden/serve_draws.npz. */
+int ppenv_serve_from_draws(struct ppenv* env, const float* draws_dev, int32_t m, float* vel_dev, void* stream);
+
+/* The handle's device status word (PPENV_STATUS_* bits), readable at any time without synchronising (it lives in pinned
+ * host memory the kernels write through).  Every entry point that touches the state checks it first and fails with
+ * PPENV_EDEVICE once it is non-zero. */
+uint32_t ppenv_status(struct ppenv* env);
+
 /* What the reference prints every 40 steps (mean reward, mean progress: TT:763-766) plus the number of
  * finished episodes, as sums over this handle's envs: out_dev[4] (f64) = { sum rew_buf, sum progress_buf,
  * sum episode, num_envs }.  One small reduction launch; the caller all-reduces it across ranks. */
@@ -403,6 +431,10 @@ typedef struct ppenv_ta_sim ppenv_ta_sim;
  * contact scalars, ball, table, net, paddle blade and the humanoid's ball-collision shapes (its 7-DoF arm tables are ignored). */
 int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, void* stream, ppenv_ta_sim** out);
 void ppenv_ta_sim_destroy(ppenv_ta_sim* sim);
+/* The GPU the handle lives on (scene->device_id at create time): every ppenv_ta_* entry selects it before launching, whatever
+ * the caller's current device is.  The stateless entries (ppenv_ta_post_physics_step, ppenv_t4_rewards) launch on the device
+ * that owns their output tensor. */
+int ppenv_ta_sim_device(const ppenv_ta_sim* sim);
 /* One pre_physics_step + gym.simulate + refresh.  actions [N,27]; root_states [N,3,13] (humanoid, table, ball) and
  * dof_states [N,27,2] are read and updated in place; rb_states [N,42,13], dof_force [N,27], pre_ball_vx [N] are written. */
 int ppenv_ta_simulate(ppenv_ta_sim* sim, int32_t num_envs, const float* actions_dev, float* root_states_dev, float* dof_states_dev,
@@ -414,6 +446,11 @@ int ppenv_ta_step(ppenv_ta_sim* sim, const ppenv_ta_params* params, const float*
                   float* root_states_dev, float* dof_states_dev, float* rb_states_dev, float* dof_force_dev, float* pre_ball_vx_dev,
                   const float* reset_override_dev, uint32_t* flags_dev, uint32_t* episode_dev, int64_t* progress_dev, float* obs_dev,
                   float* rew_dev, int64_t* reset_dev, uint32_t* scratch_any_reset_dev /* 1 word */, void* stream);
+/* pre_physics_step's PD targets alone for actions [N,27] (TA:1131 with offset / scale TA:729-733, after the clipActions
+ * clamp) and TA's generate_random_speed_for_ball (TA:346-377) on explicit draws [M,3] = (speed, tilt deg, tilt_z deg):
+ * the 27-DoF counterparts of ppenv_pd_targets / ppenv_serve_from_draws. */
+int ppenv_ta_pd_targets(ppenv_ta_sim* sim, int32_t num_envs, const float* actions_dev, float* pd_tar_dev, void* stream);
+int ppenv_ta_serve_from_draws(ppenv_ta_sim* sim, const float* draws_dev, int32_t m, float* vel_dev, void* stream);
 /* rigid-body states of the current root / dof states without stepping (initial_rb_states of TA:1152; tests) */
 int ppenv_ta_forward_kinematics(ppenv_ta_sim* sim, int32_t num_envs, const float* root_states_dev, const float* dof_states_dev,
                                 float* rb_states_dev, void* stream);

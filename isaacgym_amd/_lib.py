@@ -79,6 +79,14 @@ def lib():
     L.ppenv_step.argtypes = [vp, vp, vp]
     L.ppenv_reset_all.argtypes = [vp, vp]
     L.ppenv_reduce_stats.argtypes = [vp, vp, vp]
+    L.ppenv_reset_idx.argtypes = [vp, vp, C.c_int32, C.c_int, vp]
+    L.ppenv_pd_targets.argtypes = [vp, vp, vp, vp]
+    L.ppenv_serve_from_draws.argtypes = [vp, vp, C.c_int32, vp, vp]
+    L.ppenv_status.restype = C.c_uint32
+    L.ppenv_status.argtypes = [vp]
+    L.ppenv_ta_pd_targets.argtypes = [vp, C.c_int32, vp, vp, vp]
+    L.ppenv_ta_serve_from_draws.argtypes = [vp, vp, C.c_int32, vp, vp]
+    L.ppenv_ta_sim_device.argtypes = [vp]
     L.ppenv_post_physics_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     for name in ("ppenv_refresh_root_states", "ppenv_refresh_dof_states", "ppenv_refresh_dof_force",
                  "ppenv_refresh_rigid_body_states"):

@@ -255,12 +255,23 @@ __device__ __forceinline__ void flush_obs_cols(const float* s_obs, float* obs, i
 __device__ __forceinline__ void publish(int* flag, int value) {
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void await(int* flag, int value) {
+// Returns false when the partner never publishes (2^22 polls, ~0.2 s): the caller then reports it in the handle's status word
+// and leaves WITHOUT storing anything — stale LDS must never reach HBM as a plausible-looking state.
+__device__ __forceinline__ bool await(int* flag, int value) {
     for (int spin = 0; spin < (1 << 22); spin++) {
-        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= value) return;
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= value) return true;
         __builtin_amdgcn_s_sleep(1);
     }
+    return false;
 }
+// the status word lives in pinned host memory (ppenv::status_host): the host reads it at its next call without a synchronisation
+__device__ __forceinline__ void report_fault(uint32_t* status, uint32_t bit) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#define PP_AWAIT(flag, value)                                                                        \
+    do {                                                                                             \
+        if (!await(flag, value)) { report_fault(status, PPENV_STATUS_HANDOFF_TIMEOUT); return; }     \
+    } while (0)
 
 // the parts of an arm's collision geometry that move with it: paddle centre / normal / their rates, then end points and
 // velocities of the link-attached shapes
@@ -295,7 +306,8 @@ struct MovingGeom {
 // LDS slots; the ball wave is left with the contacts.  (Tried and dropped: separate geometry waves — five waves on four
 // SIMDs slow each other more than the hand-off saves.)
 template <class T, int A, int G>
-__global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
+__global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on,
+                                                                       uint32_t* status, int dbg_drop_handoff) {
     constexpr int kGeo = MovingGeom<T>::count();
     // Who writes dof_pos / dof_vel / dof_force.  With one humanoid the arm wave is the critical path and would sit waiting
     // for the ball wave's reset decision just to pick between q and the initial pose: the ball wave, which has both, stores
@@ -336,15 +348,13 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
                 q[d] = b.dof_pos[(size_t)(arm * ND + d) * n + i];
                 qd[d] = b.dof_vel[(size_t)(arm * ND + d) * n + i];
                 tau[d] = 0.f;
-                float a = fminf(fmaxf(actions[((size_t)i * A + arm) * ND + d], -K.clip_actions), K.clip_actions);   // VecTask.step clamp
-                const float lo = T::drive(d).lower, hi = T::drive(d).upper;
-                target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;                                     // TT:1008, 664-665
+                target[d] = pd_target(actions[((size_t)i * A + arm) * ND + d], T::drive(d).lower, T::drive(d).upper, K.clip_actions);   // VecTask.step clamp + TT:1008
             }
         }
         PP_STAMP_AT(1);
         for (int s = 0; s < substeps; s++) {
             if (G) {
-                if (s >= 2) await(&s_bflag, s - 1);     // the ball is done with the slot's previous content (substep s - 2)
+                if (s >= 2) PP_AWAIT(&s_bflag, s - 1);     // the ball is done with the slot's previous content (substep s - 2)
                 if (active) {
                     ArmGeom<T::kShapes> gg;             // world-space sweep: velocity recursion + the collision geometry of boundary s
                     GeomVisitor<T> gv(gg);
@@ -390,7 +400,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
             static_body<false>(S, bodies[0]);
             s_paddle[arm * 3 + 0][lane] = bodies[NB - 1].pos.x; s_paddle[arm * 3 + 1][lane] = bodies[NB - 1].pos.y; s_paddle[arm * 3 + 2][lane] = bodies[NB - 1].pos.z;
         }
-        publish(&s_flag[arm], substeps + 1);
+        if (!dbg_drop_handoff) publish(&s_flag[arm], substeps + 1);   // (dbg: tests force the partner's time-out path, PPENV_DEBUG_DROP_HANDOFF)
         if (active) {
             V3 bpos[NB], bvel[NB];
 #pragma unroll
@@ -402,7 +412,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         __builtin_amdgcn_wave_barrier();   // columns [0,60) of this agent's rows were written by this wave only: no rendezvous needed
         flush_obs_cols<0, 6 * NB>(s_obs, b.obs, arm * kBlock, nvalid, (size_t)base * A + arm, A, lane);
         if (kBallStoresDofs) return;       // (A = 1) the ball wave holds the final dof state and the reset decision: it stores them
-        await(&s_flag_ball, 1);            // the ball wave's reset decision
+        PP_AWAIT(&s_flag_ball, 1);         // the ball wave's reset decision
         PP_STAMP_AT(7);
         if (active) {
             const bool rst = s_reset[lane] != 0 && K.rc.variant != PPENV_VARIANT_TN;   // TN:888-901 keeps the dof state
@@ -452,10 +462,10 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     for (int s = 0; s < substeps; s++) {
         if (G) {
 #pragma unroll
-            for (int a = 0; a < A; a++) await(&s_gflag[a], s + 1);   // the geometry waves have boundary s in LDS
+            for (int a = 0; a < A; a++) PP_AWAIT(&s_gflag[a], s + 1);   // the geometry waves have boundary s in LDS
         } else if (s > 0) {
 #pragma unroll
-            for (int a = 0; a < A; a++) await(&s_flag[a], s);   // the arm waves have published boundary s
+            for (int a = 0; a < A; a++) PP_AWAIT(&s_flag[a], s);   // the arm waves have published boundary s
             if (active) {
 #pragma unroll
                 for (int a = 0; a < A; a++)
@@ -482,7 +492,7 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         PP_STAMP_AT(19 + 2 * s);
     }
 #pragma unroll
-    for (int a = 0; a < A; a++) await(&s_flag[a], substeps + 1);   // final dof state, drive torques and paddle position
+    for (int a = 0; a < A; a++) PP_AWAIT(&s_flag[a], substeps + 1);   // final dof state, drive torques and paddle position
     if (active) {
         BodyState bodies[A * NB];   // the task part reads the pelvis (row 0) and the paddle (row 9) only
         LdsRowStore stores[A];
@@ -562,6 +572,64 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const StepConsts K, DevBuf
 #pragma unroll
     for (int a = 0; a < A; a++)
         flush_obs_cols<0, PPENV_NUM_OBS>(s_obs, b.obs, a * kBlock, nvalid, (size_t)base * A + a, A, lane);
+}
+
+// reset_idx(env_ids) -> _reset_idx (TT:809-812, 847-906): one lane per listed env; everything it writes is that env's own
+// (scattered SoA elements and, with refresh_obs, its obs rows), so duplicate ids only repeat the same stores.
+template <class T, int A>
+__global__ __launch_bounds__(kBlock) void reset_idx_kernel(const StepConsts K, DevBuffers b, const long long* __restrict__ ids, int count, int refresh_obs,
+                                                           int serve_on, uint32_t* status) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= count) return;
+    const int n = K.num_envs;
+    const long long id = ids[t];
+    if (id < 0 || id >= n) return;                                         // validated on the host when the ids are host-visible; never index out of range
+    const int i = (int)id;
+    EnvStateT<A> st;
+#pragma unroll
+    for (int d = 0; d < A * ND; d++) { st.q[d] = b.dof_pos[(size_t)d * n + i]; st.qd[d] = b.dof_vel[(size_t)d * n + i]; }
+    st.episode = b.episode[i] + 1u;
+    const V3 serve = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
+                              : serve_velocity(K, (uint32_t)(K.env_id_offset + i), st.episode);
+    reset_state(K, st, serve, K.rc.variant != PPENV_VARIANT_TN);        // TN:888-901 keeps the dof state
+#pragma unroll
+    for (int d = 0; d < A * ND; d++) { b.dof_pos[(size_t)d * n + i] = st.q[d]; b.dof_vel[(size_t)d * n + i] = st.qd[d]; }
+    store_ball(b, n, i, st.ball);
+    b.episode[i] = st.episode;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        b.progress[(size_t)i * A + a] = 0;                                  // TT:902
+        b.flags[(size_t)a * n + i] = PPENV_FLAG_NO_BOUNCE;                  // TT:903-905
+        if (refresh_obs) {
+            BodyState bodies[NB];
+            bodies_of_state<T>(K.site[a], &st.q[a * ND], &st.qd[a * ND], bodies);
+            V3 bpos[NB], bvel[NB];
+#pragma unroll
+            for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
+            LdsRowStore store{b.obs + ((size_t)i * A + a) * PPENV_NUM_OBS};   // a plain row pointer here: a rare, scattered write
+            write_obs(bpos, bvel, K.site[a].hinv, &st.q[a * ND], &st.qd[a * ND], st.ball.p, st.ball.v, store);
+        }
+    }
+}
+
+// pre_physics_step alone: PD targets of [rows, 7] actions (ppenv_pd_targets) — the step kernels' own pd_target()
+template <class T>
+__global__ void pd_targets_kernel(int rows, float clip, const float* __restrict__ actions, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * ND) return;
+    const int d = t % ND;
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+        if (k == d) { lo = T::drive(k).lower; hi = T::drive(k).upper; }
+    out[t] = pd_target(actions[t], lo, hi, clip);
+}
+// generate_random_speed_for_ball on explicit draws (ppenv_serve_from_draws) — the reset path's own serve_from_draws()
+__global__ void serve_from_draws_kernel(int form, int m, const float* __restrict__ draws, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const V3 v = serve_from_draws(form, draws[3 * t], draws[3 * t + 1], draws[3 * t + 2]);
+    out[3 * t] = v.x; out[3 * t + 1] = v.y; out[3 * t + 2] = v.z;
 }
 
 // ---------------------------------------- Isaac-Gym tensor-API mode: TT:1022-1039 on caller tensors
@@ -840,6 +908,13 @@ bool validate(const ppenv_config* c) {
     if (agents_of(c) == 2 && c->substeps > kMaxSplitSubsteps) { set_err("the 4-actor variant supports at most 4 substeps"); return false; }
     if (c->substeps < 1 || c->substeps > 16 || c->ball_substeps < 1 || c->ball_substeps > 64) { set_err("substeps / ball_substeps out of range"); return false; }
     if (!(c->dt > 0.f)) { set_err("dt must be positive"); return false; }
+    {   // the serve's sines and cosines are a degree-9 / degree-8 series (sincos_small): fp32-exact up to ~1 rad, not beyond
+        const float lim = 57.0f;
+        if (fabsf(c->serve_tilt_lo_deg) > lim || fabsf(c->serve_tilt_hi_deg) > lim || fabsf(c->serve_tilt_z_lo_deg) > lim || fabsf(c->serve_tilt_z_hi_deg) > lim) {
+            set_err("serve tilt angles must lie within +-57 degrees (the kernel's small-angle sine / cosine series)");
+            return false;
+        }
+    }
     if (!model_matches<ModelG1>(*c)) {
         set_err("chain topology (joint axes / shape links / observed-body frames) has no compiled kernel instantiation; "
                 "this build ships the Unitree G1 right-arm chain (ppenv_device.h ModelG1)");
@@ -864,6 +939,9 @@ struct ppenv {
     int serve_on;
     int split;               // 1: step_kernel_split (two waves per 64 envs; three for the 4-actor variant), 2: 4-actor with the arm waves sweeping the geometry, 0: step_kernel
     int agents;              // 1, or 2 for PPENV_VARIANT_T4
+    uint32_t* status_host;   // PPENV_STATUS_* bits, pinned host memory mapped into the device: kernels write it through, the host reads it without a sync
+    uint32_t* status_dev;
+    int dbg_drop_handoff;    // PPENV_DEBUG_DROP_HANDOFF=1 at create (tests): the arm wave withholds its last hand-off, so the partner waves time out
 };
 
 namespace {
@@ -872,6 +950,16 @@ int use_device(const ppenv* e) {
     PP_HIP(hipGetDevice(&cur));
     if (cur != e->cfg.device_id) PP_HIP(hipSetDevice(e->cfg.device_id));
     return PPENV_OK;
+}
+// every entry point that reads or advances the state: refuse to go on once a kernel has reported a fault
+int check_status(const ppenv* e) {
+    const uint32_t st = *(volatile uint32_t*)e->status_host;
+    if (st == 0) return PPENV_OK;
+    char msg[200];
+    snprintf(msg, sizeof msg, "device status 0x%x: %s; the environment state is no longer valid (destroy the handle)", st,
+             (st & PPENV_STATUS_HANDOFF_TIMEOUT) ? "a step-kernel wave timed out waiting for its partner wave's LDS hand-off and did not store its envs" : "unknown fault");
+    set_err("%s", msg);
+    return PPENV_EDEVICE;
 }
 }  // namespace
 
@@ -908,16 +996,30 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
     }
     e->arena = nullptr;
     e->owns_arena = false;
+    e->status_host = e->status_dev = nullptr;
+    {
+        const char* d = getenv("PPENV_DEBUG_DROP_HANDOFF");
+        e->dbg_drop_handoff = (d && d[0] == '1') ? 1 : 0;
+    }
     if (hipSetDevice(cfg->device_id) != hipSuccess) { delete e; set_err("hipSetDevice failed"); return PPENV_EHIP; }
+    if (hipHostMalloc((void**)&e->status_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&e->status_dev, e->status_host, 0) != hipSuccess) {
+        if (e->status_host) (void)hipHostFree(e->status_host);
+        delete e;
+        set_err("allocating the device status word failed");
+        return PPENV_ENOMEM;
+    }
+    *e->status_host = 0u;
     if (arena_dev) {
         if (arena_bytes < e->lay.total || ((uintptr_t)arena_dev & 255u)) {
+            (void)hipHostFree(e->status_host);
             delete e;
             set_err("arena too small or not 256-byte aligned");
             return PPENV_EINVAL;
         }
         e->arena = arena_dev;
     } else {
-        if (hipMalloc(&e->arena, e->lay.total) != hipSuccess) { delete e; set_err("hipMalloc of the env arena failed"); return PPENV_ENOMEM; }
+        if (hipMalloc(&e->arena, e->lay.total) != hipSuccess) { (void)hipHostFree(e->status_host); delete e; set_err("hipMalloc of the env arena failed"); return PPENV_ENOMEM; }
         e->owns_arena = true;
     }
     char* a = (char*)e->arena;
@@ -936,6 +1038,7 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
     if (err != hipSuccess) {
         set_err("initialising the env state failed: %s", hipGetErrorString(err));
         if (e->owns_arena) (void)hipFree(e->arena);
+        (void)hipHostFree(e->status_host);
         delete e;
         return PPENV_EHIP;
     }
@@ -945,10 +1048,9 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
 
 void ppenv_destroy(ppenv* e) {
     if (!e) return;
-    if (e->owns_arena && e->arena) {
-        (void)hipSetDevice(e->cfg.device_id);
-        (void)hipFree(e->arena);
-    }
+    (void)hipSetDevice(e->cfg.device_id);
+    if (e->owns_arena && e->arena) (void)hipFree(e->arena);
+    if (e->status_host) (void)hipHostFree(e->status_host);
     delete e;
 }
 
@@ -971,16 +1073,17 @@ int ppenv_config_of(ppenv* e, ppenv_config* out) {
 
 int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = check_status(e)) return rc;
     if (int rc = use_device(e)) return rc;
     if (e->agents == 2 && e->split == 2)
         hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
-                           actions_dev, e->serve_on);
+                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->agents == 2)
         hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
-                           actions_dev, e->serve_on);
+                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->split)
         hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
-                           actions_dev, e->serve_on);
+                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else
         hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
                            e->serve_on);
@@ -990,6 +1093,7 @@ int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
 
 int ppenv_reset_all(ppenv* e, void* stream) {
     if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = check_status(e)) return rc;
     if (int rc = use_device(e)) return rc;
     if (e->agents == 2) hipLaunchKernelGGL((init_kernel<ModelG1, 2>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, 1, e->serve_on);
     else hipLaunchKernelGGL((init_kernel<ModelG1, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, 1, e->serve_on);
@@ -997,8 +1101,42 @@ int ppenv_reset_all(ppenv* e, void* stream) {
     return PPENV_OK;
 }
 
+uint32_t ppenv_status(ppenv* e) { return e ? *(volatile uint32_t*)e->status_host : 0u; }
+
+int ppenv_reset_idx(ppenv* e, const int64_t* env_ids_dev, int32_t count, int refresh_obs, void* stream) {
+    if (!e || (count > 0 && !env_ids_dev) || count < 0) { set_err("ppenv_reset_idx: NULL ids or negative count"); return PPENV_EINVAL; }
+    if (count == 0) return PPENV_OK;
+    if (int rc = check_status(e)) return rc;
+    if (int rc = use_device(e)) return rc;
+    const dim3 grid((count + kBlock - 1) / kBlock), block(kBlock);
+    if (e->agents == 2)
+        hipLaunchKernelGGL((reset_idx_kernel<ModelG1, 2>), grid, block, 0, (hipStream_t)stream, e->K, e->buf, (const long long*)env_ids_dev, count, refresh_obs, e->serve_on, e->status_dev);
+    else
+        hipLaunchKernelGGL((reset_idx_kernel<ModelG1, 1>), grid, block, 0, (hipStream_t)stream, e->K, e->buf, (const long long*)env_ids_dev, count, refresh_obs, e->serve_on, e->status_dev);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+
+int ppenv_pd_targets(ppenv* e, const float* actions_dev, float* pd_tar_dev, void* stream) {
+    if (!e || !actions_dev || !pd_tar_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    const int rows = e->cfg.num_envs * e->agents;
+    hipLaunchKernelGGL(pd_targets_kernel<ModelG1>, dim3((rows * ND + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, e->K.clip_actions, actions_dev, pd_tar_dev);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+
+int ppenv_serve_from_draws(ppenv* e, const float* draws_dev, int32_t m, float* vel_dev, void* stream) {
+    if (!e || !draws_dev || !vel_dev || m <= 0) { set_err("NULL argument or m <= 0"); return PPENV_EINVAL; }
+    if (int rc = use_device(e)) return rc;
+    hipLaunchKernelGGL(serve_from_draws_kernel, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->cfg.variant, m, draws_dev, vel_dev);
+    PP_HIP(hipGetLastError());
+    return PPENV_OK;
+}
+
 int ppenv_reduce_stats(ppenv* e, double* out_dev, void* stream) {
     if (!e || !out_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (int rc = check_status(e)) return rc;
     if (int rc = use_device(e)) return rc;
     const int rows = e->cfg.num_envs * e->agents;   // one row per agent: out[3] counts agents
     if (rows <= 32768) {
@@ -1021,6 +1159,7 @@ int ppenv_post_physics_step(ppenv* e, const float* rigid_body_states_dev, float*
         return PPENV_EINVAL;
     }
     if (e->agents != 1) { set_err("ppenv_post_physics_step serves the 3-actor variants; the 4-actor entry is ppenv_t4_rewards"); return PPENV_EINVAL; }
+    if (int rc = check_status(e)) return rc;
     if (int rc = use_device(e)) return rc;
     hipLaunchKernelGGL(post_physics_kernel, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf,
                        rigid_body_states_dev, root_states_dev, dof_states_dev, dof_force_dev, pre_ball_vx_dev, e->serve_on);
@@ -1088,6 +1227,7 @@ static int state_io(ppenv* e, char* blob, size_t nbytes, bool to_host) {
     if (nbytes != ppenv_state_bytes(e)) { set_err("state blob size does not match this handle"); return PPENV_ESTATE; }
     if (int rc = use_device(e)) return rc;
     PP_HIP(hipDeviceSynchronize());
+    if (int rc = check_status(e)) return rc;       // after the synchronisation: a fault of the step still in flight is seen here
     const size_t n = (size_t)e->cfg.num_envs, A = (size_t)e->agents;
     struct Part { void* dev; size_t bytes; };
     const Part parts[] = {{e->buf.dof_pos, n * A * ND * 4}, {e->buf.dof_vel, n * A * ND * 4}, {e->buf.dof_force, n * A * ND * 4}, {e->buf.ball, n * 13 * 4},

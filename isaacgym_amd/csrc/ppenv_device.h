@@ -298,21 +298,33 @@ PP_HD void sincos_small(float x, float& s, float& c) {
     s = x * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f)))));
     c = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f + x2 * (1.f / 40320.f))));
 }
-// generate_random_speed_for_ball: TT:296-323 / T3:289-305 / TN:301-328
-PP_HD V3 serve_velocity(const StepConsts& K, uint32_t gid, uint32_t episode) {   // T4:299-326 = TT's
+// generate_random_speed_for_ball from its three draws (speed, tilt and tilt_z in degrees, in the reference's draw order):
+// T3:289-305, TT:296-323 (sic: the y component multiplies two sines and z has no tilt_z), TN:301-328, T4:299-326 = TT's,
+// TA:346-377 = TN's form.  `form` is a PPENV_VARIANT_* value (TA passes PPENV_VARIANT_TN).
+// Pinned to the reference functions by tests/golden/serve_draws.npz.
+PP_HD V3 serve_from_draws(int form, float speed, float tilt_deg, float tilt_z_deg) {
     const float deg = 0.017453292519943295f;
+    float sa, ca, sz, cz;
+    sincos_small(tilt_deg * deg, sa, ca);
+    sincos_small(tilt_z_deg * deg, sz, cz);
+    if (form == PPENV_VARIANT_T3) return mk(-speed * ca, -speed * sa, 0.f);                                             // T3:296-300
+    if (form == PPENV_VARIANT_TT || form == PPENV_VARIANT_T4) return mk(-speed * ca * cz, -speed * sa * sz, -speed * sa); // TT:307-318 (sic)
+    return mk(-speed * ca * cz, speed * sa * cz, speed * sz);                                                           // TN:312-323
+}
+PP_HD V3 serve_velocity(const StepConsts& K, uint32_t gid, uint32_t episode) {
     float u0 = rng_uniform(K.seed, gid, episode, 0);
     float u1 = rng_uniform(K.seed, gid, episode, 1);
     float u2 = rng_uniform(K.seed, gid, episode, 2);
     float speed = K.serve_speed_lo + (K.serve_speed_hi - K.serve_speed_lo) * u0;
-    float a = (K.serve_tilt_lo_deg + (K.serve_tilt_hi_deg - K.serve_tilt_lo_deg) * u1) * deg;
-    float az = (K.serve_tilt_z_lo_deg + (K.serve_tilt_z_hi_deg - K.serve_tilt_z_lo_deg) * u2) * deg;
-    float sa, ca, sz, cz;
-    sincos_small(a, sa, ca);
-    sincos_small(az, sz, cz);
-    if (K.rc.variant == PPENV_VARIANT_T3) return mk(-speed * ca, -speed * sa, 0.f);                 // T3:296-300
-    if (K.rc.variant == PPENV_VARIANT_TT || K.rc.variant == PPENV_VARIANT_T4) return mk(-speed * ca * cz, -speed * sa * sz, -speed * sa); // TT:307-318 (sic)
-    return mk(-speed * ca * cz, speed * sa * cz, speed * sz);                                     // TN:312-323
+    float a = K.serve_tilt_lo_deg + (K.serve_tilt_hi_deg - K.serve_tilt_lo_deg) * u1;
+    float az = K.serve_tilt_z_lo_deg + (K.serve_tilt_z_hi_deg - K.serve_tilt_z_lo_deg) * u2;
+    return serve_from_draws(K.rc.variant, speed, a, az);
+}
+// pre_physics_step's action -> PD target (TT:1008 with offset / scale = (hi +- lo) / 2, TT:664-665; TA:1131, 729-733), after
+// upstream VecTask.step's clamp to +-clipActions.  Pinned to the reference's pre_physics_step by tests/golden/pre_physics.npz.
+PP_HD float pd_target(float action, float lo, float hi, float clip) {
+    const float a = fminf(fmaxf(action, -clip), clip);
+    return 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;
 }
 
 // Per-joint constant groups of the compiled model: kinematics, PD drive, inertial.
@@ -914,10 +926,7 @@ PP_HD void simulate_env(const StepConsts& K, const float* actions, EnvStateT<A>&
     float target[A * ND];
 #pragma unroll
     for (int d = 0; d < A * ND; d++) {   // VecTask.step clamp + TT:1008 (offset/scale TT:664-665)
-        const float clip = K.clip_actions;
-        float a = fminf(fmaxf(actions[d], -clip), clip);
-        const float lo = T::drive(d % ND).lower, hi = T::drive(d % ND).upper;
-        target[d] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;
+        target[d] = pd_target(actions[d], T::drive(d % ND).lower, T::drive(d % ND).upper, K.clip_actions);
     }
     pre_vx = st.ball.v.x;   // TT:1020
     const int substeps = K.substeps;

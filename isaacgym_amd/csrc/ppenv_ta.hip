@@ -87,6 +87,22 @@ __global__ __launch_bounds__(kTaBlock) void t4_rewards_kernel(const ppenv_t4_par
 
 void ppenv_set_error(const char* msg);   // ppenv.hip
 
+namespace {
+// The stateless entries have no handle to remember a device: they launch on the device that owns their output tensor, whatever the
+// caller's current device is (a rank that never called hipSetDevice would otherwise launch on device 0 with another device's pointers).
+int use_device_of(const void* dev_ptr) {
+    hipPointerAttribute_t at;
+    int cur = -1;
+    if (hipPointerGetAttributes(&at, dev_ptr) != hipSuccess || hipGetDevice(&cur) != hipSuccess) {
+        (void)hipGetLastError();
+        ppenv_set_error("could not determine the device of the output tensor (is it a device pointer?)");
+        return PPENV_EINVAL;
+    }
+    if (at.device != cur && hipSetDevice(at.device) != hipSuccess) { ppenv_set_error("hipSetDevice to the output tensor's device failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
+}  // namespace
+
 // TA:1162-1166 as a launch of its own (also used by the fused step of ppenv_ta_sim.hip); not part of the public ABI
 int ppenv_ta_clear_counts(int n, uint32_t* flags_dev, uint32_t* any_reset_dev, void* stream) {
     hipLaunchKernelGGL(ta_clear_counts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, flags_dev, any_reset_dev);
@@ -105,6 +121,7 @@ extern "C" int ppenv_t4_rewards(const ppenv_t4_params* params, const float* rb_s
         return PPENV_EINVAL;
     }
     const int n = params->num_envs;
+    if (int rc = use_device_of(rew1_dev)) return rc;
     hipLaunchKernelGGL(t4_rewards_kernel, dim3((n + kTaBlock - 1) / kTaBlock), dim3(kTaBlock), 0, (hipStream_t)stream, *params, rb_states_dev,
                        root_states_dev, dof_states_dev, dof_force_dev, pre_ball_vx_dev, (const long long*)progress_dev, flags1_in_dev, flags2_in_dev, flags1_dev, flags2_dev,
                        rew1_dev, rew2_dev, (long long*)reset1_dev, (long long*)reset2_dev);
@@ -125,6 +142,7 @@ extern "C" int ppenv_ta_post_physics_step(const ppenv_ta_params* params, const f
     }
     hipStream_t s = (hipStream_t)stream;
     const int n = params->num_envs;
+    if (int rc = use_device_of(obs_dev)) return rc;
     hipLaunchKernelGGL(ta_post_physics_kernel, dim3((n + kTaBlock - 1) / kTaBlock), dim3(kTaBlock), 0, s, *params, rb_states_dev,
                        initial_rb_states_dev, root_states_dev, dof_states_dev, dof_force_dev, pre_ball_vx_dev, reset_override_dev, flags_dev,
                        episode_dev, (long long*)progress_dev, obs_dev, rew_dev, (long long*)reset_dev, scratch_any_reset_dev);

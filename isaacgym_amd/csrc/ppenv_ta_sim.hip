@@ -76,8 +76,7 @@ __global__ __launch_bounds__(kTaLanes) void ta_sim_kernel(const TAConsts* __rest
     if (STEP) {
         for (int d = 0; d < NDOF; d++) {   // VecTask.step clamp + TA:1131 (offset / scale TA:729-733)
             const LinkC& L = C.link[d + 1];
-            float a = fminf(fmaxf(actions[(size_t)e * NDOF + d], -C.sc.clip_actions), C.sc.clip_actions);
-            st(DOF_BASE + d * DOF_STRIDE + G_TARGET) = 0.5f * (L.hi + L.lo) + 0.5f * (L.hi - L.lo) * a;
+            st(DOF_BASE + d * DOF_STRIDE + G_TARGET) = pd_target(actions[(size_t)e * NDOF + d], L.lo, L.hi, C.sc.clip_actions);
             st(DOF_BASE + d * DOF_STRIDE + G_FORCE) = 0.f;
         }
         float* bl = root + 26;
@@ -303,9 +302,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         s_q[d][es] = dofs[2 * d];
         s_qd[d][es] = dofs[2 * d + 1];
         if (STEP) {
-            float a = fminf(fmaxf(actions[(size_t)(live ? e : 0) * NDOF + d], -P.clip_actions), P.clip_actions);   // VecTask.step clamp
-            const float lo = C.link[d + 1].lo, hi = C.link[d + 1].hi;
-            s_target[d][es] = 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;                                            // TA:1131, 729-733
+            s_target[d][es] = pd_target(actions[(size_t)(live ? e : 0) * NDOF + d], C.link[d + 1].lo, C.link[d + 1].hi, P.clip_actions);   // VecTask.step clamp + TA:1131, 729-733
             s_force[d][es] = 0.f;
         }
     }
@@ -505,6 +502,20 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
     TA_STAMP_AT(15);
 }
 
+// pre_physics_step alone (ppenv_ta_pd_targets) and TA's serve on explicit draws (ppenv_ta_serve_from_draws): the step's own device functions
+__global__ void ta_pd_targets_kernel(const TAConsts* __restrict__ Cp, int n, const float* __restrict__ actions, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * NDOF) return;
+    const LinkC& L = Cp->link[t % NDOF + 1];
+    out[t] = pd_target(actions[t], L.lo, L.hi, Cp->sc.clip_actions);
+}
+__global__ void ta_serve_from_draws_kernel(int m, const float* __restrict__ draws, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const V3 v = serve_from_draws(PPENV_VARIANT_TN, draws[3 * t], draws[3 * t + 1], draws[3 * t + 2]);   // TA:370-375 is TN's form
+    out[3 * t] = v.x; out[3 * t + 1] = v.y; out[3 * t + 2] = v.z;
+}
+
 // does the model have the tree the quad kernel's chains are written for?
 bool quad_topology(const TAConsts& C) {
     static const int parents[NL] = {-1, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10, 11, 0, 13, 14, 15, 16, 17, 18, 19, 20, 21, 15, 23, 24, 25, 26};
@@ -523,7 +534,21 @@ struct ppenv_ta_sim {
     int quad;     // 1: ta_sim_quad_kernel (four lanes per env), 0: ta_sim_kernel (one lane per env; any tree)
 };
 
+namespace {
+// every entry point launches on the device the handle was created on, whatever the caller's current device is
+int ta_use_device(const ppenv_ta_sim* s) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || (cur != s->device && hipSetDevice(s->device) != hipSuccess)) {
+        ppenv_set_error("selecting the 27-dof handle's device failed");
+        return PPENV_EHIP;
+    }
+    return PPENV_OK;
+}
+}  // namespace
+
 extern "C" {
+
+int ppenv_ta_sim_device(const ppenv_ta_sim* s) { return s ? s->device : -1; }
 
 #if defined(TA_STAMP)
 int ppenv_ta_debug_read_stamps(unsigned long long* dst, size_t count) {
@@ -553,7 +578,11 @@ int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, 
         const char* k = getenv("PPENV_TA_KERNEL");
         s->quad = quad_topology(s->host) && !(k && strcmp(k, "lane") == 0);
     }
-    if (hipGetDevice(&s->device) != hipSuccess || hipMalloc((void**)&s->dev, sizeof(TAConsts)) != hipSuccess ||
+    // the handle lives on scene->device_id when that names a visible GPU (the caller's current device otherwise)
+    int ndev = 0;
+    s->device = -1;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && scene->device_id >= 0 && scene->device_id < ndev && hipSetDevice(scene->device_id) == hipSuccess) s->device = scene->device_id;
+    if ((s->device < 0 && hipGetDevice(&s->device) != hipSuccess) || hipMalloc((void**)&s->dev, sizeof(TAConsts)) != hipSuccess ||
         hipMalloc((void**)&s->devK, sizeof(StepConsts)) != hipSuccess) {
         ppenv_set_error("ppenv_ta_sim_create: hipMalloc of the model constants failed");
         if (s->dev) (void)hipFree(s->dev);
@@ -575,6 +604,7 @@ int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, 
 
 void ppenv_ta_sim_destroy(ppenv_ta_sim* s) {
     if (!s) return;
+    (void)ta_use_device(s);
     if (s->dev) (void)hipFree(s->dev);
     if (s->devK) (void)hipFree(s->devK);
     delete s;
@@ -586,6 +616,7 @@ int ppenv_ta_simulate(ppenv_ta_sim* s, int32_t n, const float* actions_dev, floa
         ppenv_set_error("ppenv_ta_simulate: NULL argument or num_envs <= 0");
         return PPENV_EINVAL;
     }
+    if (int rc = ta_use_device(s)) return rc;
     if (s->quad)
         hipLaunchKernelGGL((ta_sim_quad_kernel<true, false>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->devK, n, actions_dev,
                            root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev, TaskArgs{});
@@ -606,6 +637,7 @@ int ppenv_ta_step(ppenv_ta_sim* s, const ppenv_ta_params* params, const float* a
         return PPENV_EINVAL;
     }
     const int n = params->num_envs;
+    if (int rc = ta_use_device(s)) return rc;
     if (!s->quad) {   // another tree, or PPENV_TA_KERNEL=lane: the two launches
         int rc = ppenv_ta_simulate(s, n, actions_dev, root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev, stream);
         if (rc) return rc;
@@ -621,12 +653,29 @@ int ppenv_ta_step(ppenv_ta_sim* s, const ppenv_ta_params* params, const float* a
     return ppenv_ta_clear_counts(n, flags_dev, scratch_any_reset_dev, stream);
 }
 
+int ppenv_ta_pd_targets(ppenv_ta_sim* s, int32_t n, const float* actions_dev, float* pd_tar_dev, void* stream) {
+    if (!s || n <= 0 || !actions_dev || !pd_tar_dev) { ppenv_set_error("ppenv_ta_pd_targets: NULL argument or num_envs <= 0"); return PPENV_EINVAL; }
+    if (int rc = ta_use_device(s)) return rc;
+    hipLaunchKernelGGL(ta_pd_targets_kernel, dim3((n * NDOF + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->dev, n, actions_dev, pd_tar_dev);
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching ta_pd_targets_kernel failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
+
+int ppenv_ta_serve_from_draws(ppenv_ta_sim* s, const float* draws_dev, int32_t m, float* vel_dev, void* stream) {
+    if (!s || m <= 0 || !draws_dev || !vel_dev) { ppenv_set_error("ppenv_ta_serve_from_draws: NULL argument or m <= 0"); return PPENV_EINVAL; }
+    if (int rc = ta_use_device(s)) return rc;
+    hipLaunchKernelGGL(ta_serve_from_draws_kernel, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, draws_dev, vel_dev);
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching ta_serve_from_draws_kernel failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
+
 int ppenv_ta_forward_kinematics(ppenv_ta_sim* s, int32_t n, const float* root_states_dev, const float* dof_states_dev, float* rb_states_dev,
                                 void* stream) {
     if (!s || n <= 0 || !root_states_dev || !dof_states_dev || !rb_states_dev) {
         ppenv_set_error("ppenv_ta_forward_kinematics: NULL argument or num_envs <= 0");
         return PPENV_EINVAL;
     }
+    if (int rc = ta_use_device(s)) return rc;
     if (s->quad)
         hipLaunchKernelGGL((ta_sim_quad_kernel<false, false>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->devK, n,
                            (const float*)nullptr, const_cast<float*>(root_states_dev), const_cast<float*>(dof_states_dev), rb_states_dev,

@@ -175,16 +175,13 @@ __device__ __forceinline__ void ta_task_env(const ppenv_ta_params& p, int i, con
                 uint64_t x = mix64(s + 0x9E3779B97F4A7C15ull * ((uint64_t)ep * 8 + k + 1));
                 u[k] = (float)(x >> 40) * (1.0f / 16777216.0f);
             }
-            const float deg = 0.017453292519943295f;
             ov[0] = p.ball_y_lo + (p.ball_y_hi - p.ball_y_lo) * u[0];           // draw order TA:976-979: y, z, speed, tilt, tilt_z
             ov[1] = p.ball_z_lo + (p.ball_z_hi - p.ball_z_lo) * u[1];
-            float speed = p.serve_speed_lo + (p.serve_speed_hi - p.serve_speed_lo) * u[2];
-            float a = (p.serve_tilt_lo_deg + (p.serve_tilt_hi_deg - p.serve_tilt_lo_deg) * u[3]) * deg;
-            float az = (p.serve_tilt_z_lo_deg + (p.serve_tilt_z_hi_deg - p.serve_tilt_z_lo_deg) * u[4]) * deg;
-            float sa, ca, sz, cz;
-            sincos_small(a, sa, ca);
-            sincos_small(az, sz, cz);
-            ov[2] = -speed * ca * cz; ov[3] = speed * sa * cz; ov[4] = speed * sz;   // TA:370-375
+            const float speed = p.serve_speed_lo + (p.serve_speed_hi - p.serve_speed_lo) * u[2];
+            const float a = p.serve_tilt_lo_deg + (p.serve_tilt_hi_deg - p.serve_tilt_lo_deg) * u[3];
+            const float az = p.serve_tilt_z_lo_deg + (p.serve_tilt_z_hi_deg - p.serve_tilt_z_lo_deg) * u[4];
+            const V3 sv = serve_from_draws(PPENV_VARIANT_TN, speed, a, az);      // TA:370-375 is TN's form
+            ov[2] = sv.x; ov[3] = sv.y; ov[4] = sv.z;
         }
 #pragma unroll
         for (int k = 0; k < 7; k++) bs[k] = p.init_root[2][k];

@@ -80,6 +80,37 @@ class PPEnv:
     def reset_all(self):
         _lib.check(self.L.ppenv_reset_all(self.h, self._stream()))
 
+    def reset_idx(self, env_ids, refresh_obs=True):
+        """reset_idx(env_ids) -> _reset_idx (TT:809-812, 847-906) for the listed local env ids only (int64 tensor / sequence)."""
+        ids = torch.as_tensor(env_ids, dtype=torch.int64).reshape(-1)
+        if ids.numel() == 0:
+            return
+        if ids.device.type != "cuda":        # host-visible ids are validated here; device ids are range-checked by the kernel
+            if int(ids.min()) < 0 or int(ids.max()) >= self.num_envs:
+                raise IndexError(f"env id outside [0, {self.num_envs})")
+        ids = ids.to(self.device).contiguous()
+        _lib.check(self.L.ppenv_reset_idx(self.h, ids.data_ptr(), ids.numel(), int(bool(refresh_obs)), self._stream()))
+        ids.record_stream(torch.cuda.current_stream(self.device))   # the kernel reads `ids` after this frame is gone
+
+    def pd_targets(self, actions):
+        """pre_physics_step's PD targets (TT:1008-1014) for actions [A*N, 7]: what set_dof_position_target_tensor receives."""
+        a = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_rows, scene.NUM_DOF).contiguous()
+        out = torch.empty_like(a)
+        _lib.check(self.L.ppenv_pd_targets(self.h, a.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def serve_from_draws(self, draws):
+        """generate_random_speed_for_ball of this variant on [M,3] draws (speed, tilt deg, tilt_z deg) -> [M,3] velocities."""
+        d = torch.as_tensor(draws, dtype=torch.float32).to(self.device).reshape(-1, 3).contiguous()
+        out = torch.empty_like(d)
+        _lib.check(self.L.ppenv_serve_from_draws(self.h, d.data_ptr(), d.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    @property
+    def status(self):
+        """PPENV_STATUS_* bits reported by the kernels (0 = healthy); read without synchronising."""
+        return int(self.L.ppenv_status(self.h))
+
     def reduce_stats(self, out=None):
         """float64[4] on the device: sum rew_buf, sum progress_buf, sum episode, num_envs (one reduction launch)."""
         if out is None:

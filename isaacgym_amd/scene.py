@@ -25,12 +25,17 @@ NUM_BODIES = 42
 NUM_HUMANOID_BODIES = 40
 NUM_ACTORS = 3
 MAX_SHAPES = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
+STATUS_HANDOFF_TIMEOUT = 1       # include/ppenv.h PPENV_STATUS_*
+SERVE_ANGLE_LIMIT_DEG = 57.0   # csrc/ppenv_device.h sincos_small; ppenv_create refuses wider ranges too
 
 VARIANT_T3, VARIANT_TT, VARIANT_TN, VARIANT_T4 = 0, 1, 2, 3
 VARIANT_IDS = {"T3": VARIANT_T3, "TT": VARIANT_TT, "TN": VARIANT_TN, "T4": VARIANT_T4}
 
 FLAG_REWARD_CALC, FLAG_COND_CALC, FLAG_NO_BOUNCE, FLAG_MISSED_CALC = 1, 2, 4, 8
+# 27-dof task (include/ppenv.h PPENV_TA_*): sticky flags TA:279-286, diagnostic count flags TA:289-293
+TA_FLAG_PADDLE_COND, TA_FLAG_HIT_TABLE_CALC, TA_FLAG_DIE_PENALTY_CALC, TA_FLAG_HUMANOID_DIE_CALC = 1, 2, 4, 8
+TA_COUNT_MASK = 0x1F0
 
 # reference task name (tasks/__init__.py:49-53,118-120) -> variant tag
 TASK_VARIANTS = {
@@ -498,6 +503,9 @@ def build_config(variant, cfg=None, num_envs=None, seed=0, device_id=0, env_id_o
     c.serve_speed_lo, c.serve_speed_hi = scene["serve_speed"]
     c.serve_tilt_lo_deg, c.serve_tilt_hi_deg = scene["serve_tilt"]
     c.serve_tilt_z_lo_deg, c.serve_tilt_z_hi_deg = scene["serve_tilt_z"]
+    for name in ("serve_tilt", "serve_tilt_z"):   # the kernels' sine / cosine of a serve angle is a short series, fp32-exact up to ~1 rad
+        if max(abs(float(v)) for v in scene[name]) > SERVE_ANGLE_LIMIT_DEG:
+            raise ValueError(f"scene.{name} = {tuple(scene[name])}: serve angles must lie within +-{SERVE_ANGLE_LIMIT_DEG} degrees")
 
     c.max_episode_length = int(env["episodeLength"])
     c.alpha_velocity_reward = env["alphaVelocityReward"]

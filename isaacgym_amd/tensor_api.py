@@ -39,6 +39,7 @@ class TAState:
         if reset_override is not None:
             ov = reset_override.to(self.device, torch.float32).reshape(n, 5).contiguous()
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        # (the library launches on the device that owns obs_buf, whatever the caller's current device is)
         _lib.check(self.L.ppenv_ta_post_physics_step(
             C.byref(self.params), rb_states.data_ptr(), initial_rb_states.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(),
             dof_force.data_ptr(), pre_ball_vx.data_ptr(), ov.data_ptr() if ov is not None else None, self.flags.data_ptr(),
@@ -104,6 +105,20 @@ class TASim:
         if ov is not None:
             torch.cuda.current_stream(self.device).synchronize()
 
+    def pd_targets(self, actions):
+        """pre_physics_step's PD targets (TA:1131) for actions [N,27]."""
+        a = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, 27).contiguous()
+        out = torch.empty_like(a)
+        _lib.check(self.L.ppenv_ta_pd_targets(self.h, self.num_envs, a.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def serve_from_draws(self, draws):
+        """TA's generate_random_speed_for_ball (TA:346-377) on [M,3] draws (speed, tilt deg, tilt_z deg)."""
+        d = torch.as_tensor(draws, dtype=torch.float32).to(self.device).reshape(-1, 3).contiguous()
+        out = torch.empty_like(d)
+        _lib.check(self.L.ppenv_ta_serve_from_draws(self.h, d.data_ptr(), d.shape[0], out.data_ptr(), self._stream()))
+        return out
+
     def forward_kinematics(self, root_states, dof_states, rb_states):
         n = self.num_envs
         for t, k in ((root_states, n * 39), (dof_states, n * 54), (rb_states, n * 42 * 13)):
@@ -149,6 +164,33 @@ class TAEnv:
             self.sim.simulate(actions, self.root_states, self.dof_states, self.rb_states, self.dof_force_tensor, self.pre_ball_vx)
             self.state.post_physics_step(self.rb_states, self.initial_rb_states, self.root_states, self.dof_states, self.dof_force_tensor, self.pre_ball_vx)
         return {"obs": self.obs_buf}, self.rew_buf, self.reset_buf, {}
+
+    def reset_idx(self, env_ids=None):
+        """_reset_idx (TA:965-1028) outside a step, for the listed env ids (None: all).  A rare host-driven path: plain torch
+        indexing on the task's own tensors with the draws of each env's next episode (the same keyed draws the kernel uses)."""
+        n = self.num_envs
+        ids = torch.arange(n) if env_ids is None else torch.as_tensor(env_ids, dtype=torch.int64).reshape(-1).cpu()
+        if ids.numel() == 0:
+            return
+        if int(ids.min()) < 0 or int(ids.max()) >= n:
+            raise IndexError(f"env id outside [0, {n})")
+        ids = torch.unique(ids)
+        dev_ids = ids.to(self.device)
+        st = self.state
+        ep = (st.episode[dev_ids].to(torch.int64) + 1).cpu()
+        ov = scene.ta_reset_draws(self.params, ids, ep).to(self.device)               # y, z, vx, vy, vz (TA:976-979)
+        init = torch.tensor([[self.params.init_root[a][k] for k in range(7)] for a in range(3)], dtype=torch.float32, device=self.device)
+        rows = torch.zeros((ids.numel(), 3, 13), dtype=torch.float32, device=self.device)
+        rows[:, :, 0:7] = init
+        rows[:, 2, 1:3] = ov[:, 0:2]
+        rows[:, 2, 7:10] = ov[:, 2:5]
+        self.root_states[dev_ids] = rows                                              # TA:969-983
+        dof0 = torch.tensor([[self.params.init_dof_pos[d], self.params.init_dof_vel[d]] for d in range(27)], dtype=torch.float32, device=self.device)
+        self.dof_states[dev_ids] = dof0
+        st.episode[dev_ids] = ep.to(self.device, torch.int32)
+        st.progress_buf[dev_ids] = 0
+        sticky = scene.TA_FLAG_PADDLE_COND | scene.TA_FLAG_HIT_TABLE_CALC | scene.TA_FLAG_DIE_PENALTY_CALC | scene.TA_FLAG_HUMANOID_DIE_CALC
+        st.flags[dev_ids] = st.flags[dev_ids] & ~sticky                               # TA:1021-1024
 
     def close(self):
         self.sim.close()

@@ -94,13 +94,18 @@ class VecTask:
         self.states_buf = torch.zeros((rows, self.num_states), device=self.device, dtype=torch.float)
         self.timeout_buf = torch.zeros(rows, device=self.device, dtype=torch.long)
         self.randomize_buf = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
-        self.reset_buf_force = torch.zeros(rows, device=self.device, dtype=torch.long)   # TT:1037
+        # Fork-specific buffer of the reference's base class.  In the reference it is write-only: post_physics_step zeroes it
+        # every step (TT:1037) and the one statement that would read it is commented out (TT:761), so it never influences a
+        # reset.  Kept for attribute compatibility, all zeros, and — like the reference — never consulted.
+        self.reset_buf_force = torch.zeros(rows, device=self.device, dtype=torch.long)
+        self._obs_clipped = None if not np.isfinite(self.clip_obs) else torch.empty_like(self.obs_buf)
 
     # -- the surface rl_games drives
     def step(self, actions):
-        """One control step: K1..K8 in a single kernel launch (TT:1002-1052)."""
-        for _ in range(self.control_freq_inv):
-            self.env.step(actions)          # action clamp (clipActions) happens inside the kernel
+        """One control step: K1..K8 in a single kernel launch (TT:1002-1052).  controlFrequencyInv = k (upstream: pre_physics_step
+        once, k simulate calls, post_physics_step once) is folded into the native config at create time — k * substeps physics
+        substeps of the same length ahead of one reward / reset / observation pass — so it is still one launch."""
+        self.env.step(actions)              # action clamp (clipActions) happens inside the kernel
         self.control_steps += 1
         # upstream: timeout_buf = (progress_buf >= max_episode_length - 1) & (reset_buf != 0), evaluated after
         # post_physics_step.  These tasks zero progress_buf inside post_physics_step on every reset (TT:902), so
@@ -113,8 +118,14 @@ class VecTask:
         return self._obs_dict()
 
     def reset_idx(self, env_ids=None):
-        """Full reset of every env (the per-env masked reset lives inside the step kernel, TT:847-906)."""
-        self.env.reset_all()
+        """reset_idx(env_ids) -> _reset_idx (TT:809-812, 847-906): the listed envs go back to their initial state with a fresh
+        serve, progress 0 and the initial flags; every other env keeps its trajectory.  `env_ids` as the reference passes them:
+        an int64 tensor of env indices (`reset_buf.nonzero()`, TT:1034).  None resets every env (VecTask.reset_idx() of a fresh
+        task).  For the two-agent task an id is an ENV index (both agent rows of that env reset together, T4:853-912)."""
+        if env_ids is None:
+            self.env.reset_all()
+        else:
+            self.env.reset_idx(env_ids)
 
     def reset_done(self):
         return self._obs_dict(), torch.nonzero(self.reset_buf, as_tuple=False).flatten()
@@ -133,7 +144,7 @@ class VecTask:
         return t if self.rl_device == self.device else t.to(self.rl_device)
 
     def _obs_dict(self):
-        obs = self.obs_buf if not np.isfinite(self.clip_obs) else torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs)
+        obs = self.obs_buf if self._obs_clipped is None else torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs, out=self._obs_clipped)
         self.obs_dict["obs"] = self._to_rl(obs)
         if self.num_states > 0:
             self.obs_dict["states"] = self._to_rl(self.states_buf)
@@ -189,6 +200,12 @@ class _HumanoidPingpongBase(VecTask):
         self.up_axis_idx = 2
         self.native_config = scene.build_config(self.VARIANT, cfg=self.cfg, num_envs=self.num_envs, seed=self._seed,
                                                 device_id=self.device_id, env_id_offset=self._env_id_offset)
+        k = self.control_freq_inv
+        if k < 1:
+            raise ValueError("controlFrequencyInv must be >= 1")
+        if k > 1:   # k simulate calls of dt each = k * substeps substeps of dt / substeps, then ONE post_physics_step
+            self.native_config.dt = self.native_config.dt * k
+            self.native_config.substeps = self.native_config.substeps * k
         self.env = PPEnv(self.native_config, device=self.device)
         return self.env
 
@@ -293,6 +310,9 @@ class HumanoidPingpongTiltNESSparse27DOF(VecTask):
         keys = ("episodeLength", "alphaVelocityReward", "powerCoefficient", "hitTableReward", "nothitTablePenalty", "crossNetRewardFloat",
                 "diePenaltyFloat", "hitPaddleReward", "missPaddlePenaltyCoefficient")
         env = {k: self.cfg["env"][k] for k in keys if k in self.cfg["env"]}
+        if self.control_freq_inv != 1:
+            raise NotImplementedError("controlFrequencyInv != 1 is not wired for the 27-dof task (its yaml has none; "
+                                      "cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml)")
         with torch.cuda.device(self.device):
             self.env = TAEnv(self.num_envs, device=self.device, seed=self._seed, env_id_offset=self._env_id_offset, env=env)
         e = self.env
@@ -305,11 +325,12 @@ class HumanoidPingpongTiltNESSparse27DOF(VecTask):
         return e
 
     def step(self, actions):
-        for _ in range(self.control_freq_inv):
-            self.env.step(actions)          # the clipActions clamp happens inside the kernel
+        self.env.step(actions)              # the clipActions clamp happens inside the kernel
         self.control_steps += 1
         self.extras["time_outs"] = self.timeout_buf if self.rl_device == self.device else self.timeout_buf.to(self.rl_device)
         return self._obs_dict(), self._to_rl(self.rew_buf), self._to_rl(self.reset_buf), self.extras
 
     def reset_idx(self, env_ids=None):
-        raise NotImplementedError("the 27-dof task resets inside post_physics_step (TA:965-1028); a forced full reset is not part of its surface")
+        """_reset_idx (TA:965-1028) for the listed envs (None: all): root states, dof states, ball y / z and serve of the env's
+        next episode, progress 0, the four sticky flags cleared.  Like the reference's, it leaves obs_buf to the next step."""
+        self.env.reset_idx(env_ids)

@@ -125,6 +125,12 @@ class OracleEnv:
     def set_threads(self, t):
         self.L.ppo_set_threads(self.h, t)
 
+    def reset_idx(self, env_ids, refresh_obs=True):
+        ids = np.ascontiguousarray(env_ids, np.int64).reshape(-1)
+        self.L.ppo_reset_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        if self.L.ppo_reset_idx(self.h, ids.ctypes.data_as(C.c_void_p), ids.size, int(bool(refresh_obs))) != 0:
+            raise IndexError("env id out of range")
+
     def step(self, actions):
         a = _f32(actions)
         assert a.shape == (self.num_envs * self.num_agents, scene.NUM_DOF)
@@ -216,6 +222,24 @@ def serve_velocity(config, gid, episode):
     out = (C.c_float * 3)()
     lib().ppo_serve_velocity(C.byref(config), gid, episode, out)
     return np.array(list(out), np.float32)
+
+
+def serve_from_draws(form, draws):
+    """generate_random_speed_for_ball of variant `form` (scene.VARIANT_IDS value) on [M,3] draws (speed, tilt deg, tilt_z deg)."""
+    d = np.ascontiguousarray(draws, np.float64).reshape(-1, 3)
+    out = np.zeros((d.shape[0], 3), np.float32)
+    lib().ppo_serve_from_draws(int(form), d.shape[0], d.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def pd_targets(actions, lo, hi, clip):
+    """pre_physics_step's PD targets for [M,D] actions and joint limits lo / hi [D] (after the clipActions clamp)."""
+    a = _f32(actions)
+    lo, hi = _f32(lo), _f32(hi)
+    out = np.zeros_like(a)
+    lib().ppo_pd_targets(a.shape[0], a.shape[1], a.ctypes.data_as(C.c_void_p), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
+                         C.c_float(clip), out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 def compute_obs(bodies, dof_pos, dof_vel, ball):

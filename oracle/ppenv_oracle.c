@@ -147,24 +147,37 @@ static float rng_uniform(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t
     h = hash32(h + (k + 1u) * 0x85EBCA6Bu);
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
-/* generate_random_speed_for_ball: TT:296-323 / T3:289-305 / TN:301-328 */
-static void serve_velocity(const ppenv_config* c, uint32_t gid, uint32_t episode, float out[3]) {
-    float u0 = rng_uniform(c->seed, gid, episode, 0);
-    float u1 = rng_uniform(c->seed, gid, episode, 1);
-    float u2 = rng_uniform(c->seed, gid, episode, 2);
-    double speed = c->serve_speed_lo + (c->serve_speed_hi - c->serve_speed_lo) * u0;
-    double a = (c->serve_tilt_lo_deg + (c->serve_tilt_hi_deg - c->serve_tilt_lo_deg) * u1) * (M_PI / 180.0);
-    double az = (c->serve_tilt_z_lo_deg + (c->serve_tilt_z_hi_deg - c->serve_tilt_z_lo_deg) * u2) * (M_PI / 180.0);
-    if (c->variant == PPENV_VARIANT_T3) {            /* T3:296-300 */
+/* generate_random_speed_for_ball from its three draws (speed, tilt, tilt_z; degrees; the reference's draw order), in the
+ * reference's double arithmetic: T3:289-305, TT:296-323, TN:301-328, T4:299-326 (= TT), TA:346-377 (= TN's form; `form` is a
+ * PPENV_VARIANT_* value).  Pinned by tests/golden/serve_draws.npz (the reference functions with random.uniform scripted). */
+static void serve_from_draws(int form, double speed, double tilt_deg, double tilt_z_deg, float out[3]) {
+    double a = tilt_deg * (M_PI / 180.0), az = tilt_z_deg * (M_PI / 180.0);
+    if (form == PPENV_VARIANT_T3) {            /* T3:296-300 */
         double s = -speed;
         out[0] = (float)(s * cos(a)); out[1] = (float)(s * sin(a)); out[2] = 0.0f;
-    } else if (c->variant == PPENV_VARIANT_TT || c->variant == PPENV_VARIANT_T4) {   /* TT:307-318 = T4:310-321 (sic: sin a sin az, then sin a) */
+    } else if (form == PPENV_VARIANT_TT || form == PPENV_VARIANT_T4) {   /* TT:307-318 = T4:310-321 (sic: sin a sin az, then sin a) */
         double s = -speed;
         out[0] = (float)(s * cos(a) * cos(az)); out[1] = (float)(s * sin(a) * sin(az)); out[2] = (float)(s * sin(a));
     } else {                                         /* TN:312-323 */
         double s = speed;
         out[0] = (float)(-s * cos(a) * cos(az)); out[1] = (float)(s * sin(a) * cos(az)); out[2] = (float)(s * sin(az));
     }
+}
+static void serve_velocity(const ppenv_config* c, uint32_t gid, uint32_t episode, float out[3]) {
+    float u0 = rng_uniform(c->seed, gid, episode, 0);
+    float u1 = rng_uniform(c->seed, gid, episode, 1);
+    float u2 = rng_uniform(c->seed, gid, episode, 2);
+    double speed = c->serve_speed_lo + (c->serve_speed_hi - c->serve_speed_lo) * u0;
+    double a = c->serve_tilt_lo_deg + (c->serve_tilt_hi_deg - c->serve_tilt_lo_deg) * u1;
+    double az = c->serve_tilt_z_lo_deg + (c->serve_tilt_z_hi_deg - c->serve_tilt_z_lo_deg) * u2;
+    serve_from_draws(c->variant, speed, a, az, out);
+}
+/* pre_physics_step's action -> PD target: TT:1008 with offset / scale TT:664-665 (float32 numpy there), after upstream
+ * VecTask.step's clamp to clipActions.  Pinned by tests/golden/pre_physics.npz (the reference's own pre_physics_step). */
+static float pd_target(float action, float lo, float hi, float clip) {
+    float a = fminf(fmaxf(action, -clip), clip);
+    float off = 0.5f * (hi + lo), scale = 0.5f * (hi - lo);   /* TT:664-665 */
+    return off + scale * a;                                    /* TT:1008 */
 }
 
 /* ------------------------------------------------------- arm kinematics (world) */
@@ -699,6 +712,22 @@ void ppo_init(ppo_env* e) {
 void ppo_reset_all(ppo_env* e) {
     for (int i = 0; i < e->n; i++) { e->episode[i] += 1; init_env(e, i); }
 }
+/* reset_idx(env_ids) -> _reset_idx (TT:809-812, 847-906): only the listed envs; TN keeps its dof state (TN:888-901).
+ * The reference leaves obs_buf alone there; refresh_obs rewrites the listed envs' rows from the reset state. */
+int ppo_reset_idx(ppo_env* e, const int64_t* ids, int count, int refresh_obs) {
+    for (int t = 0; t < count; t++) {
+        if (ids[t] < 0 || ids[t] >= e->n) return -1;
+        int i = (int)ids[t];
+        e->episode[i] += 1;
+        reset_env_state(e, i, e->cfg.variant != PPENV_VARIANT_TN);
+        for (int a = 0; a < e->A; a++) {
+            e->flags[(size_t)a * e->n + i] = initial_flags(&e->cfg);   /* TT:903-905 */
+            e->progress[(size_t)i * e->A + a] = 0;                      /* TT:902 */
+        }
+        if (refresh_obs) obs_from_state(e, i);
+    }
+    return 0;
+}
 void ppo_set_serve_override(ppo_env* e, const float* serve /* [N,3] */, int on) {
     e->serve_on = on;
     if (on && serve)
@@ -716,11 +745,7 @@ static void step_env(ppo_env* e, int i, const float* actions) {
     /* pre_physics_step: TT:1003-1020 (clamp is VecTask.step, clipActions) */
     double target[ND];
     for (int d = 0; d < ND; d++) {
-        float a = actions[(size_t)i * ND + d];
-        a = fminf(fmaxf(a, -c->clip_actions), c->clip_actions);
-        float lo = c->joint[d].lower, hi = c->joint[d].upper;
-        float off = 0.5f * (hi + lo), scale = 0.5f * (hi - lo);   /* TT:664-665 */
-        target[d] = off + scale * a;                                /* TT:1008 */
+        target[d] = pd_target(actions[(size_t)i * ND + d], c->joint[d].lower, c->joint[d].upper, c->clip_actions);   /* TT:1008 */
     }
     float pre_vx = ballf[7];                                        /* TT:1020 */
 
@@ -974,6 +999,13 @@ double ppo_arm_energy(const ppenv_config* c, const double* q, const double* qd) 
     return E;
 }
 void ppo_serve_velocity(const ppenv_config* c, uint32_t gid, uint32_t episode, float out[3]) { serve_velocity(c, gid, episode, out); }
+void ppo_serve_from_draws(int form, int m, const double* draws /* [m,3] */, float* out /* [m,3] */) {
+    for (int i = 0; i < m; i++) serve_from_draws(form, draws[3 * i], draws[3 * i + 1], draws[3 * i + 2], &out[3 * i]);
+}
+void ppo_pd_targets(int m, int nd, const float* actions /* [m,nd] */, const float* lo, const float* hi /* [nd] */, float clip, float* out) {
+    for (int i = 0; i < m; i++)
+        for (int d = 0; d < nd; d++) out[(size_t)i * nd + d] = pd_target(actions[(size_t)i * nd + d], lo[d], hi[d], clip);
+}
 void ppo_compute_obs(const float* bodies /* [10][13] */, const float* dof_pos, const float* dof_vel, const float* ball, float* obs) {
     compute_obs((const float(*)[13])bodies, dof_pos, dof_vel, ball, obs);
 }
@@ -1102,9 +1134,9 @@ void ppo_ta_post_physics_step(const ppenv_ta_params* p, const float* rb_states, 
                 ov[0] = p->ball_y_lo + (p->ball_y_hi - p->ball_y_lo) * u[0];      /* draw order TA:976-979: y, z, speed, tilt, tilt_z */
                 ov[1] = p->ball_z_lo + (p->ball_z_hi - p->ball_z_lo) * u[1];
                 double speed = p->serve_speed_lo + (p->serve_speed_hi - p->serve_speed_lo) * u[2];
-                double a = (p->serve_tilt_lo_deg + (p->serve_tilt_hi_deg - p->serve_tilt_lo_deg) * u[3]) * (M_PI / 180.0);
-                double az = (p->serve_tilt_z_lo_deg + (p->serve_tilt_z_hi_deg - p->serve_tilt_z_lo_deg) * u[4]) * (M_PI / 180.0);
-                ov[2] = (float)(-speed * cos(a) * cos(az)); ov[3] = (float)(speed * sin(a) * cos(az)); ov[4] = (float)(speed * sin(az));   /* TA:370-375 */
+                double a = p->serve_tilt_lo_deg + (p->serve_tilt_hi_deg - p->serve_tilt_lo_deg) * u[3];
+                double az = p->serve_tilt_z_lo_deg + (p->serve_tilt_z_hi_deg - p->serve_tilt_z_lo_deg) * u[4];
+                serve_from_draws(PPENV_VARIANT_TN, speed, a, az, &ov[2]);          /* TA:370-375 is TN's form */
             }
             for (int a = 0; a < 3; a++) {
                 memcpy(&root[a * 13], p->init_root[a], 7 * sizeof(float));
@@ -1225,11 +1257,7 @@ static void step_env_t4(ppo_env* e, int i, const float* actions) {
     double target[2][ND], q[2][ND], qd[2][ND], tau_drive[2][ND] = {{0}};
     for (int a = 0; a < 2; a++)
         for (int d = 0; d < ND; d++) {
-            float act = actions[((size_t)i * 2 + a) * ND + d];
-            act = fminf(fmaxf(act, -c->clip_actions), c->clip_actions);
-            float lo = c->joint[d].lower, hi = c->joint[d].upper;
-            float off = 0.5f * (hi + lo), scale = 0.5f * (hi - lo);
-            target[a][d] = off + scale * act;                      /* T4:1014 */
+            target[a][d] = pd_target(actions[((size_t)i * 2 + a) * ND + d], c->joint[d].lower, c->joint[d].upper, c->clip_actions);   /* T4:1014 */
             q[a][d] = qf[a * ND + d]; qd[a][d] = qdf[a * ND + d];
         }
     float pre_vx = ballf[7];                                        /* T4:1026 */
@@ -1584,9 +1612,7 @@ static void ta_simulate_env(const ppenv_config* c, const ppenv_ta_model* M, cons
     double q[NDF], qd[NDF], target[NDF], tau_drive[NDF] = {0};
     for (int d = 0; d < NDF; d++) {
         const ppenv_ta_link* L = &M->link[d + 1];
-        float a = fminf(fmaxf(act[d], -c->clip_actions), c->clip_actions);
-        float off = 0.5f * (L->upper + L->lower), scale = 0.5f * (L->upper - L->lower);   /* TA:729-733 */
-        target[d] = off + scale * a;                                                       /* TA:1131 */
+        target[d] = pd_target(act[d], L->lower, L->upper, c->clip_actions);               /* TA:1131, 729-733 */
         q[d] = dofs[2 * d]; qd[d] = dofs[2 * d + 1];
     }
     float* ballf = &root[26];

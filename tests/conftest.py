@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """What the probe-using parity tests excluded, and the worst error they retained (tests/helpers.py ExclusionLog)."""
+    import helpers
+    if helpers.PARITY_REPORT:
+        terminalreporter.write_sep("-", "parity: probe exclusions and worst retained errors")
+        for line in helpers.PARITY_REPORT:
+            terminalreporter.write_line(line)
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     from oracle import binding

@@ -95,6 +95,17 @@ void shim_arm_qdd(const ppenv_config* cfg, const float* q, const float* qd, cons
     aba_solve<T>(K.site[0], js, qd, tau, arm_eff, qdd);
 }
 
+void shim_serve_from_draws(int form, int m, const float* draws /*[m,3]*/, float* out /*[m,3]*/) {
+    for (int i = 0; i < m; i++) {
+        V3 v = serve_from_draws(form, draws[3 * i], draws[3 * i + 1], draws[3 * i + 2]);
+        out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+    }
+}
+void shim_pd_targets(int m, int nd, const float* actions /*[m,nd]*/, const float* lo, const float* hi /*[nd]*/, float clip, float* out) {
+    for (int i = 0; i < m; i++)
+        for (int d = 0; d < nd; d++) out[(size_t)i * nd + d] = pd_target(actions[(size_t)i * nd + d], lo[d], hi[d], clip);
+}
+
 void shim_serve_velocity(const ppenv_config* cfg, uint32_t gid, uint32_t episode, float* out) {
     V3 v = serve_velocity(make_step_consts(*cfg), gid, episode);
     out[0] = v.x; out[1] = v.y; out[2] = v.z;
@@ -123,8 +134,7 @@ extern "C" int shim_ta_simulate(const ppenv_config* scene, const ppenv_ta_model*
         float* dofs = &dof_states[(size_t)e * 2 * NDOF];
         for (int d = 0; d < NDOF; d++) {
             const LinkC& L = C.link[d + 1];
-            float a = fminf(fmaxf(actions[(size_t)e * NDOF + d], -C.sc.clip_actions), C.sc.clip_actions);
-            st(DOF_BASE + d * DOF_STRIDE + G_TARGET) = 0.5f * (L.hi + L.lo) + 0.5f * (L.hi - L.lo) * a;
+            st(DOF_BASE + d * DOF_STRIDE + G_TARGET) = pd_target(actions[(size_t)e * NDOF + d], L.lo, L.hi, C.sc.clip_actions);
             st(DOF_BASE + d * DOF_STRIDE + G_Q) = dofs[2 * d];
             st(DOF_BASE + d * DOF_STRIDE + G_QD) = dofs[2 * d + 1];
             st(DOF_BASE + d * DOF_STRIDE + G_FORCE) = 0.f;

@@ -33,11 +33,40 @@ def expand_bodies(compact):
     return full
 
 
+PARITY_REPORT = []      # one line per probe-using test: printed in the terminal summary by tests/conftest.py
+_WORST = [0.0]          # largest |err| / tolerance any assert_close has retained since the last ExclusionLog was opened
+
+
+class ExclusionLog:
+    """Book-keeping of a test that uses SensitivityProbe: how many env-steps the probe excluded and how close to the tolerance the
+    worst RETAINED comparison came; asserts the exclusion bound and leaves one line for the terminal summary."""
+
+    def __init__(self, name, bound):
+        self.name, self.bound, self.excluded, self.total = name, bound, 0, 0
+        _WORST[0] = 0.0
+
+    def add(self, keep):
+        self.excluded += int((~keep).sum())
+        self.total += int(keep.size)
+
+    def close(self):
+        frac = self.excluded / max(self.total, 1)
+        line = (f"{self.name}: probe excluded {self.excluded} of {self.total} env-steps ({100 * frac:.3f} %, bound {100 * self.bound:.2f} %); "
+                f"worst retained error = {_WORST[0]:.3f} x tolerance")
+        PARITY_REPORT.append(line)
+        print(line)
+        assert frac <= self.bound, line
+
+
 def assert_close(actual, expected, what, rtol=RTOL, atol=ATOL):
     actual = np.asarray(actual, dtype=np.float64)
     expected = np.asarray(expected, dtype=np.float64)
     err = np.abs(actual - expected)
     tol = atol + rtol * np.abs(expected)
+    if err.size:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratio = np.where(tol > 0, err / np.where(tol > 0, tol, 1.0), np.where(err > 0, np.inf, 0.0))
+        _WORST[0] = max(_WORST[0], float(np.max(ratio)))
     bad = err > tol
     if bad.any():
         idx = np.unravel_index(np.argmax(err - tol), err.shape)

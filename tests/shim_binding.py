@@ -92,3 +92,20 @@ def ta_simulate(scene_cfg, model, actions, root, dof):
     rc = lib().shim_ta_simulate(C.byref(scene_cfg), C.byref(model), n, _p(actions), _p(root), _p(dof), _p(rb), _p(frc), _p(pvx))
     assert rc == 0
     return rb, frc, pvx
+
+
+def serve_from_draws(form, draws):
+    """The kernels' serve_from_draws() (fp32) on [M,3] draws (speed, tilt deg, tilt_z deg)."""
+    d = np.ascontiguousarray(draws, np.float32).reshape(-1, 3)
+    out = np.zeros_like(d)
+    lib().shim_serve_from_draws(int(form), d.shape[0], _p(d), _p(out))
+    return out
+
+
+def pd_targets(actions, lo, hi, clip):
+    """The kernels' pd_target() on [M,D] actions."""
+    a = np.ascontiguousarray(actions, np.float32)
+    lo, hi = np.ascontiguousarray(lo, np.float32), np.ascontiguousarray(hi, np.float32)
+    out = np.zeros_like(a)
+    lib().shim_pd_targets(a.shape[0], a.shape[1], _p(a), _p(lo), _p(hi), C.c_float(clip), _p(out))
+    return out

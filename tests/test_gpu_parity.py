@@ -3,7 +3,7 @@ outputs (tests/golden) and (ii) the CPU oracle on the same seeded inputs.  Need 
 import numpy as np
 import pytest
 
-from helpers import (RTOL, SensitivityProbe, assert_close, assert_state_close, expand_bodies, golden_config, load_golden,
+from helpers import (RTOL, ExclusionLog, SensitivityProbe, assert_close, assert_state_close, expand_bodies, golden_config, load_golden,
                      mask_envs, obs_atol, reward_atol)
 from isaacgym_amd import scene
 
@@ -70,8 +70,9 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant)
     rng = np.random.default_rng(1)
     oa, ra = obs_atol(), reward_atol(cfg)
     steps = 180 if variant == "TN" else 120
-    resets, excluded = 0, 0
+    resets = 0
     probe = SensitivityProbe(oracle_lib, cfg)
+    log = ExclusionLog(f"gpu fused step vs oracle [{variant}]", bound=0.005)
     for t in range(steps):
         actions = rng.uniform(-1.2, 1.2, (n, 7)).astype(np.float32)
         st = o.get_state()
@@ -79,7 +80,7 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant)
         o.step(actions)
         env.step(torch.from_numpy(actions).cuda())
         keep = ~probe.sensitive(st, actions, o)      # envs sitting on a switch of the physics spec this step are skipped
-        excluded += int((~keep).sum())
+        log.add(keep)
         v, o_all = mask_envs(DevView(env), keep), o
         o = mask_envs(o_all, keep)
         np.testing.assert_array_equal(v.reset_buf, o.reset_buf, err_msg=f"reset step {t}")
@@ -92,7 +93,7 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant)
         o = o_all
         resets += int(o.reset_buf.sum())
     assert resets > 50   # the masked-reset path was exercised
-    assert excluded < 0.005 * n * steps
+    log.close()          # prints excluded count + worst retained error, asserts the bound
     env.close()
 
 
@@ -372,3 +373,109 @@ def test_reduce_stats_matches_torch_sums(torch_cuda, variant, n):
             float(n * env.num_agents)]
     np.testing.assert_allclose(s, want, rtol=1e-9, atol=1e-6)
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reset_idx(env_ids), the device status word, controlFrequencyInv
+
+
+@pytest.mark.parametrize("variant", ["TT", "TN", "T4"])
+def test_reset_idx_resets_only_the_listed_envs(torch_cuda, oracle_lib, variant):
+    """ppenv_reset_idx = reset_idx(env_ids) -> _reset_idx (TT:809-812, 847-906) against the oracle's: the listed envs get their
+    next episode's serve, progress 0 and the initial flags (TN keeps its dof state, TN:888-901), every other env is untouched."""
+    torch = torch_cuda
+    n = 300
+    cfg = scene.build_config(variant, num_envs=n, seed=13)
+    o = oracle_lib.OracleEnv(cfg, threads=8)
+    env = make_env(scene.build_config(variant, num_envs=n, seed=13))
+    A = env.num_agents
+    rng = np.random.default_rng(3)
+    for t in range(25):                                   # get away from the initial state
+        o.step(rng.uniform(-1, 1, (n * A, 7)).astype(np.float32))
+    env.set_state(o.get_state())
+    before = DevView(env)
+    ids = np.unique(rng.integers(0, n, 70))
+    ids_dup = np.concatenate([ids, ids[:5]])              # duplicates are harmless
+    o.reset_idx(ids)
+    env.reset_idx(torch.from_numpy(ids_dup).cuda())       # device ids, as the reference's reset_buf.nonzero() result
+    v = DevView(env)
+    for name in ("dof_pos", "dof_vel", "ball"):
+        np.testing.assert_allclose(getattr(v, name), getattr(o, name), rtol=1e-6, atol=1e-6, err_msg=name)
+    np.testing.assert_array_equal(v.progress_buf, o.progress_buf)
+    np.testing.assert_array_equal(v.flags, o.flags)
+    np.testing.assert_array_equal(v.episode, o.episode)
+    rows = np.repeat(np.isin(np.arange(n), ids), A)
+    assert_close(v.obs_buf[rows], o.obs_buf[rows], "obs rows of the reset envs", atol=obs_atol())
+    other = ~np.isin(np.arange(n), ids)
+    for name in ("dof_pos", "dof_vel", "dof_force", "ball"):
+        np.testing.assert_array_equal(getattr(v, name)[:, other], getattr(before, name)[:, other], err_msg=f"{name} of untouched envs")
+    np.testing.assert_array_equal(v.episode[other], before.episode[other])
+    np.testing.assert_array_equal(v.progress_buf[np.repeat(other, A)], before.progress_buf[np.repeat(other, A)])
+    assert (v.episode[ids] == before.episode[ids] + 1).all() and (v.progress_buf[rows] == 0).all()
+    if variant == "TN":
+        np.testing.assert_array_equal(v.dof_pos[:, ids], before.dof_pos[:, ids])     # TN:888-901
+    with pytest.raises(IndexError):
+        env.reset_idx([n])
+    env.close()
+
+
+def test_vectask_reset_idx_and_control_frequency(torch_cuda):
+    """VecTask.reset_idx(env_ids) resets the subset only; controlFrequencyInv = 2 is two simulate calls ahead of ONE post_physics_step."""
+    torch = torch_cuda
+    import isaacgym_amd
+    n = 256
+    task = isaacgym_amd.make(seed=4, task="HumanoidPingpongTiltG1", num_envs=n)
+    a = torch.zeros(n, 7, device="cuda")
+    for _ in range(10):
+        task.step(a)
+    ep0, prog0 = task.env.episode.clone(), task.progress_buf.clone()
+    ids = torch.tensor([3, 77, 200], device="cuda")
+    task.reset_idx(ids)
+    assert (task.env.episode[ids] == ep0[ids] + 1).all() and (task.progress_buf[ids] == 0).all()
+    mask = torch.ones(n, dtype=torch.bool, device="cuda")
+    mask[ids] = False
+    assert torch.equal(task.env.episode[mask], ep0[mask]) and torch.equal(task.progress_buf[mask], prog0[mask])
+    assert int(task.reset_buf_force.abs().sum()) == 0
+
+    # controlFrequencyInv: one step of a k = 2 task == two substep-pairs of physics, progress + 1, one reward
+    cfg = scene.default_task_cfg("TT")
+    cfg["env"]["numEnvs"], cfg["env"]["controlFrequencyInv"], cfg["seed"] = n, 2, 4
+    from isaacgym_amd.tasks import isaacgym_task_map
+    t2 = isaacgym_task_map["HumanoidPingpongTiltG1"](cfg, "cuda:0", "cuda:0", -1, True, False, False)
+    assert t2.native_config.substeps == 4 and abs(t2.native_config.dt - 2 * 0.0083) < 1e-7
+    t1 = isaacgym_amd.make(seed=4, task="HumanoidPingpongTiltG1", num_envs=n)
+    ball0 = t1.env.ball.clone()
+    t2.step(a)
+    assert int(t2.progress_buf.max()) == 1
+    # free flight over two sim steps: x advances by ~ 2 dt vx (no contact in the first steps of a serve)
+    dx = (t2.env.ball[0] - ball0[0]).cpu().numpy()
+    np.testing.assert_allclose(dx, 2 * 0.0083 * ball0[7].cpu().numpy(), rtol=1e-3)
+
+
+def test_handoff_timeout_is_reported_not_stored(torch_cuda, monkeypatch):
+    """A wave of the multi-wave step kernel that never receives its partner's LDS hand-off must not store plausible garbage:
+    it sets the handle's status word and every later call fails with PPENV_EDEVICE.  PPENV_DEBUG_DROP_HANDOFF withholds the
+    arm wave's last hand-off so that the ball wave's bounded wait runs out."""
+    torch = torch_cuda
+    from isaacgym_amd import _lib
+    monkeypatch.setenv("PPENV_DEBUG_DROP_HANDOFF", "1")
+    env = make_env(scene.build_config("TT", num_envs=64, seed=2))
+    monkeypatch.delenv("PPENV_DEBUG_DROP_HANDOFF")
+    assert env.status == 0
+    ball0, rew0 = env.ball.clone(), env.rew_buf.clone()
+    env.step(torch.zeros(64, 7, device="cuda"))          # the launch itself succeeds; the fault is reported by the device
+    torch.cuda.synchronize()
+    assert env.status & scene.STATUS_HANDOFF_TIMEOUT
+    assert torch.equal(env.ball, ball0) and torch.equal(env.rew_buf, rew0)     # the timed-out wave stored nothing
+    with pytest.raises(_lib.PPEnvError, match="hand-off"):
+        env.step(torch.zeros(64, 7, device="cuda"))
+    with pytest.raises(_lib.PPEnvError):
+        env.get_state()
+    with pytest.raises(_lib.PPEnvError):
+        env.reduce_stats()
+    env.close()
+    ok = make_env(scene.build_config("TT", num_envs=64, seed=2))               # a healthy handle is unaffected
+    ok.step(torch.zeros(64, 7, device="cuda"))
+    torch.cuda.synchronize()
+    assert ok.status == 0
+    ok.close()

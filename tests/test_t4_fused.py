@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import shim_binding as sb
-from helpers import RTOL, SensitivityProbe, assert_close, assert_state_close, mask_envs, obs_atol, reward_atol
+from helpers import RTOL, ExclusionLog, SensitivityProbe, assert_close, assert_state_close, mask_envs, obs_atol, reward_atol
 from isaacgym_amd import scene
 
 
@@ -138,7 +138,8 @@ def test_t4_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, monke
     rng = np.random.default_rng(1)
     oa, ra = obs_atol(), 2 * reward_atol(cfg)
     probe = SensitivityProbe(oracle_lib, cfg)
-    resets, excluded = 0, 0
+    resets = 0
+    log = ExclusionLog(f"gpu 4-actor step vs oracle [{schedule}]", bound=0.01)
     for t in range(160):
         actions = rng.uniform(-1.2, 1.2, (2 * n, 7)).astype(np.float32)
         st = o.get_state()
@@ -146,10 +147,11 @@ def test_t4_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, monke
         o.step(actions)
         env.step(torch.from_numpy(actions).cuda())
         keep = ~probe.sensitive(st, actions, o)      # envs sitting on a switch of the physics spec this step are skipped
-        excluded += int((~keep).sum())
+        log.add(keep)
         _check_step(mask_envs(DevView(env), keep, 2), mask_envs(o, keep, 2), t, oa, ra)
         resets += int(o.reset_buf.sum())
-    assert resets > 50 and excluded < 0.01 * n * 160
+    assert resets > 50
+    log.close()
     # gym.refresh_* equivalents in the 4-actor layouts
     env.set_state(o.get_state())
     assert_close(env.refresh_rigid_body_states().cpu().numpy(), o.refresh_rigid_body_states(), "rb states", atol=2e-3)

@@ -539,6 +539,128 @@ def generate_t4(seed):
     return out
 
 
+SERVE_FILES = {   # variant -> (task file, default ranges of its own class attributes: TT:111-113 etc. come from the cfg; TA:129-131 are literals)
+    "T3": "humanoid_interos_edit_pingpong_only_3_actor.py",
+    "TT": "humanoid_pingpong_3_actor_tilt.py",
+    "TN": "humanoid_pingpong_3_actor_tilt_no_earlystop.py",
+    "T4": "humanoid_pingpong_4_actor_tilt.py",
+    "TA": "humanoid_pingpong_3_actor_all_dof.py",
+}
+
+
+def generate_serve(seed):
+    """serve_draws.npz: every variant's own generate_random_speed_for_ball (T3:289-305, TT:296-323, TN:301-328, T4:299-326,
+    TA:346-377) with `random.uniform` scripted: call k returns the k-th scripted draw, so the function's three (T3: two) draws
+    are known inputs.  Stored per variant: draws [M,3] float64 = (speed, tilt deg, tilt_z deg) as `random.uniform` returned them,
+    ranges [3,2] the function was called with, out [M,3] float64 = the Vec3 it returned, ndraws = how many draws a call made."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for variant, fname in SERVE_FILES.items():
+        mod = ref_loader.load_task(fname)
+        sys.modules["isaacgym.gymapi"].Vec3 = Vec3
+        mod.gymapi.Vec3 = Vec3
+        cls = find_task_class(mod)
+        o = object.__new__(cls)
+        if variant == "TA":
+            ranges = [(5.0, 5.4), (-8.0, 3.0), (14.0, 24.0)]                 # TA:129-131
+        else:
+            sc = scene.default_task_cfg(variant)["scene"]
+            ranges = [tuple(sc["serve_speed"]), tuple(sc["serve_tilt"]), tuple(sc["serve_tilt_z"])]
+        M = 96
+        draws = np.stack([rng.uniform(lo, hi, M) for lo, hi in ranges], axis=1)
+        # range corners and zero angles as well
+        corners = np.array([[r[i] for r, i in zip(ranges, idx)] for idx in np.ndindex(2, 2, 2)], np.float64)
+        draws = np.concatenate([draws, corners, [[ranges[0][0], 0.0, 0.0], [ranges[0][1], 0.0, ranges[2][0]]]])
+        res, ncalls = [], []
+        real_uniform = mod.random.uniform
+        try:
+            for row in draws:
+                script = list(row)
+                calls = []
+
+                def scripted(a, b, _s=script, _c=calls):
+                    _c.append((a, b))
+                    return _s[len(_c) - 1]
+                mod.random.uniform = scripted
+                nargs = o.generate_random_speed_for_ball.__func__.__code__.co_argcount - 1   # T3's takes (speed, tilt) only (T3:289)
+                v = o.generate_random_speed_for_ball(*ranges[:nargs])
+                assert calls == list(ranges[:len(calls)]), (calls, ranges)           # draw order: speed, tilt, tilt_z
+                ncalls.append(len(calls))
+                res.append((v.x, v.y, v.z))
+        finally:
+            mod.random.uniform = real_uniform
+        assert len(set(ncalls)) == 1
+        out[f"{variant}_draws"] = draws
+        out[f"{variant}_ranges"] = np.array(ranges, np.float64)
+        out[f"{variant}_out"] = np.array(res, np.float64)
+        out[f"{variant}_ndraws"] = np.array(ncalls[0])
+    out["seed"] = np.array(seed)
+    return out
+
+
+def generate_pre_physics(seed):
+    """pre_physics.npz: the reference's own pre_physics_step (TT:1002-1020, T3:977-995, TN:1013-1031, T4:1008-1026, TA:1124-1143)
+    with `gymtorch.unwrap_tensor` stubbed to record the tensor handed to gym.set_dof_position_target_tensor.
+    `_pd_action_offset / _pd_action_scale` are built the way TT:649-671 / TA:720-733 build them (float32 numpy 0.5 * (hi +- lo))
+    from the joint limits of this build's model tables (the URDF limits themselves are UNVERIFIED placeholders: what is pinned
+    here is the MAPPING).  Actions are clamped to +-clipActions first, as upstream VecTask.step does before calling the hook
+    (SURVEY.md App. D); raw values beyond +-1 are in the fixture.  Stored per variant: actions [M,D] (raw), clip, lo / hi [D],
+    pd_tar [M,D] float32 (recorded), ball [M,13] and pre_ball [M,13] (the snapshot the hook takes, TT:1020)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    M = 64
+    for variant, fname in SERVE_FILES.items():
+        mod = ref_loader.load_task(fname)
+        cls = find_task_class(mod)
+        o = object.__new__(cls)
+        if variant == "TA":
+            model = scene.build_ta_model()
+            lo = np.array([model.link[d + 1].lower for d in range(27)], np.float32)
+            hi = np.array([model.link[d + 1].upper for d in range(27)], np.float32)
+            clip = float(scene.default_task_cfg("TA")["env"].get("clipActions", 1.0))
+        else:
+            c = scene.build_config(variant, num_envs=1)
+            lo = np.array([c.joint[j].lower for j in range(7)], np.float32)
+            hi = np.array([c.joint[j].upper for j in range(7)], np.float32)
+            clip = float(c.clip_actions)
+        D = lo.size
+        lim_low, lim_high = lo.copy(), hi.copy()
+        o._pd_action_offset = ref_loader.to_torch(0.5 * (lim_high + lim_low))        # TT:664-668
+        o._pd_action_scale = ref_loader.to_torch(0.5 * (lim_high - lim_low))
+        o.device = "cpu"
+        o.gym, o.sim = FakeGym(), None
+        captured = []
+
+        class _GT:
+            @staticmethod
+            def unwrap_tensor(t):
+                captured.append(t.detach().clone())
+                return t
+        mod.gymtorch = _GT
+        ball = np.zeros((M, 13), np.float32)
+        ball[:, 0:3] = rng.uniform([0, -0.8, 0.1], [3.3, 0.8, 1.5], (M, 3))
+        ball[:, 6] = 1.0
+        ball[:, 7:13] = rng.uniform(-9, 9, (M, 6))
+        o.ball2_root_states = torch.from_numpy(ball.copy())
+        actions = rng.uniform(-1.6, 1.6, (M, D)).astype(np.float32)
+        actions[0] = 0.0
+        actions[1] = 1.0
+        actions[2] = -1.0
+        a = torch.clamp(torch.from_numpy(actions), -clip, clip)                        # upstream VecTask.step
+        with contextlib.redirect_stdout(io.StringIO()):
+            o.pre_physics_step(a)
+        assert len(captured) == 1 and captured[0].dtype == torch.float32
+        out[f"{variant}_actions"] = actions
+        out[f"{variant}_clip"] = np.array(clip, np.float32)
+        out[f"{variant}_lo"], out[f"{variant}_hi"] = lo, hi
+        out[f"{variant}_pd_tar"] = captured[0].numpy().reshape(M, D)
+        out[f"{variant}_ball"] = ball
+        out[f"{variant}_pre_ball"] = o.pre_ball2_root_states.numpy().copy()
+        assert np.array_equal(o.actions.numpy(), a.numpy())
+    out["seed"] = np.array(seed)
+    return out
+
+
 def branch_report(variant, g):
     rew, reset, fl = g["out_rew"], g["out_reset"], g["out_flags"]
     print(f"[{variant}] steps x envs = {rew.shape}, resets {int(reset.sum())}, "
@@ -566,6 +688,12 @@ def main():
           f"flag bits seen {sorted({b for w in set(fl.ravel().tolist()) for b in range(9) if w >> b & 1})}, "
           f"rew>2500: {int((rew > 2500).sum())}, rew<-2500: {int((rew < -2500).sum())}, ref=-50 steps: {int((np.abs(rew + 50) < 30).sum())}")
     np.savez_compressed(os.path.join(outdir, "post_physics_TA.npz"), **g)
+    g = generate_serve(seed=20280)
+    np.savez_compressed(os.path.join(outdir, "serve_draws.npz"), **g)
+    print("[serve]", {v: (g[f"{v}_draws"].shape[0], int(g[f"{v}_ndraws"])) for v in SERVE_FILES})
+    g = generate_pre_physics(seed=20290)
+    np.savez_compressed(os.path.join(outdir, "pre_physics.npz"), **g)
+    print("[pre_physics]", {v: g[f"{v}_pd_tar"].shape for v in SERVE_FILES})
     print("wrote", sorted(os.listdir(outdir)))
 
 
