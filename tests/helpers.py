@@ -90,6 +90,13 @@ SCALES = {
 BALL_ROWS = {"ball_pos": slice(0, 3), "ball_quat": slice(3, 7), "ball_vel": slice(7, 10), "ball_spin": slice(10, 13)}
 
 
+# Round 2: the absolute part of the 7-dof tolerances is a QUARTER of "1e-4 x the tensor's range".  The probe-using tests print the
+# worst error they retain (ExclusionLog); on the GPU it is < 0.1 x the round-1 tolerance, i.e. < 0.4 x this one.
+ATOL_FRACTION = 0.25
+for _k in list(SCALES):
+    SCALES[_k] *= ATOL_FRACTION
+
+
 def assert_state_close(got, want, what):
     """got / want: objects with SoA arrays dof_pos, dof_vel, dof_force [7,N], ball [13,N]."""
     for name in ("dof_pos", "dof_vel", "dof_force"):
@@ -105,8 +112,8 @@ def assert_state_close(got, want, what):
 def obs_atol():
     """Per-column atol of an obs row: body pos (30), body vel (30), dof_pos (7), 0.1*dof_vel (7), ball pos (3), ball vel (3)."""
     a = np.empty(scene.NUM_OBS, np.float64)
-    a[0:30] = RTOL * 1.0        # arm reach ~1 m
-    a[30:60] = RTOL * 20.0      # link velocities up to ~20 m/s when the arm flails at the velocity limits
+    a[0:30] = RTOL * 1.0 * ATOL_FRACTION        # arm reach ~1 m
+    a[30:60] = RTOL * 20.0 * ATOL_FRACTION      # link velocities up to ~20 m/s when the arm flails at the velocity limits
     a[60:67] = RTOL * SCALES["dof_pos"]
     a[67:74] = RTOL * SCALES["dof_vel"] * 0.1
     a[74:77] = RTOL * SCALES["ball_pos"]
@@ -116,7 +123,7 @@ def obs_atol():
 
 def reward_atol(config):
     """Reward scale: alpha * |vx| dominates (TT:1159); the power term is c * sum|tau qd| <= c * 7 * 25 * 37."""
-    return RTOL * max(1.0, abs(config.alpha_velocity_reward) * SCALES["ball_vel"], abs(config.power_coefficient) * 6475.0)
+    return RTOL * max(ATOL_FRACTION, abs(config.alpha_velocity_reward) * SCALES["ball_vel"], abs(config.power_coefficient) * 6475.0 * ATOL_FRACTION)
 
 
 class SensitivityProbe:
@@ -129,7 +136,7 @@ class SensitivityProbe:
     under that jitter is excluded from the continuous comparison of that step (integer outputs are still compared for all
     envs that the jitter leaves unchanged)."""
 
-    def __init__(self, oracle_lib, config, rel=4e-6, seed=99):
+    def __init__(self, oracle_lib, config, rel=1e-6, seed=99):   # ~10 ulp of fp32: the size of the kernel's own rounding after ~1e3 operations
         self.o2 = oracle_lib.OracleEnv(config, threads=8)
         self.rew_atol = reward_atol(config)
         self.rel = rel
