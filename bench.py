@@ -136,7 +136,7 @@ def kernel_name(variant):
     if variant == "T4":
         return "step_kernel_split<ModelG1, 2, 0>" if os.environ.get("PPENV_STEP_KERNEL") == "split3" else "step_kernel_split<ModelG1, 2, 1>"
     if variant == "TA":
-        return "ta_sim_quad_kernel<true>" if os.environ.get("PPENV_TA_KERNEL") != "lane" else "ta_sim_kernel<true>"
+        return {"lane": "ta_sim_kernel<true>", "quad": "ta_sim_quad_kernel<true, true>"}.get(os.environ.get("PPENV_TA_KERNEL"), "ta_chain_kernel")
     split = os.environ.get("PPENV_STEP_KERNEL") != "fused"
     return "step_kernel_split<ModelG1, 1, 0>" if split else "step_kernel<ModelG1>"
 

@@ -435,13 +435,24 @@ void ppenv_ta_sim_destroy(ppenv_ta_sim* sim);
  * the caller's current device is.  The stateless entries (ppenv_ta_post_physics_step, ppenv_t4_rewards) launch on the device
  * that owns their output tensor. */
 int ppenv_ta_sim_device(const ppenv_ta_sim* sim);
+/* PPENV_STATUS_* bits reported by the handle's kernels (0 = healthy), readable without synchronising; ppenv_ta_step fails with
+ * PPENV_EDEVICE once it is non-zero.  ppenv_ta_sim_kernel: which kernel ppenv_ta_step launches — 2 = chain-wave (one lane per
+ * env, one wave per limb; needs the model compiled into the library, csrc/ppenv_model_g1_ta.h), 1 = four lanes per env,
+ * 0 = one lane per env (any tree).  PPENV_TA_KERNEL=chain|quad|lane forces one. */
+uint32_t ppenv_ta_sim_status(const ppenv_ta_sim* sim);
+int ppenv_ta_sim_kernel(const ppenv_ta_sim* sim);
+/* Host-only (no GPU call): 1 when `model` equals, bit for bit, the tables compiled into the chain-wave kernel
+ * (csrc/ppenv_model_g1_ta.h, generated by isaacgym_amd/modelgen_ta.py), 0 when it differs, < 0 on an invalid model. */
+int ppenv_ta_model_is_compiled(const ppenv_config* scene, const ppenv_ta_model* model);
 /* One pre_physics_step + gym.simulate + refresh.  actions [N,27]; root_states [N,3,13] (humanoid, table, ball) and
  * dof_states [N,27,2] are read and updated in place; rb_states [N,42,13], dof_force [N,27], pre_ball_vx [N] are written. */
 int ppenv_ta_simulate(ppenv_ta_sim* sim, int32_t num_envs, const float* actions_dev, float* root_states_dev, float* dof_states_dev,
                       float* rb_states_dev, float* dof_force_dev, float* pre_ball_vx_dev, void* stream);
-/* The whole VecTask step of the 27-DoF task in one launch (+ the count-flag clear): ppenv_ta_simulate followed by
- * ppenv_ta_post_physics_step, with the task arithmetic running on the rigid-body kernel's LDS tiles.  Arguments as in
- * those two entries; rb_states receives the pre-reset body states, root / dof states the post-reset ones (TA:1150-1160). */
+/* The whole VecTask step of the 27-DoF task in ONE launch: ppenv_ta_simulate followed by ppenv_ta_post_physics_step, the task
+ * arithmetic running on the rigid-body kernel's registers / LDS tiles and the cross-env count-flag clear (TA:1162-1166) done by
+ * the workgroup that finishes last.  Arguments as in those two entries; rb_states receives the pre-reset body states, root / dof
+ * states the post-reset ones (TA:1150-1160).  With the chain-wave kernel rb_states_dev may be NULL: the [N,42,13] tensor is
+ * then not materialised (nothing in the step reads it back; ppenv_ta_forward_kinematics produces it on demand). */
 int ppenv_ta_step(ppenv_ta_sim* sim, const ppenv_ta_params* params, const float* actions_dev, const float* initial_rb_states_dev,
                   float* root_states_dev, float* dof_states_dev, float* rb_states_dev, float* dof_force_dev, float* pre_ball_vx_dev,
                   const float* reset_override_dev, uint32_t* flags_dev, uint32_t* episode_dev, int64_t* progress_dev, float* obs_dev,

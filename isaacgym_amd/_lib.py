@@ -13,8 +13,9 @@ from . import scene
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("PPENV_LIB", os.path.join(_PKG, "lib", "libppenv.so"))   # PPENV_LIB: profiling builds only
-SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip"), os.path.join(_PKG, "csrc", "ppenv_ta.hip"), os.path.join(_PKG, "csrc", "ppenv_ta_sim.hip")]
-HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1.h"), os.path.join(_PKG, "csrc", "ppenv_ta_device.h"), os.path.join(_PKG, "csrc", "ppenv_ta_task.h"),
+SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip"), os.path.join(_PKG, "csrc", "ppenv_ta.hip"), os.path.join(_PKG, "csrc", "ppenv_ta_sim.hip"),
+           os.path.join(_PKG, "csrc", "ppenv_ta_chain.hip")]
+HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1.h"), os.path.join(_PKG, "csrc", "ppenv_ta_device.h"), os.path.join(_PKG, "csrc", "ppenv_ta_task.h"), os.path.join(_PKG, "csrc", "ppenv_ta_chain.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1_ta.h"),
            os.path.join(ROOT, "include", "ppenv.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-fno-signed-zeros", "-ffinite-math-only", "-fPIC", "-shared"]
 
@@ -87,6 +88,10 @@ def lib():
     L.ppenv_ta_pd_targets.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.ppenv_ta_serve_from_draws.argtypes = [vp, vp, C.c_int32, vp, vp]
     L.ppenv_ta_sim_device.argtypes = [vp]
+    L.ppenv_ta_sim_status.restype = C.c_uint32
+    L.ppenv_ta_sim_status.argtypes = [vp]
+    L.ppenv_ta_sim_kernel.argtypes = [vp]
+    L.ppenv_ta_model_is_compiled.argtypes = [cfgp, C.POINTER(scene.TAModel)]
     L.ppenv_post_physics_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     for name in ("ppenv_refresh_root_states", "ppenv_refresh_dof_states", "ppenv_refresh_dof_force",
                  "ppenv_refresh_rigid_body_states"):

@@ -1,0 +1,37 @@
+// ppenv_ta_chain.h — interface between ppenv_ta_sim.hip (the C ABI of the 27-DoF step) and ppenv_ta_chain.hip (its chain-wave kernel).
+#pragma once
+
+#include "ppenv_ta_device.h"
+
+namespace pp {
+namespace ta {
+
+// everything one launch of the chain-wave step needs besides the model scalars (ppenv_ta_step's arguments)
+struct TAChainArgs {
+    ppenv_ta_params p;
+    const StepConsts* K;          // device copy of the scene constants (read by the ball wave only)
+    const float* actions;         // [N,27]
+    const float* initial_rb;      // [N,42,13]
+    float* root_states;           // [N,3,13]   in / out
+    float* dof_states;            // [N,27,2]   in / out
+    float* rb_states;             // [N,42,13]  out, or NULL: not materialised
+    float* dof_force;             // [N,27]     out
+    float* pre_vx;                // [N]        out, or NULL
+    const float* reset_override;  // [N,5] or NULL
+    uint32_t* flags;
+    uint32_t* episode;
+    long long* progress;
+    float* obs;                   // [N,313]
+    float* rew;
+    long long* reset;
+    uint32_t* scratch;            // one word, zero between launches: bit 0 = some env reset in this launch, bits 1.. = workgroups done
+    uint32_t* status;             // host-visible status word of the handle (bit 0: a hand-off timed out)
+};
+
+// does the run-time model equal, bit for bit, the tables the chain-wave kernel was compiled from?
+bool ta_chain_model_matches(const TAConsts& C, char* why = nullptr, size_t nwhy = 0);
+// enqueue one step; returns a PPENV_* code
+int ta_chain_launch(const TAScal& P, const TAChainArgs& a, void* stream);
+
+}  // namespace ta
+}  // namespace pp

@@ -17,6 +17,7 @@
 
 #include "ppenv_ta_device.h"
 #include "ppenv_ta_task.h"
+#include "ppenv_ta_chain.h"
 
 using namespace pp;
 using namespace pp::ta;
@@ -532,6 +533,9 @@ struct ppenv_ta_sim {
     StepConsts* devK;      // the same in device memory (the quad kernel stages it in LDS)
     int device;
     int quad;     // 1: ta_sim_quad_kernel (four lanes per env), 0: ta_sim_kernel (one lane per env; any tree)
+    int chain;    // 1: ppenv_ta_step runs the chain-wave kernel (ppenv_ta_chain.hip: one lane per env, one wave per limb; the compiled G1 model only)
+    uint32_t* status_host;   // PPENV_STATUS_* bits, pinned host memory the kernels write through (cf. ppenv::status_host)
+    uint32_t* status_dev;
 };
 
 namespace {
@@ -549,6 +553,19 @@ int ta_use_device(const ppenv_ta_sim* s) {
 extern "C" {
 
 int ppenv_ta_sim_device(const ppenv_ta_sim* s) { return s ? s->device : -1; }
+uint32_t ppenv_ta_sim_status(const ppenv_ta_sim* s) { return s ? *(volatile uint32_t*)s->status_host : 0u; }
+/* which kernel ppenv_ta_step launches: 2 chain-wave, 1 quad, 0 one lane per env */
+int ppenv_ta_sim_kernel(const ppenv_ta_sim* s) { return s ? (s->chain ? 2 : (s->quad ? 1 : 0)) : -1; }
+/* host-only (no GPU call): 1 when the model equals, bit for bit, the tables compiled into the chain-wave kernel; 0 when it differs; < 0 on a bad model */
+int ppenv_ta_model_is_compiled(const ppenv_config* scene, const ppenv_ta_model* model) {
+    static TAConsts C;
+    const char* why = "";
+    if (!scene || !model || !make_ta_consts(*scene, *model, C, &why)) { ppenv_set_error(why); return PPENV_EINVAL; }
+    char msg[160] = "";
+    const bool same = ta_chain_model_matches(C, msg, sizeof msg);
+    if (!same) ppenv_set_error(msg);
+    return same ? 1 : 0;
+}
 
 #if defined(TA_STAMP)
 int ppenv_ta_debug_read_stamps(unsigned long long* dst, size_t count) {
@@ -574,10 +591,17 @@ int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, 
     s->K = make_step_consts(*scene);
     s->dev = nullptr;
     s->devK = nullptr;
-    {   // PPENV_TA_KERNEL=lane|quad forces a mapping (same arithmetic; the quad kernel needs the G1 tree)
+    {   // PPENV_TA_KERNEL=lane|quad|chain forces a mapping (same arithmetic; quad needs the G1 tree, chain the compiled G1 model)
         const char* k = getenv("PPENV_TA_KERNEL");
         s->quad = quad_topology(s->host) && !(k && strcmp(k, "lane") == 0);
+        s->chain = ta_chain_model_matches(s->host) && !(k && (strcmp(k, "lane") == 0 || strcmp(k, "quad") == 0));
+        if (k && strcmp(k, "chain") == 0 && !s->chain) {
+            ppenv_set_error("PPENV_TA_KERNEL=chain, but the model differs from the one compiled into the chain-wave kernel (run python -m isaacgym_amd.modelgen_ta and rebuild)");
+            delete s;
+            return PPENV_EINVAL;
+        }
     }
+    s->status_host = s->status_dev = nullptr;
     // the handle lives on scene->device_id when that names a visible GPU (the caller's current device otherwise)
     int ndev = 0;
     s->device = -1;
@@ -589,11 +613,21 @@ int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, 
         delete s;
         return PPENV_EHIP;
     }
+    if (hipHostMalloc((void**)&s->status_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&s->status_dev, s->status_host, 0) != hipSuccess) {
+        ppenv_set_error("ppenv_ta_sim_create: allocating the device status word failed");
+        if (s->status_host) (void)hipHostFree(s->status_host);
+        (void)hipFree(s->dev); (void)hipFree(s->devK);
+        delete s;
+        return PPENV_ENOMEM;
+    }
+    *s->status_host = 0u;
     // pageable host source: the copy is staged before the call returns, the struct may be reused by the caller
     if (hipMemcpyAsync(s->dev, &s->host, sizeof(TAConsts), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
         hipMemcpyAsync(s->devK, &s->K, sizeof(StepConsts), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
         (void)hipFree(s->dev);
         (void)hipFree(s->devK);
+        (void)hipHostFree(s->status_host);
         delete s;
         ppenv_set_error("ppenv_ta_sim_create: uploading the model constants failed");
         return PPENV_EHIP;
@@ -607,6 +641,7 @@ void ppenv_ta_sim_destroy(ppenv_ta_sim* s) {
     (void)ta_use_device(s);
     if (s->dev) (void)hipFree(s->dev);
     if (s->devK) (void)hipFree(s->devK);
+    if (s->status_host) (void)hipHostFree(s->status_host);
     delete s;
 }
 
@@ -631,13 +666,23 @@ int ppenv_ta_step(ppenv_ta_sim* s, const ppenv_ta_params* params, const float* a
                   float* dof_states_dev, float* rb_states_dev, float* dof_force_dev, float* pre_ball_vx_dev, const float* reset_override_dev,
                   uint32_t* flags_dev, uint32_t* episode_dev, int64_t* progress_dev, float* obs_dev, float* rew_dev, int64_t* reset_dev,
                   uint32_t* scratch_any_reset_dev, void* stream) {
-    if (!s || !params || params->num_envs <= 0 || !actions_dev || !initial_rb_states_dev || !root_states_dev || !dof_states_dev || !rb_states_dev ||
+    if (!s || !params || params->num_envs <= 0 || !actions_dev || !initial_rb_states_dev || !root_states_dev || !dof_states_dev ||
         !dof_force_dev || !pre_ball_vx_dev || !flags_dev || !episode_dev || !progress_dev || !obs_dev || !rew_dev || !reset_dev || !scratch_any_reset_dev) {
         ppenv_set_error("ppenv_ta_step: NULL argument or num_envs <= 0");
         return PPENV_EINVAL;
     }
+    if (*(volatile uint32_t*)s->status_host != 0u) {
+        ppenv_set_error("ppenv_ta_step: an earlier launch reported a hand-off time-out (status word set): the state tensors of that launch were not stored; destroy the handle");
+        return PPENV_EDEVICE;
+    }
     const int n = params->num_envs;
     if (int rc = ta_use_device(s)) return rc;
+    if (s->chain) {   // one lane per env, one wave per limb; rigid_body_states only on request
+        TAChainArgs a{*params, s->devK, actions_dev, initial_rb_states_dev, root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev,
+                      reset_override_dev, flags_dev, episode_dev, (long long*)progress_dev, obs_dev, rew_dev, (long long*)reset_dev, scratch_any_reset_dev, s->status_dev};
+        return ta_chain_launch(s->host.sc, a, stream);
+    }
+    if (!rb_states_dev) { ppenv_set_error("ppenv_ta_step: rb_states may only be NULL with the chain-wave kernel (the compiled G1 model)"); return PPENV_EINVAL; }
     if (!s->quad) {   // another tree, or PPENV_TA_KERNEL=lane: the two launches
         int rc = ppenv_ta_simulate(s, n, actions_dev, root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev, stream);
         if (rc) return rc;

@@ -23,6 +23,15 @@ constexpr bool ta_id_formulas_match() {
     return true;
 }
 static_assert(ta_id_formulas_match(), "body id lists");
+// inverse maps: position of a rigid body in the balance / observation id lists, or -1
+__host__ __device__ constexpr int ta_bal_index(int body) {
+    for (int j = 0; j < TA_NBAL; j++) if (kTaBalIdTable[j] == body) return j;
+    return -1;
+}
+__host__ __device__ constexpr int ta_obs_index(int body) {
+    for (int j = 0; j < NB; j++) if (kTaObsIdTable[j] == body) return j;
+    return -1;
+}
 
 // sum over the NR lanes that share an env (NR = 4: the lanes of a quad, lane & 3 = role; every lane of the quad must call it)
 template <int NR>

@@ -88,18 +88,28 @@ class TASim:
         _lib.check(self.L.ppenv_ta_simulate(self.h, n, actions.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(), rb_states.data_ptr(),
                                             dof_force.data_ptr(), pre_ball_vx.data_ptr(), self._stream()))
 
+    @property
+    def kernel(self):
+        """Which kernel ppenv_ta_step launches: 'chain' (one lane per env, one wave per limb), 'quad' or 'lane'."""
+        return {2: "chain", 1: "quad", 0: "lane"}[int(self.L.ppenv_ta_sim_kernel(self.h))]
+
+    @property
+    def status(self):
+        return int(self.L.ppenv_ta_sim_status(self.h))
+
     def step(self, state, actions, initial_rb_states, root_states, dof_states, rb_states, dof_force, pre_ball_vx, reset_override=None):
-        """ppenv_ta_step: simulate + post_physics_step (on `state`: a TAState) in one launch."""
+        """ppenv_ta_step: simulate + post_physics_step (on `state`: a TAState) in one launch.  rb_states may be None with the
+        chain-wave kernel: rigid_body_states [N,42,13] is then not materialised."""
         n = self.num_envs
-        for t, k in ((actions, n * 27), (initial_rb_states, n * 42 * 13), (root_states, n * 39), (dof_states, n * 54), (rb_states, n * 42 * 13),
-                     (dof_force, n * 27), (pre_ball_vx, n)):
+        for t, k in ((actions, n * 27), (initial_rb_states, n * 42 * 13), (root_states, n * 39), (dof_states, n * 54),
+                     (dof_force, n * 27), (pre_ball_vx, n)) + (((rb_states, n * 42 * 13),) if rb_states is not None else ()):
             self._check(t, k)
         ov = None
         if reset_override is not None:
             ov = reset_override.to(self.device, torch.float32).reshape(n, 5).contiguous()
         _lib.check(self.L.ppenv_ta_step(
             self.h, C.byref(state.params), actions.data_ptr(), initial_rb_states.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(),
-            rb_states.data_ptr(), dof_force.data_ptr(), pre_ball_vx.data_ptr(), ov.data_ptr() if ov is not None else None, state.flags.data_ptr(),
+            rb_states.data_ptr() if rb_states is not None else None, dof_force.data_ptr(), pre_ball_vx.data_ptr(), ov.data_ptr() if ov is not None else None, state.flags.data_ptr(),
             state.episode.data_ptr(), state.progress_buf.data_ptr(), state.obs_buf.data_ptr(), state.rew_buf.data_ptr(), state.reset_buf.data_ptr(),
             state._any_reset.data_ptr(), self._stream()))
         if ov is not None:
@@ -132,7 +142,11 @@ class TAEnv:
     (ppenv_ta_step) plus the tiny count-flag clear; `fused=False` keeps the two launches (ppenv_ta_simulate +
     ppenv_ta_post_physics_step).  Surface: obs_buf [N,313], rew_buf, reset_buf, progress_buf, 27 actions."""
 
-    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_offset=0, env=None, fused=True):
+    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_offset=0, env=None, fused=True, materialize_rb=None):
+        """materialize_rb: write rigid_body_states [N,42,13] in every step (the reference's refresh_rigid_body_state_tensor, pre-reset
+        body states).  Default: only where the kernel needs the tensor itself (the two-launch path and the table-driven kernels);
+        the chain-wave kernel keeps the body states in registers and `rb_states` is then produced on demand by forward kinematics
+        of the CURRENT (post-reset) state."""
         self.fused = bool(fused)
         self.device = torch.device(device)
         n = self.num_envs = int(num_envs)
@@ -142,15 +156,16 @@ class TAEnv:
         self.state = TAState(self.params, device=self.device)
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
         self.root_states, self.dof_states = z(n, 3, 13), z(n, 27, 2)          # TA:187-193, 237-240
-        self.rb_states, self.dof_force_tensor, self.pre_ball_vx = z(n, 42, 13), z(n, 27), z(n)
+        self._rb_states, self.dof_force_tensor, self.pre_ball_vx = z(n, 42, 13), z(n, 27), z(n)
+        self.materialize_rb = bool(materialize_rb) if materialize_rb is not None else not (self.fused and self.sim.kernel == "chain")
         init = torch.tensor([[self.params.init_root[a][k] for k in range(7)] for a in range(3)], dtype=torch.float32, device=self.device)
         self.root_states[:, :, 0:7] = init
         # creation = episode 0: the serve and ball position every env starts with come from the same keyed draws a reset uses
         ov = scene.ta_reset_draws(self.params, torch.arange(n), torch.zeros(n, dtype=torch.int64))
         self.root_states[:, 2, 1:3] = ov[:, 0:2].to(self.device)
         self.root_states[:, 2, 7:10] = ov[:, 2:5].to(self.device)
-        self.sim.forward_kinematics(self.root_states, self.dof_states, self.rb_states)
-        self.initial_rb_states = self.rb_states.clone()                       # TA:1152 initial_body_states
+        self.sim.forward_kinematics(self.root_states, self.dof_states, self._rb_states)
+        self.initial_rb_states = self._rb_states.clone()                      # TA:1152 initial_body_states
         self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf = self.state.obs_buf, self.state.rew_buf, self.state.reset_buf, self.state.progress_buf
         self.reset_buf.fill_(1)   # upstream VecTask.allocate_buffers
 
@@ -158,12 +173,20 @@ class TAEnv:
         if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if self.fused:
-            self.sim.step(self.state, actions, self.initial_rb_states, self.root_states, self.dof_states, self.rb_states, self.dof_force_tensor,
-                          self.pre_ball_vx)
+            self.sim.step(self.state, actions, self.initial_rb_states, self.root_states, self.dof_states,
+                          self._rb_states if self.materialize_rb else None, self.dof_force_tensor, self.pre_ball_vx)
         else:
-            self.sim.simulate(actions, self.root_states, self.dof_states, self.rb_states, self.dof_force_tensor, self.pre_ball_vx)
-            self.state.post_physics_step(self.rb_states, self.initial_rb_states, self.root_states, self.dof_states, self.dof_force_tensor, self.pre_ball_vx)
+            self.sim.simulate(actions, self.root_states, self.dof_states, self._rb_states, self.dof_force_tensor, self.pre_ball_vx)
+            self.state.post_physics_step(self._rb_states, self.initial_rb_states, self.root_states, self.dof_states, self.dof_force_tensor, self.pre_ball_vx)
         return {"obs": self.obs_buf}, self.rew_buf, self.reset_buf, {}
+
+    @property
+    def rb_states(self):
+        """rigid_body_states [N,42,13].  Materialised by the step when `materialize_rb`; otherwise gym.refresh_rigid_body_state_tensor
+        on demand: forward kinematics of the current root / dof states (which, for an env that has just reset, are the reset ones)."""
+        if not self.materialize_rb:
+            self.sim.forward_kinematics(self.root_states, self.dof_states, self._rb_states)
+        return self._rb_states
 
     def reset_idx(self, env_ids=None):
         """_reset_idx (TA:965-1028) outside a step, for the listed env ids (None: all).  A rare host-driven path: plain torch

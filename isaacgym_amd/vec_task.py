@@ -319,10 +319,16 @@ class HumanoidPingpongTiltNESSparse27DOF(VecTask):
         self.root_states = self.vec_root_states = e.root_states
         self.vec_dof_states = e.dof_states
         self.dof_pos, self.dof_vel = e.dof_states[..., 0], e.dof_states[..., 1]
-        self.body_states = self.vec_rb_states = e.rb_states
         self.initial_body_states = e.initial_rb_states
         self.dof_force_tensor = e.dof_force_tensor
         return e
+
+    @property
+    def body_states(self):
+        """rigid_body_states [N,42,13] (TA:195-200); refreshed on demand when the step does not materialise it (TAEnv.rb_states)."""
+        return self.env.rb_states
+
+    vec_rb_states = body_states
 
     def step(self, actions):
         self.env.step(actions)              # the clipActions clamp happens inside the kernel

@@ -54,6 +54,18 @@ def test_generated_model_header_is_current():
     assert modelgen.is_current(), "isaacgym_amd/csrc/ppenv_model_g1.h is stale: run `python -m isaacgym_amd.modelgen`"
 
 
+def test_generated_27dof_model_header_is_current_and_equals_the_runtime_tables():
+    """csrc/ppenv_model_g1_ta.h (compiled into the chain-wave kernel) is what modelgen_ta writes today, and its values equal, bit for
+    bit, what the library derives from the run-time model (make_ta_consts) — otherwise ppenv_ta_step would silently fall back."""
+    from isaacgym_amd import modelgen_ta
+    assert modelgen_ta.is_current(), "isaacgym_amd/csrc/ppenv_model_g1_ta.h is stale: run `python -m isaacgym_amd.modelgen_ta` and rebuild"
+    L = _lib.lib()
+    cfg, m = scene.build_ta_scene(4), scene.build_ta_model()
+    assert L.ppenv_ta_model_is_compiled(C.byref(cfg), C.byref(m)) == 1
+    m.link[5].mass *= 1.5                       # any other model: not the compiled one (the table-driven kernels serve it)
+    assert L.ppenv_ta_model_is_compiled(C.byref(cfg), C.byref(m)) == 0
+
+
 def test_reference_constants_in_config():
     """Constants the reference states verbatim."""
     tt = scene.build_config("TT", num_envs=4)

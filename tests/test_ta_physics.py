@@ -224,13 +224,16 @@ def test_ta_vec_task_surface():
 
 
 @pytest.mark.gpu
-def test_ta_fused_step_equals_the_two_launches():
-    """ppenv_ta_step (task arithmetic on the rigid-body kernel's LDS tiles) vs ppenv_ta_simulate + ppenv_ta_post_physics_step
-    (pinned to the reference's post_physics_step by post_physics_TA.npz): same tensors after every step, through resets."""
+def test_ta_fused_step_equals_the_two_launches(monkeypatch):
+    """ppenv_ta_step with the four-lanes-per-env kernel (task arithmetic on the rigid-body kernel's LDS tiles) vs ppenv_ta_simulate +
+    ppenv_ta_post_physics_step (pinned to the reference's post_physics_step by post_physics_TA.npz): the same arithmetic, so the same
+    tensors after every step of a free-running rollout, through resets."""
     import torch
     from isaacgym_amd.tensor_api import TAEnv
+    monkeypatch.setenv("PPENV_TA_KERNEL", "quad")
     n = 1000   # ragged last workgroup
     a_, b_ = TAEnv(n, device="cuda:0", seed=3, fused=True), TAEnv(n, device="cuda:0", seed=3, fused=False)
+    assert a_.sim.kernel == "quad"
     gen = torch.Generator(device="cuda").manual_seed(1)
     for t in range(170):     # past the 160-step time-out: every env resets once
         a = torch.rand(n, 27, device="cuda", generator=gen) * 2 - 1
@@ -244,3 +247,111 @@ def test_ta_fused_step_equals_the_two_launches():
             assert torch.allclose(x, y, rtol=1e-6, atol=1e-6), (name, t, float((x - y).abs().max()))
     assert int(a_.state.episode.sum()) == n
     a_.close(); b_.close()
+
+
+def _ta_obs_atol():
+    """Per-column atol of the 313-wide row: body pos / vel (TA:1849-1888), dofs, ball (+ y intercept), imitation blocks (TA:1891-1927)."""
+    a = np.empty(scene.TA_NUM_OBS, np.float64)
+    a[0:30] = TOL["rb_pos"]
+    a[30:60] = TOL["rb_vel"]
+    a[60:87] = TOL["q"]
+    a[87:114] = TOL["qd"] * 0.1
+    a[114:117] = 3e-4
+    a[117:120] = 2e-3
+    a[120] = 5e-3                      # y + (vy / (-vx + 1e-6)) x: a quotient of ball velocities
+    a[121:190] = 10 * TOL["rb_pos"]    # 10 x position differences
+    a[190:259] = TOL["rb_vel"]
+    a[259:313] = 0.0                   # constants
+    return a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [640, 1000, 50])
+def test_ta_chain_kernel_step_matches_oracle(oracle_lib, monkeypatch, n):
+    """The chain-wave kernel (one lane per env, one wave per limb: ppenv_ta_chain.hip) through ppenv_ta_step, against the oracle's
+    rigid-body step followed by its post_physics_step, restarted from the oracle's tensors every step.  n = 1000 / 50 leave a
+    ragged last workgroup; episodeLength 40 makes every env reset (with the keyed draws) inside the run."""
+    import torch
+    from isaacgym_amd.tensor_api import TAEnv
+    monkeypatch.setenv("PPENV_TA_KERNEL", "chain")
+    cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
+    env = TAEnv(n, device="cuda:0", seed=11, env={"episodeLength": 40}, materialize_rb=True)
+    assert env.sim.kernel == "chain"
+    p = env.params
+    root, dof = env.root_states.cpu().numpy().copy(), env.dof_states.cpu().numpy().copy()
+    irb = env.initial_rb_states.cpu().numpy().copy()
+    flags, episode, progress = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64)
+    rng = np.random.default_rng(5)
+    oa = _ta_obs_atol()
+    log = ExclusionLog(f"gpu 27-dof chain-wave step vs oracle [n={n}]", bound=20 / (90 * n))
+    resets = 0
+    act = None
+    for t in range(90):
+        if t % 4 == 0:
+            act = rng.uniform(-1.2, 1.2, (n, 27)).astype(np.float32)
+            act[: n // 3] *= 0.1
+        env.root_states.copy_(torch.from_numpy(root)); env.dof_states.copy_(torch.from_numpy(dof))
+        env.state.flags.copy_(torch.from_numpy(flags.view(np.int32))); env.state.episode.copy_(torch.from_numpy(episode.view(np.int32)))
+        env.state.progress_buf.copy_(torch.from_numpy(progress))
+        env.step(torch.from_numpy(act).cuda())
+        ball_before = root[:, 2, 7:10].copy()
+        rb, frc, pvx = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=8)         # root / dof: stepped in place (pre-reset)
+        pre_root, pre_dof = root.copy(), dof.copy()
+        obs, rew, reset = oracle_lib.ta_post_physics_step(p, rb, irb, root, dof, frc, pvx, None, flags, episode, progress)
+        g_rb = env._rb_states.cpu().numpy()
+        np.testing.assert_array_equal(env.pre_ball_vx.cpu().numpy(), pvx)
+        # the ball's contact decisions are discrete: an env whose stepped ball differs took another branch (cf. the quad test above)
+        keep = ~(np.abs(g_rb[:, 41, 7:10] - rb[:, 41, 7:10]).max(axis=1) > 1e-3)
+        log.add(keep)
+        # pre-reset physics through the materialised rigid_body_states; post-reset tensors against the oracle's
+        assert_close(g_rb[keep][..., 0:3], rb[keep][..., 0:3], f"step {t}: body pos", atol=TOL["rb_pos"])
+        assert_close(g_rb[keep][..., 7:10], rb[keep][..., 7:10], f"step {t}: body vel", atol=TOL["rb_vel"])
+        assert_close(g_rb[keep][..., 10:13], rb[keep][..., 10:13], f"step {t}: body ang vel", atol=TOL["rb_ang"])
+        sign = np.sign(np.sum(g_rb[..., 3:7] * rb[..., 3:7], axis=-1, keepdims=True))
+        assert_close((g_rb[..., 3:7] * sign)[keep], rb[keep][..., 3:7], f"step {t}: body quat", atol=2e-4)
+        assert_close(env.dof_force_tensor.cpu().numpy()[keep], frc[keep], f"step {t}: dof force", atol=TOL["frc"])
+        g_root, g_dof = env.root_states.cpu().numpy(), env.dof_states.cpu().numpy()
+        np.testing.assert_array_equal(env.reset_buf.cpu().numpy(), reset)
+        np.testing.assert_array_equal(env.progress_buf.cpu().numpy(), progress)
+        np.testing.assert_array_equal(env.state.episode.cpu().numpy().view(np.uint32), episode)
+        np.testing.assert_array_equal(env.state.flags.cpu().numpy().view(np.uint32)[keep], flags[keep])
+        check_step((g_root[keep], g_dof[keep], g_rb[keep][:, :40], env.dof_force_tensor.cpu().numpy()[keep]),
+                   (root[keep], dof[keep], rb[keep][:, :40], frc[keep]), f"step {t}")
+        assert_close(env.obs_buf.cpu().numpy()[keep], obs[keep], f"step {t}: obs", atol=oa)
+        assert_close(env.rew_buf.cpu().numpy()[keep], rew[keep], f"step {t}: rew", atol=1e-4 * 3000.0 * 0.5)   # alpha |vx| dominates (TA:1590)
+        resets += int(reset.sum())
+        flags[~keep] = env.state.flags.cpu().numpy().view(np.uint32)[~keep]                 # continue from a common state
+    assert resets >= 2 * n
+    log.close()
+    assert env.sim.status == 0
+    env.close()
+
+
+@pytest.mark.gpu
+def test_ta_chain_kernel_clears_count_flags_across_workgroups_and_skips_rb(monkeypatch):
+    """TA:1162-1166 inside the one launch: when any env resets, the workgroup that finishes last clears every env's count flags
+    and leaves the scratch word zero.  Without a rigid_body_states buffer the step stores none, and `rb_states` is forward
+    kinematics on demand."""
+    import torch
+    from isaacgym_amd.tensor_api import TAEnv
+    monkeypatch.setenv("PPENV_TA_KERNEL", "chain")
+    n = 1500
+    env = TAEnv(n, device="cuda:0", seed=2, env={"episodeLength": 30})
+    assert env.sim.kernel == "chain" and not env.materialize_rb
+    env.state.flags.fill_(scene.TA_COUNT_MASK)            # every env carries count flags
+    env.state.progress_buf[:] = 0
+    env.state.progress_buf[n - 1] = 27                    # ... and one env of the LAST workgroup times out in this step
+    sentinel = env._rb_states.clone().fill_(123.0)
+    env._rb_states.copy_(sentinel)
+    env.step(torch.zeros(n, 27, device="cuda"))
+    torch.cuda.synchronize()
+    assert int(env.reset_buf.sum()) == 1 and int(env.reset_buf[n - 1]) == 1
+    assert int((env.state.flags & scene.TA_COUNT_MASK).abs().sum()) == 0
+    assert int(env.state._any_reset.item()) == 0          # the ticket word is zero again
+    assert torch.equal(env._rb_states, sentinel)          # not materialised
+    rb = env.rb_states                                    # on demand
+    assert float(rb[:, :40, 2].min()) > scene.TA_GROUND_Z - 0.2 and not torch.equal(rb, sentinel)
+    env.step(torch.zeros(n, 27, device="cuda"))           # nobody resets: count flags may come back, the word stays zero
+    torch.cuda.synchronize()
+    assert int(env.reset_buf.sum()) == 0 and int(env.state._any_reset.item()) == 0
+    env.close()
