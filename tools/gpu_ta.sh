@@ -8,7 +8,7 @@ timeout -k 10 300 python - <<'PY'
 import time, torch
 from isaacgym_amd.tensor_api import TAEnv
 import os
-for mapping, n in (("quad", 4096), ("lane", 4096), ("quad", 16384)):
+for mapping, n in (("chain", 4096), ("quad", 4096), ("chain", 16384), ("chain", 65536), ("quad", 16384)):
     os.environ["PPENV_TA_KERNEL"] = mapping
     env = TAEnv(n, device="cuda:0")
     gen = torch.Generator(device="cuda").manual_seed(0)
