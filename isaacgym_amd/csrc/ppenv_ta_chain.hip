@@ -49,6 +49,21 @@ enum { W_LL = 0, W_RL = 1, W_WAIST = 2, W_LA = 3, W_RA = 4, W_BALL = 5 };
 constexpr int kTorso = 15;
 constexpr int kGeoW = 39, kGeoRA = 48; // floats of collision geometry the waist / right-arm wave hand to the ball wave
 
+// Diagnostic builds only (-DTA_STAMP, tools/gpu_ta_chain_stamps.py): shader-clock stamps per workgroup and wave.
+#if defined(TA_STAMP)
+__device__ unsigned long long ta_chain_stamp_buf[1024 * 6 * 32];
+#define CH_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (lane == 0 && blockIdx.x < 1024) ta_chain_stamp_buf[(blockIdx.x * 6 + wave) * 32 + (k)] = t_; \
+    } while (0)
+#else
+#define CH_STAMP(k) do { } while (0)
+#endif
+
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>)
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -405,6 +420,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     bool dead = false;                            // a hand-off timed out: finish without storing (TA_AWAIT)
     const int substeps = P.substeps;
 
+    CH_STAMP(0);
     if (tid < 12) (&S.f_torso)[tid] = 0;          // the eleven sequence numbers and `dead`
     // inputs -> LDS, coalesced: the workgroup's blocks of dof_states [N,27,2], actions [N,27], root_states [N,3,13]
     for (int t = tid; t < nvalid * 2 * NDOF; t += kWaves * 64) {
@@ -429,6 +445,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     }
     __syncthreads();
 
+    CH_STAMP(1);
     // ---- physics: every wave runs its own role, start to finish (its limb's state lives in ITS registers only; the substep loop is
     // inside the role so that no other role's variables are live across it) -----------------------------------------------------
     auto no_geo = [](auto, const Frame&) {};
@@ -437,13 +454,18 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         L.load(S, e);
         for (int sub = 0; sub < substeps; sub++) {
             if (sub > 0) TA_AWAIT(&S.f_base, sub);                  // the base state of this substep
+            CH_STAMP(2 + 8 * (sub & 1));
             L.pass1(base_frame(S.root, e), no_geo);
+            CH_STAMP(3 + 8 * (sub & 1));
             const ArtI up = L.pass2(P, art_zero());
             put_art(S.u.hub.art_leg[leg], e, up);
             publish(&S.f_leg[leg], sub + 1);
+            CH_STAMP(4 + 8 * (sub & 1));
             TA_AWAIT(&S.f_accb, sub + 1);
+            CH_STAMP(5 + 8 * (sub & 1));
             V3 aw = row3(S.u.hub.acc_base, 0, e), av = row3(S.u.hub.acc_base, 3, e);
             L.pass3(P, aw, av);
+            CH_STAMP(6 + 8 * (sub & 1));
         }
         L.store(S, e);
     };
@@ -452,6 +474,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         L.load(S, e);
         for (int sub = 0; sub < substeps; sub++) {
             TA_AWAIT(&S.f_torso, sub + 1);
+            CH_STAMP(2 + 8 * (sub & 1));
             const Frame ft = torso_frame(S, e);
             if constexpr (decltype(with_geo)::value) {              // the right arm carries collision shapes and the paddle
                 if (sub >= 2) TA_AWAIT(&S.f_ball, sub - 1);         // the ball wave is done with this geometry slot
@@ -462,12 +485,16 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             } else {
                 L.pass1(ft, no_geo);
             }
+            CH_STAMP(3 + 8 * (sub & 1));
             const ArtI up = L.pass2(P, art_zero());
             put_art(S.u.hub.art_arm[arm], e, up);
             publish(&S.f_arm[arm], sub + 1);
+            CH_STAMP(4 + 8 * (sub & 1));
             TA_AWAIT(&S.f_acct, sub + 1);
+            CH_STAMP(5 + 8 * (sub & 1));
             V3 aw = row3(S.u.hub.acc_torso, 0, e), av = row3(S.u.hub.acc_torso, 3, e);
             L.pass3(P, aw, av);
+            CH_STAMP(6 + 8 * (sub & 1));
         }
         L.store(S, e);
     };
@@ -481,6 +508,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         base.ww = row3(S.root, 10, e);
         for (int sub = 0; sub < substeps; sub++) {
             if (sub >= 2) TA_AWAIT(&S.f_ball, sub - 1);             // the ball wave is done with this geometry slot
+            CH_STAMP(2 + 8 * (sub & 1));
             const Frame f0 = base_frame(S.root, e);                 // (this wave's own write of the previous substep)
             int grow = 0;
             float (*gslot)[kE] = S.u.hub.geo_w[sub & 1];
@@ -495,21 +523,27 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             publish(&S.f_geo_w, sub + 1);
             constexpr CPTable cp = cp_table();
             constexpr LinkC L0 = T::link(0);
+            CH_STAMP(3 + 8 * (sub & 1));
             ArtI I0 = link_dynamics(P, L0, cp.p, f0.Rw, f0.pw, f0.w, f0.v);
+            CH_STAMP(7 + 8 * (sub & 1));
             TA_AWAIT(&S.f_arm[0], sub + 1);
             TA_AWAIT(&S.f_arm[1], sub + 1);
+            CH_STAMP(4 + 8 * (sub & 1));
             ArtI arms = get_art(S.u.hub.art_arm[0], e);
             add_art(arms, get_art(S.u.hub.art_arm[1], e));
             const ArtI up = WA.pass2(P, arms);
             add_art(I0, up);
+            CH_STAMP(8 + 8 * (sub & 1));
             TA_AWAIT(&S.f_leg[0], sub + 1);
             TA_AWAIT(&S.f_leg[1], sub + 1);
+            CH_STAMP(9 + 8 * (sub & 1));
             add_art(I0, get_art(S.u.hub.art_leg[0], e));
             add_art(I0, get_art(S.u.hub.art_leg[1], e));
             V3 alpha, acc;
             solve_base_art(I0, alpha, acc);
             put3(S.u.hub.acc_base, 0, e, alpha); put3(S.u.hub.acc_base, 3, e, acc);
             publish(&S.f_accb, sub + 1);
+            CH_STAMP(5 + 8 * (sub & 1));
             V3 aw = alpha, av = acc;
             WA.pass3(P, aw, av);                                    // leaves the torso's acceleration in (aw, av)
             put3(S.u.hub.acc_torso, 0, e, aw); put3(S.u.hub.acc_torso, 3, e, av);
@@ -519,6 +553,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             for (int k = 0; k < 4; k++) S.root[3 + k][e] = base.quat[k];
             put3(S.root, 7, e, base.vw); put3(S.root, 10, e, base.ww);
             publish(&S.f_base, sub + 1);
+            CH_STAMP(6 + 8 * (sub & 1));
         }
         WA.store(S, e);
     };
@@ -533,6 +568,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         for (int sub = 0; sub < substeps; sub++) {
             TA_AWAIT(&S.f_geo_w, sub + 1);
             TA_AWAIT(&S.f_geo_ra, sub + 1);
+            CH_STAMP(2 + 8 * (sub & 1));
             constexpr GeoMap gm = geo_map();
             ArmGeom<ModelG1TA::kShapes> g[1];
             V3 bound[1];
@@ -550,6 +586,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             }
             ball_substep<ModelG1TA, 1>(*a.K, ball, g, bound);
             publish(&S.f_ball, sub + 1);
+            CH_STAMP(6 + 8 * (sub & 1));
         }
         put3(S.root, 26, e, ball.p);
         for (int k = 0; k < 4; k++) S.root[29 + k][e] = ball.quat[k];
@@ -561,7 +598,9 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     else if (wave == W_LA) arm_role(std::common_type<Limb<16, 7>>{}, 0, std::false_type{});
     else if (wave == W_RA) arm_role(std::common_type<Limb<23, 5>>{}, 1, std::true_type{});
     else ball_role();
+    CH_STAMP(20);
     __syncthreads();   // B1: the hubs are dead from here on (their memory becomes the observation tile)
+    CH_STAMP(21);
 
     // ---- final phase 1: kinematics of the new state; every rigid body's share of the reward sums and of the observation row ----
     float* const orow = &S.u.obs[e * PPENV_TA_NUM_OBS];
@@ -599,7 +638,9 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             for (int k = 0; k < 13; k++) { rb[40 * 13 + k] = S.root[13 + k][e]; rb[41 * 13 + k] = S.root[26 + k][e]; }
         }
     }
+    CH_STAMP(22);
     __syncthreads();   // B2
+    CH_STAMP(23);
 
     // ---- final phase 2 (ball wave): reward, reset, the rest of the row — ppenv_ta_task.h ta_task_env, one lane per env ---------
     if (wave == W_BALL) {
@@ -745,7 +786,9 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             if (lane == 0) __hip_atomic_store(a.scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
         }
     }
+    CH_STAMP(24);
     __syncthreads();   // B3
+    CH_STAMP(25);
 
     // ---- final phase 3: the tiles leave as the workgroup's contiguous blocks ------------------------------------------------------
     if (S.dead) return;
@@ -763,8 +806,16 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     }
     tile_out<NDOF>(a.dof_force + (size_t)e0 * NDOF, S.act_frc, nvalid, tid);
     tile_out<39>(a.root_states + (size_t)e0 * 39, S.root, nvalid, tid);
+    CH_STAMP(26);
 }
 }  // namespace
+
+#if defined(TA_STAMP)
+extern "C" int ppenv_ta_chain_debug_read_stamps(unsigned long long* dst, size_t count) {
+    if (hipDeviceSynchronize() != hipSuccess) return PPENV_EHIP;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ta_chain_stamp_buf), count * sizeof(unsigned long long)) == hipSuccess ? 0 : PPENV_EHIP;
+}
+#endif
 
 namespace pp {
 namespace ta {
