@@ -45,7 +45,12 @@ namespace {
 using T = ModelG1Tree;
 constexpr int kE = 64;                 // envs per workgroup = lanes per wave
 constexpr int kWaves = 6;
-enum { W_LL = 0, W_RL = 1, W_WAIST = 2, W_LA = 3, W_RA = 4, W_BALL = 5 };
+// Role -> wave index.  A workgroup's waves are dealt round-robin over the CU's four SIMDs (wave i on SIMD i & 3), so six waves
+// leave two SIMDs with two waves each.  The critical path is waist -> arms -> waist; the legs finish early and the ball wave is
+// short.  The arms therefore get SIMDs 2 and 3 to themselves, the waist shares SIMD 0 with the left leg (it waits for the arms
+// while the leg works) and the right leg shares SIMD 1 with the ball.  (Measured with the first numbering — right arm on the
+// left leg's SIMD: the right arm's five links took 15.7k cycles against 11k for the left arm's seven.)
+enum { W_WAIST = 0, W_RL = 1, W_LA = 2, W_RA = 3, W_LL = 4, W_BALL = 5 };
 constexpr int kTorso = 15;
 constexpr int kGeoW = 39, kGeoRA = 48; // floats of collision geometry the waist / right-arm wave hand to the ball wave
 
@@ -257,15 +262,33 @@ struct TaskCtx {
     float hinv[4];
     V3 rootp;
     float pos_acc, vel_acc, norm_acc;
+    float irb[tatask::TA_NBAL][6];   // initial position / velocity of the balance bodies THIS wave owns (the other entries are never touched)
 };
+// issue the loads of the initial body states of link LI's bodies (uncoalesced: 52-byte rows at a 2184-byte stride); they are consumed by body_out
+template <int BODY>
+__device__ __forceinline__ void prefetch_body(TaskCtx& c) {
+    constexpr int jb = tatask::ta_bal_index(BODY);
+    if constexpr (jb >= 0) {
+        const float* r = c.a.initial_rb + ((size_t)c.env * PPENV_NUM_BODIES + BODY) * 13;
+        c.irb[jb][0] = r[0]; c.irb[jb][1] = r[1]; c.irb[jb][2] = r[2]; c.irb[jb][3] = r[7]; c.irb[jb][4] = r[8]; c.irb[jb][5] = r[9];
+    }
+}
+template <int FIRST, int N>
+__device__ __forceinline__ void prefetch_limb(TaskCtx& c) {
+    static_for<N>([&](auto kc) {
+        constexpr LinkC L = T::link(FIRST + decltype(kc)::value);
+        prefetch_body<L.body>(c);
+        static_for<L.fcount>([&](auto fc) { prefetch_body<T::fixed(L.ffirst + decltype(fc)::value).body>(c); });
+    });
+}
 // body `BODY` (Isaac Gym rigid-body index) at world position p, linear velocity v; R / w only feed the optional rigid_body_states row
 template <int BODY>
 __device__ __forceinline__ void body_out(TaskCtx& c, const M3& R, V3 p, V3 v, V3 wworld) {
     constexpr int jb = tatask::ta_bal_index(BODY), jo = tatask::ta_obs_index(BODY);
     float* o = &c.S.u.obs[c.e * PPENV_TA_NUM_OBS];
     if (jb >= 0) {                                                       // compute_imitation_reward TA:1313-1418, compute_imitation_observations TA:1891-1927
-        const float* r = c.a.initial_rb + ((size_t)c.env * PPENV_NUM_BODIES + BODY) * 13;
-        const float dp0 = r[0] - p.x, dp1 = r[1] - p.y, dp2 = r[2] - p.z, dv0 = r[7] - v.x, dv1 = r[8] - v.y, dv2 = r[9] - v.z;
+        const float* r = c.irb[jb];                                      // prefetched (prefetch_limb)
+        const float dp0 = r[0] - p.x, dp1 = r[1] - p.y, dp2 = r[2] - p.z, dv0 = r[3] - v.x, dv1 = r[4] - v.y, dv2 = r[5] - v.z;
         c.pos_acc += (dp0 * dp0 + dp1 * dp1 + dp2 * dp2) / 3.0f;
         c.vel_acc += (dv0 * dv0 + dv1 * dv1 + dv2 * dv2) / 3.0f;
         c.norm_acc += sqrtf(dp0 * dp0 + dp1 * dp1 + dp2 * dp2);
@@ -422,23 +445,73 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
 
     CH_STAMP(0);
     if (tid < 12) (&S.f_torso)[tid] = 0;          // the eleven sequence numbers and `dead`
-    // inputs -> LDS, coalesced: the workgroup's blocks of dof_states [N,27,2], actions [N,27], root_states [N,3,13]
-    for (int t = tid; t < nvalid * 2 * NDOF; t += kWaves * 64) {
-        const int ee = t / (2 * NDOF), c = t - ee * 2 * NDOF;
-        const float v = a.dof_states[(size_t)e0 * 2 * NDOF + t];
-        if (c & 1) S.qd[c >> 1][ee] = v; else S.q[c >> 1][ee] = v;
+    // inputs -> LDS, coalesced: the workgroup's blocks of dof_states [N,27,2], actions [N,27], root_states [N,3,13].  A full
+    // workgroup moves them as float4 with constant trip counts (every load of the three tensors is in flight before the first LDS
+    // store); a ragged last one element by element.
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    if (nvalid == kE) {
+        constexpr int kThreads = kWaves * 64;
+        constexpr int nD = kE * 2 * NDOF / 4, nA = kE * NDOF / 4, nR = kE * 39 / 4;
+        static_assert(kE * 2 * NDOF % 4 == 0 && kE * NDOF % 4 == 0 && kE * 39 % 4 == 0, "float4 staging");
+        constexpr int tD = (nD + kThreads - 1) / kThreads, tA = (nA + kThreads - 1) / kThreads, tR = (nR + kThreads - 1) / kThreads;
+        f4v vd[tD], va[tA], vr[tR];
+        const f4v* sd = reinterpret_cast<const f4v*>(a.dof_states + (size_t)e0 * 2 * NDOF);
+        const f4v* sa = reinterpret_cast<const f4v*>(a.actions + (size_t)e0 * NDOF);
+        const f4v* sr = reinterpret_cast<const f4v*>(a.root_states + (size_t)e0 * 39);
+#pragma unroll
+        for (int it = 0; it < tD; it++) { const int i = it * kThreads + tid; vd[it] = i < nD ? sd[i] : f4v{0, 0, 0, 0}; }
+#pragma unroll
+        for (int it = 0; it < tA; it++) { const int i = it * kThreads + tid; va[it] = i < nA ? sa[i] : f4v{0, 0, 0, 0}; }
+#pragma unroll
+        for (int it = 0; it < tR; it++) { const int i = it * kThreads + tid; vr[it] = i < nR ? sr[i] : f4v{0, 0, 0, 0}; }
+#pragma unroll
+        for (int it = 0; it < tD; it++) {
+            const int i = it * kThreads + tid;
+            if (i < nD) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int t = 4 * i + k, ee = t / (2 * NDOF), c = t - ee * 2 * NDOF;
+                    if (c & 1) S.qd[c >> 1][ee] = vd[it][k]; else S.q[c >> 1][ee] = vd[it][k];
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < tA; it++) {
+            const int i = it * kThreads + tid;
+            if (i < nA) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int t = 4 * i + k, ee = t / NDOF, d = t - ee * NDOF;
+                    const LinkC L = T::link(d + 1);   // (a run-time index: the one place where the lanes of a wave look at different dofs)
+                    S.act_frc[d][ee] = pd_target(va[it][k], L.lo, L.hi, P.clip_actions);   // VecTask.step clamp + TA:1131, 729-733
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < tR; it++) {
+            const int i = it * kThreads + tid;
+            if (i < nR) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int t = 4 * i + k, ee = t / 39, c = t - ee * 39; S.root[c][ee] = vr[it][k]; }
+            }
+        }
+    } else {
+        for (int t = tid; t < nvalid * 2 * NDOF; t += kWaves * 64) {
+            const int ee = t / (2 * NDOF), c = t - ee * 2 * NDOF;
+            const float v = a.dof_states[(size_t)e0 * 2 * NDOF + t];
+            if (c & 1) S.qd[c >> 1][ee] = v; else S.q[c >> 1][ee] = v;
+        }
+        for (int t = tid; t < nvalid * NDOF; t += kWaves * 64) {
+            const int ee = t / NDOF, d = t - ee * NDOF;
+            const LinkC L = T::link(d + 1);
+            S.act_frc[d][ee] = pd_target(a.actions[(size_t)e0 * NDOF + t], L.lo, L.hi, P.clip_actions);
+        }
+        tile_in<39>(S.root, a.root_states + (size_t)e0 * 39, nvalid, tid);
     }
-    for (int t = tid; t < nvalid * NDOF; t += kWaves * 64) {
-        const int ee = t / NDOF, d = t - ee * NDOF;
-        // (a run-time index into the link table: this loop is the one place where the lanes of a wave look at different dofs)
-        const LinkC L = T::link(d + 1);
-        S.act_frc[d][ee] = pd_target(a.actions[(size_t)e0 * NDOF + t], L.lo, L.hi, P.clip_actions);   // VecTask.step clamp + TA:1131, 729-733
-    }
-    tile_in<39>(S.root, a.root_states + (size_t)e0 * 39, nvalid, tid);
     __syncthreads();
     if (!live) {   // a ragged last workgroup: give the idle lanes a valid state to chew on (copies of its last env)
         const int src = nvalid - 1;
-        if (wave == 0) {
+        if (wave == W_WAIST) {
             for (int d = 0; d < NDOF; d++) { S.q[d][e] = S.q[d][src]; S.qd[d][e] = S.qd[d][src]; S.act_frc[d][e] = S.act_frc[d][src]; }
             for (int k = 0; k < 39; k++) S.root[k][e] = S.root[k][src];
         }
@@ -510,16 +583,24 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             if (sub >= 2) TA_AWAIT(&S.f_ball, sub - 1);             // the ball wave is done with this geometry slot
             CH_STAMP(2 + 8 * (sub & 1));
             const Frame f0 = base_frame(S.root, e);                 // (this wave's own write of the previous substep)
-            int grow = 0;
-            float (*gslot)[kE] = S.u.hub.geo_w[sub & 1];
-            geo_capture<0, kGeoW>(gslot, e, f0, grow);
-            WA.pass1(f0, [&](auto lc, const Frame& f) { geo_capture<decltype(lc)::value, kGeoW>(gslot, e, f, grow); });
-            {
+            WA.pass1(f0, no_geo);
+            {   // the arms wait for this: the torso's pose leaves before anything else is done with the frames
                 Frame ft;
                 ft.Rw = WA.sv[2].Rw; ft.pw = WA.sv[2].pw; ft.w = WA.sv[2].w; ft.v = WA.sv[2].v;
                 put_torso(S, e, ft);
             }
             publish(&S.f_torso, sub + 1);
+            {   // collision geometry of the pelvis / torso shapes for the ball wave
+                int grow = 0;
+                float (*gslot)[kE] = S.u.hub.geo_w[sub & 1];
+                geo_capture<0, kGeoW>(gslot, e, f0, grow);
+                static_for<3>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    Frame f;
+                    f.Rw = WA.sv[k].Rw; f.pw = WA.sv[k].pw; f.w = WA.sv[k].w; f.v = WA.sv[k].v;
+                    geo_capture<13 + k, kGeoW>(gslot, e, f, grow);
+                });
+            }
             publish(&S.f_geo_w, sub + 1);
             constexpr CPTable cp = cp_table();
             constexpr LinkC L0 = T::link(0);
@@ -602,10 +683,20 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     __syncthreads();   // B1: the hubs are dead from here on (their memory becomes the observation tile)
     CH_STAMP(21);
 
-    // ---- final phase 1: kinematics of the new state; every rigid body's share of the reward sums and of the observation row ----
+    // ---- final phase 1: kinematics of the new state; every rigid body's share of the reward sums and of the observation row.
+    // Meanwhile the ball wave does the part of the task arithmetic that only needs the dof tiles (ppenv_ta_task.h ta_task_env).
     float* const orow = &S.u.obs[e * PPENV_TA_NUM_OBS];
+    const ppenv_ta_params& p = a.p;
+    float s22 = 0.f, s5 = 0.f, sv = 0.f, power = 0.f;      // ball wave: carried over B2
+    uint32_t f = 0, ep_in = 0;
+    long long prog = 0;
     if (wave != W_BALL) {
-        TaskCtx c{a, S, e, env, {0, 0, 0, 0}, mk(0, 0, 0), 0.f, 0.f, 0.f};
+        TaskCtx c{a, S, e, env, {0, 0, 0, 0}, mk(0, 0, 0), 0.f, 0.f, 0.f, {}};
+        if (wave == W_LL) prefetch_limb<1, 6>(c);
+        else if (wave == W_RL) prefetch_limb<7, 6>(c);
+        else if (wave == W_WAIST) { prefetch_limb<0, 1>(c); prefetch_limb<13, 3>(c); }
+        else if (wave == W_LA) prefetch_limb<16, 7>(c);
+        else prefetch_limb<23, 5>(c);
         {
             const float rq[4] = {S.root[3][e], S.root[4][e], S.root[5][e], S.root[6][e]};
             heading_quat_inv(rq, c.hinv);                        // calc_heading_quat_inv of the (pre-reset) pelvis, TA:1862
@@ -630,10 +721,18 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         }
         S.sums[wave][0][e] = c.pos_acc; S.sums[wave][1][e] = c.vel_acc; S.sums[wave][2][e] = c.norm_acc;
     } else {
-        // the constant tail of the row (TA:1921-1927: the initial dof state) and, on request, the table and ball rows of rigid_body_states
+        f = a.flags[env]; ep_in = a.episode[env]; prog = a.progress[env] + 1;                  // TA:1146 (loads in flight during the sums below)
 #pragma unroll
-        for (int d = 0; d < NDOF; d++) { orow[121 + 6 * tatask::TA_NBAL + d] = a.p.init_dof_pos[d]; orow[121 + 6 * tatask::TA_NBAL + NDOF + d] = a.p.init_dof_vel[d]; }
-        if (a.rb_states && live) {
+        for (int d = 0; d < NDOF; d++) {
+            const float qv = S.q[d][e], qdv = S.qd[d][e];
+            const float epd = p.init_dof_pos[d] - qv, evd = p.init_dof_vel[d] - qdv;
+            if (d < 22) { s22 += epd * epd; sv += evd * evd; } else s5 += epd * epd;
+            power += fabsf(S.act_frc[d][e] * qdv);
+            orow[60 + d] = qv; orow[60 + NDOF + d] = qdv * 0.1f;                               // TA:1881-1882 (overwritten below if the env resets)
+            // the constant tail of the row (TA:1921-1927: the initial dof state)
+            orow[121 + 6 * tatask::TA_NBAL + d] = p.init_dof_pos[d]; orow[121 + 6 * tatask::TA_NBAL + NDOF + d] = p.init_dof_vel[d];
+        }
+        if (a.rb_states && live) {   // on request: the table and ball rows of rigid_body_states
             float* rb = a.rb_states + (size_t)env * PPENV_NUM_BODIES * 13;
             for (int k = 0; k < 13; k++) { rb[40 * 13 + k] = S.root[13 + k][e]; rb[41 * 13 + k] = S.root[26 + k][e]; }
         }
@@ -643,23 +742,14 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     CH_STAMP(23);
 
     // ---- final phase 2 (ball wave): reward, reset, the rest of the row — ppenv_ta_task.h ta_task_env, one lane per env ---------
+    bool any_here = false;
     if (wave == W_BALL) {
-        const ppenv_ta_params& p = a.p;
         const bool store = live && !S.dead;
         float pos_acc = 0.f, vel_acc = 0.f, norm_acc = 0.f;
 #pragma unroll
         for (int w = 0; w < 5; w++) { pos_acc += S.sums[w][0][e]; vel_acc += S.sums[w][1][e]; norm_acc += S.sums[w][2][e]; }
         const float r_body_pos = expf(-50.f * (pos_acc / (float)tatask::TA_NBAL));             // TA:1349-1351
         const float r_body_vel = expf(-4.0f * (vel_acc / (float)tatask::TA_NBAL));             // TA:1354-1356
-        float s22 = 0.f, s5 = 0.f, sv = 0.f, power = 0.f;
-#pragma unroll
-        for (int d = 0; d < NDOF; d++) {
-            const float qv = S.q[d][e], qdv = S.qd[d][e];
-            const float ep = p.init_dof_pos[d] - qv, ev = p.init_dof_vel[d] - qdv;
-            if (d < 22) { s22 += ep * ep; sv += ev * ev; } else s5 += ep * ep;
-            power += fabsf(S.act_frc[d][e] * qdv);
-            orow[60 + d] = qv; orow[60 + NDOF + d] = qdv * 0.1f;                               // TA:1881-1882 (overwritten below if the env resets)
-        }
         const float r22 = (0.2f * 50.0f) * expf(-(5.0f * 500.0f) * (s22 / 22.0f));            // TA:1372-1380
         const float r5 = 0.2f * expf(-5.0f * (s5 / 5.0f));                                     // TA:1383-1387
         const float r_dof_vel = expf(-0.05f * (sv / 22.0f));                                   // TA:1393,1401
@@ -667,9 +757,6 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         const bool has_fallen = (norm_acc / (float)tatask::TA_NBAL) > (p.is_train ? 0.32f : 1e6f);   // TA:1407-1415
         if (has_fallen) ref_reward = 1.0f * -50.0f;                                            // TA:1416-1417
 
-        uint32_t f = a.flags[env];
-        const uint32_t ep_in = a.episode[env];
-        long long prog = a.progress[env] + 1;                                                  // TA:1146
         const bool paddle_cond = f & PPENV_TA_FLAG_PADDLE_COND, hit_table_calc = f & PPENV_TA_FLAG_HIT_TABLE_CALC;
         const bool die_pen_calc = f & PPENV_TA_FLAG_DIE_PENALTY_CALC, hum_die = f & PPENV_TA_FLAG_HUMANOID_DIE_CALC;
         const V3 paddle = row3(S.paddle, 0, e);
@@ -732,8 +819,8 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                 float u[5];
 #pragma unroll
                 for (int k = 0; k < 5; k++) {
-                    uint64_t s = mix64(p.seed + 0x9E3779B97F4A7C15ull * ((uint64_t)gid + 1));
-                    uint64_t x = mix64(s + 0x9E3779B97F4A7C15ull * ((uint64_t)ep * 8 + k + 1));
+                    uint64_t sd = mix64(p.seed + 0x9E3779B97F4A7C15ull * ((uint64_t)gid + 1));
+                    uint64_t x = mix64(sd + 0x9E3779B97F4A7C15ull * ((uint64_t)ep * 8 + k + 1));
                     u[k] = (float)(x >> 40) * (1.0f / 16777216.0f);
                 }
                 ov[0] = p.ball_y_lo + (p.ball_y_hi - p.ball_y_lo) * u[0];                      // draw order TA:976-979: y, z, speed, tilt, tilt_z
@@ -768,10 +855,78 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             orow[120] = lb.y + (lv.y / (-lv.x + 1e-6f)) * lb.x;                                 // TA:1839
         }
         if (store) { a.progress[env] = prog; a.flags[env] = f; a.rew[env] = reward; a.reset[env] = rst; }
-        // TA:1162-1166: whenever ANY env resets, the diagnostic count flags of ALL envs are cleared.  The workgroups take
-        // tickets in the scratch word (bit 0: somebody reset; the rest: workgroups done); the one that draws the last ticket has
-        // seen every other workgroup's flag stores (release before the ticket, acquire after it) and does the clearing.
-        const bool any_here = __ballot(store && rst) != 0ull;
+        any_here = __ballot(store && rst) != 0ull;
+    }
+    CH_STAMP(24);
+    __syncthreads();   // B3
+    CH_STAMP(25);
+
+    // ---- final phase 3: the tiles leave as the workgroup's contiguous blocks ------------------------------------------------------
+    if (!S.dead) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        constexpr int kThreads = kWaves * 64;
+        float* dobs = a.obs + (size_t)e0 * PPENV_TA_NUM_OBS;                                           // 16-byte aligned: e0 is a multiple of 64
+        if (nvalid == kE) {
+            // constant trip counts: several LDS reads are in flight before the first store
+            constexpr int nO = kE * PPENV_TA_NUM_OBS / 4, nD = kE * 2 * NDOF / 4, nF = kE * NDOF / 4, nR = kE * 39 / 4;
+            constexpr int tO = (nO + kThreads - 1) / kThreads;
+#pragma unroll 7
+            for (int it = 0; it < tO; it++) {
+                const int i = it * kThreads + tid;
+                if (i < nO) __builtin_nontemporal_store(reinterpret_cast<const f4v*>(S.u.obs)[i], reinterpret_cast<f4v*>(dobs) + i);
+            }
+            f4v* dd = reinterpret_cast<f4v*>(a.dof_states + (size_t)e0 * 2 * NDOF);
+#pragma unroll
+            for (int it = 0; it < (nD + kThreads - 1) / kThreads; it++) {
+                const int i = it * kThreads + tid;
+                if (i < nD) {
+                    f4v v;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const int t = 4 * i + k, ee = t / (2 * NDOF), c = t - ee * 2 * NDOF; v[k] = (c & 1) ? S.qd[c >> 1][ee] : S.q[c >> 1][ee]; }
+                    __builtin_nontemporal_store(v, dd + i);
+                }
+            }
+            f4v* df = reinterpret_cast<f4v*>(a.dof_force + (size_t)e0 * NDOF);
+#pragma unroll
+            for (int it = 0; it < (nF + kThreads - 1) / kThreads; it++) {
+                const int i = it * kThreads + tid;
+                if (i < nF) {
+                    f4v v;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const int t = 4 * i + k, ee = t / NDOF, d = t - ee * NDOF; v[k] = S.act_frc[d][ee]; }
+                    __builtin_nontemporal_store(v, df + i);
+                }
+            }
+            f4v* dr = reinterpret_cast<f4v*>(a.root_states + (size_t)e0 * 39);
+#pragma unroll
+            for (int it = 0; it < (nR + kThreads - 1) / kThreads; it++) {
+                const int i = it * kThreads + tid;
+                if (i < nR) {
+                    f4v v;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const int t = 4 * i + k, ee = t / 39, c = t - ee * 39; v[k] = S.root[c][ee]; }
+                    __builtin_nontemporal_store(v, dr + i);
+                }
+            }
+        } else {
+            const int nvec = nvalid * PPENV_TA_NUM_OBS / 4, rem = nvalid * PPENV_TA_NUM_OBS - 4 * nvec;   // a ragged block need not be a multiple of 4
+            for (int t = tid; t < nvec; t += kThreads)
+                __builtin_nontemporal_store(reinterpret_cast<const f4v*>(S.u.obs)[t], reinterpret_cast<f4v*>(dobs) + t);
+            if (tid < rem) dobs[4 * nvec + tid] = S.u.obs[4 * nvec + tid];
+            for (int t = tid; t < nvalid * 2 * NDOF; t += kThreads) {
+                const int ee = t / (2 * NDOF), c = t - ee * 2 * NDOF;
+                __builtin_nontemporal_store((c & 1) ? S.qd[c >> 1][ee] : S.q[c >> 1][ee], &a.dof_states[(size_t)e0 * 2 * NDOF + t]);
+            }
+            tile_out<NDOF>(a.dof_force + (size_t)e0 * NDOF, S.act_frc, nvalid, tid);
+            tile_out<39>(a.root_states + (size_t)e0 * 39, S.root, nvalid, tid);
+        }
+    }
+    CH_STAMP(26);
+    // TA:1162-1166: whenever ANY env resets, the diagnostic count flags of ALL envs are cleared.  The workgroups take tickets in
+    // the scratch word (bit 0: somebody reset; the rest: workgroups done); the one that draws the last ticket has seen every other
+    // workgroup's flag stores (release before the ticket, acquire after it) and does the clearing.  Last in the kernel: the round
+    // trip of the atomic overlaps the other waves' stores.  (A workgroup that died still takes its ticket.)
+    if (wave == W_BALL) {
         __threadfence();
         uint32_t old = 0;
         if (lane == 0) {
@@ -781,32 +936,11 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         old = __shfl(old, 0);
         if ((old >> 1) == gridDim.x - 1) {
             __threadfence();
-            if (old & 1u)
+            if ((old & 1u) || any_here)
                 for (int i = lane; i < n; i += 64) __hip_atomic_fetch_and(&a.flags[i], ~PPENV_TA_COUNT_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) __hip_atomic_store(a.scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
         }
     }
-    CH_STAMP(24);
-    __syncthreads();   // B3
-    CH_STAMP(25);
-
-    // ---- final phase 3: the tiles leave as the workgroup's contiguous blocks ------------------------------------------------------
-    if (S.dead) return;
-    {
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        const int nvec = nvalid * PPENV_TA_NUM_OBS / 4, rem = nvalid * PPENV_TA_NUM_OBS - 4 * nvec;     // 64 * 313 is a multiple of 4; a ragged block may not be
-        float* dst = a.obs + (size_t)e0 * PPENV_TA_NUM_OBS;                                            // 16-byte aligned: e0 is a multiple of 64
-        for (int t = tid; t < nvec; t += kWaves * 64)
-            __builtin_nontemporal_store(reinterpret_cast<const f4v*>(S.u.obs)[t], reinterpret_cast<f4v*>(dst) + t);
-        if (tid < rem) dst[4 * nvec + tid] = S.u.obs[4 * nvec + tid];
-    }
-    for (int t = tid; t < nvalid * 2 * NDOF; t += kWaves * 64) {
-        const int ee = t / (2 * NDOF), c = t - ee * 2 * NDOF;
-        __builtin_nontemporal_store((c & 1) ? S.qd[c >> 1][ee] : S.q[c >> 1][ee], &a.dof_states[(size_t)e0 * 2 * NDOF + t]);
-    }
-    tile_out<NDOF>(a.dof_force + (size_t)e0 * NDOF, S.act_frc, nvalid, tid);
-    tile_out<39>(a.root_states + (size_t)e0 * 39, S.root, nvalid, tid);
-    CH_STAMP(26);
 }
 }  // namespace
 
