@@ -511,6 +511,8 @@ def build_config(variant, cfg=None, num_envs=None, seed=0, device_id=0, env_id_o
     c.alpha_velocity_reward = env["alphaVelocityReward"]
     c.power_coefficient = env["powerCoefficient"]
     c.penalty = env["penalty"]
+    if variant == "T3":   # T3's reward has no table terms (T3:1080-1173); its yaml has no such keys
+        env = dict(env, hitTableReward=env.get("hitTableReward", 0.0), nothitTablePenalty=env.get("nothitTablePenalty", 0.0))
     c.hit_table_reward = env["hitTableReward"]
     c.not_hit_table_penalty = env["nothitTablePenalty"]
 

@@ -694,7 +694,24 @@ def main():
     g = generate_pre_physics(seed=20290)
     np.savez_compressed(os.path.join(outdir, "pre_physics.npz"), **g)
     print("[pre_physics]", {v: g[f"{v}_pd_tar"].shape for v in SERVE_FILES})
+    print("[task cfgs]", generate_task_cfgs())
     print("wrote", sorted(os.listdir(outdir)))
+
+
+def generate_task_cfgs():
+    """tests/golden/task_cfgs.json: what isaacgym_amd.cfgyaml.compose() yields for each of the reference's cfg/task/*.yaml (+ the train
+    yaml where one exists) — resolved VALUES only (nested dicts of numbers / strings / lists), so that the tests that drive the tasks
+    "from their reference yaml" also run on the GPU box, where /root/reference does not exist."""
+    import json
+    from isaacgym_amd import cfgyaml
+    out = {}
+    for name in ("HumanoidPingpongG1", "HumanoidPingpongTiltG1", "HumanoidPingpongTiltNoEarlyStopG1", "HumanoidPingpongTiltNESSparse27DOFG1"):
+        c = cfgyaml.compose(name, os.path.join(ref_loader.REF_ROOT, "cfg"))
+        out[name] = {"task": c["task"], "train": c.get("train")}
+    path = os.path.join(ROOT, "tests", "golden", "task_cfgs.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    return path
 
 
 if __name__ == "__main__":
