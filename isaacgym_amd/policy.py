@@ -1,0 +1,121 @@
+"""The policy forward of the rollout loop on the matrix cores (C ABI: include/ppenv_policy.h).
+
+rl_games' a2c_continuous network of the reference (cfg/train/HumanoidPingpongTiltG1PPO.yaml:10-31,50-51): separate actor and critic
+MLPs, units [2048, 1536, 1024, 1024, 512, 512], ELU, a linear mu head (fixed sigma) and a linear value head, inputs normalised by a
+RunningMeanStd (clamped to +-5), mixed precision.  `NativeMLP.forward(obs_buf)` runs it as eight launches of ONE hand-written MFMA
+kernel (v_mfma_f32_32x32x16_f16, fp32 accumulation):
+
+    layer 1     reads obs_buf [M, num_obs] fp32 in place, normalises / clamps / casts while staging, actor | critic as one N = 4096 GEMM
+    layers 2-6  actor and critic as the two problems of one batched launch, bias + ELU on the accumulators, fp16 activations
+    heads       mu [M, num_actions] and value [M, 1] in fp32
+
+PyTorch is only the owner of the device buffers here.  Weights are cast to fp16 once (`load`), as autocast does per call.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+UNITS = [2048, 1536, 1024, 1024, 512, 512]     # cfg/train/HumanoidPingpongTiltG1PPO.yaml:29
+
+
+class MLPLayer(C.Structure):
+    """ctypes mirror of ppenv_mlp_layer (include/ppenv_policy.h)."""
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("batch", C.c_int32),
+                ("in_", C.c_void_p), ("in_stride", C.c_int64), ("lda", C.c_int32), ("in_f32", C.c_int32),
+                ("mean", C.c_void_p), ("inv_std", C.c_void_p), ("clip", C.c_float),
+                ("w", C.c_void_p), ("w_stride", C.c_int64), ("ldw", C.c_int32),
+                ("bias", C.c_void_p), ("bias_stride", C.c_int64), ("elu", C.c_int32),
+                ("out", C.c_void_p), ("out_stride", C.c_int64), ("ldo", C.c_int32), ("out_f32", C.c_int32)]
+
+
+def _lib_policy():
+    L = _lib.lib()
+    L.ppenv_mlp_layer_forward.argtypes = [C.POINTER(MLPLayer), C.c_void_p]
+    return L
+
+
+def layer_forward(out, x, w, bias, elu, batch=1, in_stride=0, w_stride=0, bias_stride=0, out_stride=0, mean=None, inv_std=None, clip=5.0,
+                  m=None, n=None, k=None):
+    """One launch of ppenv_mlp_layer_forward on torch tensors (x: fp16 activations or fp32 observations; w: fp16 [n, k])."""
+    L = _lib_policy()
+    d = MLPLayer()
+    d.m = x.shape[0] if m is None else m
+    d.n = (w.shape[-2] if n is None else n)
+    d.k = (w.shape[-1] if k is None else k)
+    d.batch = batch
+    d.in_, d.in_stride, d.lda, d.in_f32 = x.data_ptr(), in_stride, x.stride(0), int(x.dtype == torch.float32)
+    d.mean = mean.data_ptr() if mean is not None else None
+    d.inv_std = inv_std.data_ptr() if inv_std is not None else None
+    d.clip = clip
+    d.w, d.w_stride, d.ldw = w.data_ptr(), w_stride, w.stride(-2)
+    d.bias, d.bias_stride = (bias.data_ptr() if bias is not None else None), bias_stride
+    d.elu = int(elu)
+    d.out, d.out_stride, d.ldo, d.out_f32 = out.data_ptr(), out_stride, out.stride(0), int(out.dtype == torch.float32)
+    _lib.check(L.ppenv_mlp_layer_forward(C.byref(d), torch.cuda.current_stream(x.device).cuda_stream))
+
+
+class NativeMLP:
+    """Actor + critic forward on the MFMA kernel.  `actor` / `critic`: lists of (weight [out, in], bias [out]) fp32 tensors, hidden
+    layers first, the head last (what `[m for m in net if isinstance(m, nn.Linear)]` yields for the reference's architecture)."""
+
+    def __init__(self, actor, critic, num_obs, device, mean=None, var=None, eps=1e-5, clip=5.0, max_rows=None):
+        self.device = torch.device(device)
+        assert len(actor) == len(critic) and all(a[0].shape[0] == c[0].shape[0] for a, c in zip(actor[:-1], critic[:-1]))
+        self.num_obs, self.clip = int(num_obs), float(clip)
+        self.units = [a[0].shape[0] for a in actor[:-1]]
+        self.num_actions = actor[-1][0].shape[0]
+        self.load(actor, critic)
+        self.set_normalization(mean, var, eps)
+        self._rows = 0
+        if max_rows:
+            self._alloc(max_rows)
+
+    def load(self, actor, critic):
+        """fp32 master weights -> the fp16 operand images (actor | critic stacked per layer)."""
+        h = lambda t: t.detach().to(self.device, torch.float16).contiguous()
+        self.w, self.b = [], []
+        for (wa, ba), (wc, bc) in zip(actor[:-1], critic[:-1]):
+            self.w.append(torch.stack([h(wa), h(wc)]).contiguous())       # [2, n, k]
+            self.b.append(torch.stack([h(ba), h(bc)]).contiguous())       # [2, n]
+        self.head_w = [h(actor[-1][0]), h(critic[-1][0])]
+        self.head_b = [h(actor[-1][1]), h(critic[-1][1])]
+
+    def set_normalization(self, mean, var, eps=1e-5):
+        """rl_games RunningMeanStd in eval mode: (x - mean) / sqrt(var + eps), then clamp(+-clip)."""
+        if mean is None:
+            self.mean = self.inv_std = None
+        else:
+            self.mean = mean.detach().to(self.device, torch.float32).contiguous()
+            self.inv_std = torch.rsqrt(var.detach().to(self.device, torch.float32) + eps).contiguous()
+
+    def _alloc(self, m):
+        z = lambda n, dt: torch.empty((m, n), dtype=dt, device=self.device)
+        self.h = [z(2 * u, torch.float16) for u in self.units]            # actor columns first, critic after
+        self.mu, self.value = z(self.num_actions, torch.float32), z(1, torch.float32)
+        self._rows = m
+
+    def forward(self, obs):
+        """obs: fp32 [M, num_obs] on this device (the env's obs_buf, read in place) -> (mu [M, A], value [M, 1]) fp32 (buffers reused)."""
+        m = obs.shape[0]
+        if m != self._rows:
+            self._alloc(m)
+        assert obs.dtype == torch.float32 and obs.device == self.device and obs.stride(1) == 1 and obs.shape[1] == self.num_obs
+        u = self.units
+        # layer 1: both networks read the same rows -> one N = 2 u0 GEMM over the stacked weights
+        w0 = self.w[0].view(2 * u[0], self.num_obs)
+        layer_forward(self.h[0], obs, w0, self.b[0].view(-1), elu=True, mean=self.mean, inv_std=self.inv_std, clip=self.clip)
+        for i in range(1, len(u)):
+            layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * u[i - 1],
+                          bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])
+        last = self.h[-1]
+        layer_forward(self.mu, last, self.head_w[0], self.head_b[0], elu=False, m=m, n=self.num_actions, k=u[-1])
+        layer_forward(self.value, last[:, u[-1]:], self.head_w[1], self.head_b[1], elu=False, m=m, n=1, k=u[-1])
+        return self.mu, self.value
+
+    @staticmethod
+    def flops(m, num_obs, units=UNITS, num_actions=0):
+        dims = [num_obs] + list(units)
+        per_net = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        return 2 * m * (2 * per_net + units[-1] * (num_actions + 1))

@@ -16,7 +16,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     """include/ppenv.h is the contract: every function it declares must be exported by the built .so."""
     _lib.build()
     L = C.CDLL(_lib.LIB_PATH)
-    header = open(os.path.join(ROOT, "include", "ppenv.h")).read()
+    header = open(os.path.join(ROOT, "include", "ppenv.h")).read() + open(os.path.join(ROOT, "include", "ppenv_policy.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = sorted(set(re.findall(r"\b(ppenv_[a-z_0-9]+)\s*\(", header)))
     assert len(declared) >= 17, declared

@@ -1,0 +1,71 @@
+"""N2: the policy forward on the MFMA kernel (include/ppenv_policy.h) against a plain PyTorch fp32 MLP on the same weights.
+Tolerance: fp16 operands with fp32 accumulation — rtol 1e-2 plus 1e-2 of the tensor's scale (north star for fp16 paths)."""
+import numpy as np
+import pytest
+
+
+def _mlp(torch, num_obs, units, n_out, gen):
+    layers, d = [], num_obs
+    for u in list(units) + [n_out]:
+        w = (torch.rand(u, d, generator=gen) * 2 - 1) * (1.0 / np.sqrt(d))       # nn.Linear's default range
+        b = (torch.rand(u, generator=gen) * 2 - 1) * (1.0 / np.sqrt(d))
+        layers.append((w, b))
+        d = u
+    return layers
+
+
+def _ref_forward(torch, layers, x):
+    for i, (w, b) in enumerate(layers):
+        x = x @ w.t() + b
+        if i + 1 < len(layers):
+            x = torch.nn.functional.elu(x)
+    return x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,num_obs,num_act,units", [(4096, 313, 27, (2048, 1536, 1024, 1024, 512, 512)), (1000, 80, 7, (2048, 1536, 1024, 1024, 512, 512)),
+                                                      (130, 80, 7, (256, 128))])
+def test_native_mlp_matches_fp32_pytorch(m, num_obs, num_act, units):
+    import torch
+    from isaacgym_amd.policy import NativeMLP
+    gen = torch.Generator().manual_seed(m)
+    actor, critic = _mlp(torch, num_obs, units, num_act, gen), _mlp(torch, num_obs, units, 1, gen)
+    mean = torch.randn(num_obs, generator=gen) * 0.5
+    var = torch.rand(num_obs, generator=gen) * 2 + 0.1
+    obs = (torch.randn(m, num_obs, generator=gen) * 2.0 + 0.3)
+    obs[:, 5] *= 20.0                                   # a column that hits the +-5 clamp
+    net = NativeMLP(actor, critic, num_obs, "cuda:0", mean=mean, var=var)
+    mu, value = net.forward(obs.cuda())
+    torch.cuda.synchronize()
+    x = torch.clamp((obs - mean) / torch.sqrt(var + 1e-5), -5.0, 5.0)
+    want_mu, want_v = _ref_forward(torch, actor, x), _ref_forward(torch, critic, x)
+    for got, want, what in ((mu.cpu(), want_mu, "mu"), (value.cpu(), want_v, "value")):
+        scale = float(want.abs().max())
+        err = (got - want).abs()
+        tol = 1e-2 * want.abs() + 1e-2 * scale
+        assert bool((err <= tol).all()), (what, float(err.max()), scale)
+        assert float(err.mean()) < 2e-3 * scale, (what, float(err.mean()), scale)   # and not merely inside the bound: typical error ~1e-3
+    # the intermediate activations are fp16 and finite
+    assert all(torch.isfinite(h.float()).all() for h in net.h)
+
+
+@pytest.mark.gpu
+def test_layer_kernel_exact_on_integer_data():
+    """A = I-like / asymmetric small-integer operands: every product and sum is exact in fp16 / fp32, so the MFMA operand and
+    accumulator lane maps are checked bit for bit (a transposed or permuted tile cannot pass)."""
+    import torch
+    from isaacgym_amd.policy import layer_forward
+    m, n, k = 200, 150, 100           # ragged in every dimension
+    gen = torch.Generator().manual_seed(1)
+    a = torch.randint(-3, 4, (m, k), generator=gen).to(torch.float16)
+    w = torch.randint(-3, 4, (n, k), generator=gen).to(torch.float16)
+    w[:, 0] = torch.arange(n, dtype=torch.float16) % 5 - 2          # asymmetric
+    bias = torch.randint(-2, 3, (n,), generator=gen).to(torch.float16)
+    k8 = 104                                                          # rows padded to a multiple of 8 elements (16-byte rows)
+    a_p, w_p = torch.zeros(m, k8, dtype=torch.float16), torch.zeros(n, k8, dtype=torch.float16)
+    a_p[:, :k], w_p[:, :k] = a, w
+    out = torch.zeros(m, n, dtype=torch.float32, device="cuda")
+    layer_forward(out, a_p.cuda(), w_p.cuda(), bias.cuda(), elu=False, m=m, n=n, k=k)
+    torch.cuda.synchronize()
+    want = a.float() @ w.float().t() + bias.float()
+    assert torch.equal(out.cpu(), want)

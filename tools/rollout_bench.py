@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Rollout-loop throughput of BASELINE config 5's per-GPU slice: the native 27-DoF env step together with the reference's policy
-forward, on one GPU.  Context for SURVEY.md §8(f) N2 — NOT the bench.py metric and not a hand-written kernel: the policy is plain
-PyTorch (hipBLASLt GEMMs, fp16 weights and activations), random-initialised, with the reference's architecture
+forward, on one GPU — NOT the bench.py metric.  The policy has the reference's architecture
 (cfg/train/HumanoidPingpongTiltG1PPO.yaml:11-30,50-52: separate actor and critic MLPs [2048, 1536, 1024, 1024, 512, 512], ELU,
-fixed sigma, mixed_precision, normalize_input).  One rollout step = normalise obs -> actor and critic forward -> sample and clamp
-the action -> env.step.  Prints one JSON line.
+fixed sigma, mixed_precision, normalize_input), random-initialised.  One rollout step = normalise obs -> actor and critic forward ->
+sample and clamp the action -> env.step.  --policy native: the hand-written MFMA forward (isaacgym_amd.policy, include/ppenv_policy.h:
+obs normalisation fused into the first layer's tile load, bias + ELU on the accumulators); --policy torch: plain PyTorch / hipBLASLt,
+fp16 weights and activations.  Prints one JSON line.
 
-    python tools/rollout_bench.py [--variant TA|TT] [--num-envs 4096] [--steps 320] [--no-graph]
+    python tools/rollout_bench.py [--variant TA|TT] [--num-envs 4096] [--steps 320] [--no-graph] [--policy native|torch]
 """
 import argparse
 import json
@@ -28,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=320)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--policy", default="native", choices=["native", "torch"])
     args = ap.parse_args()
 
     import torch
@@ -56,25 +58,35 @@ def main():
         return torch.nn.Sequential(*layers).to(dev)
 
     torch.manual_seed(0)
-    actor, critic = mlp(num_act).half(), mlp(1).half()   # weights cast once (rl_games' autocast re-casts the fp32 master weights in every call)
+    actor, critic = mlp(num_act), mlp(1)
     mean = torch.zeros(num_obs, device=dev)
     inv_std = torch.ones(num_obs, device=dev)
+    native = None
+    if args.policy == "native":
+        from isaacgym_amd.policy import NativeMLP
+        lin = lambda net: [(m.weight, m.bias) for m in net if isinstance(m, torch.nn.Linear)]
+        native = NativeMLP(lin(actor), lin(critic), num_obs, dev, mean=mean, var=torch.ones(num_obs, device=dev) - 1e-5, max_rows=n)
+    actor, critic = actor.half(), critic.half()   # weights cast once (rl_games' autocast re-casts the fp32 master weights in every call)
     sigma = torch.ones(num_act, device=dev)          # fixed_sigma, const_initializer 0 -> exp(0)
     values = torch.zeros(n, 1, device=dev)
 
     @torch.no_grad()
-    def rollout_step():
+    def forward():
+        if native is not None:
+            return native.forward(obs_buf)                                # normalisation fused into layer 1; obs_buf read in place
         x = torch.clamp((obs_buf - mean) * inv_std, -5.0, 5.0).half()     # rl_games RunningMeanStd in eval mode
-        mu = actor(x)
-        values.copy_(critic(x))
-        action = torch.clamp(mu.float() + sigma * torch.randn_like(mu, dtype=torch.float32), -1.0, 1.0).contiguous()
+        return actor(x).float(), critic(x).float()
+
+    @torch.no_grad()
+    def rollout_step():
+        mu, v = forward()
+        values.copy_(v)
+        action = torch.clamp(mu + sigma * torch.randn_like(mu), -1.0, 1.0).contiguous()
         step(action)
 
     @torch.no_grad()
     def policy_only():
-        x = torch.clamp((obs_buf - mean) * inv_std, -5.0, 5.0).half()
-        actor(x)
-        critic(x)
+        forward()
 
     def timed(fn, k):
         torch.cuda.synchronize()
@@ -107,13 +119,16 @@ def main():
     acts = torch.rand(n, num_act, device=dev) * 2 - 1
     t_env = timed(lambda: step(acts), 200)
     flops = 2 * 2 * n * sum(a * b for a, b in zip([num_obs] + UNITS, UNITS + [0]) if b)   # two nets; the small heads are left out
+    MFMA_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16 / bf16
     print(json.dumps({
         "what": "rollout loop (env step + policy forward) on one GPU; context for BASELINE config 5, not the bench.py metric",
         "variant": args.variant, "num_envs": n, "launch": "HIP graph of 32 rollout steps" if graph is not None else "eager",
         "rollout_env_steps_per_s": n / t_roll, "us_per_rollout_step": t_roll * 1e6,
         "us_policy_forward_eager": t_pol * 1e6, "policy_tflops_eager": flops / t_pol / 1e12,
+        "policy_mfma_frac_of_dense_peak": flops / t_pol / 1e12 / MFMA_PEAK_TFLOPS, "policy_gflop_per_step": flops / 1e9,
         "us_env_step_eager": t_env * 1e6,
-        "policy": "actor + critic MLP [2048,1536,1024,1024,512,512] ELU, fp16, random init (PyTorch / hipBLASLt)",
+        "policy": "actor + critic MLP [2048,1536,1024,1024,512,512] ELU, fp16 operands / fp32 accumulation, random init; "
+                  + ("hand-written MFMA kernel (8 launches, obs normalisation fused)" if native is not None else "PyTorch / hipBLASLt"),
     }))
 
 
