@@ -16,6 +16,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/ppenv.h"
 #include "../../include/ppenv_policy.h"
@@ -23,7 +24,7 @@
 void ppenv_set_error(const char* msg);   // ppenv.hip
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 64, LDS_LD = BK + 8;   // fp16 elements per LDS row
+constexpr int BK = 64, LDS_LD = BK + 8;   // K step; fp16 elements per LDS row (padded)
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -38,12 +39,13 @@ struct Args {
     void* out; long long out_stride;
 };
 
-// global -> registers: this thread's share of a 128 x 64 fp16 tile (rows row0.., k from k0), zero outside [rows, kmax).
-// 128 rows x 8 chunks of 8 fp16 = 1024 chunks, 4 per thread: chunk c = tid + 256 i -> row c >> 3, k-chunk c & 7.
-__device__ __forceinline__ void load_tile_h(const _Float16* __restrict__ base, int ld, int rows, int kmax, int row0, int k0, int tid, h8 (&v)[4]) {
+// global -> registers: this thread's share of a ROWS x 64 fp16 tile (rows row0.., k from k0), zero outside [rows, kmax).
+// ROWS rows x 8 chunks of 8 fp16, C = ROWS * 8 / T per thread: chunk c = tid + T i -> row c >> 3, k-chunk c & 7.
+template <int T, int C>
+__device__ __forceinline__ void load_tile_h(const _Float16* __restrict__ base, int ld, int rows, int kmax, int row0, int k0, int tid, h8 (&v)[C]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int c = tid + 256 * i, r = row0 + (c >> 3), kk = k0 + (c & 7) * 8;
+    for (int i = 0; i < C; i++) {
+        const int c = tid + T * i, r = row0 + (c >> 3), kk = k0 + (c & 7) * 8;
         h8 x = {0, 0, 0, 0, 0, 0, 0, 0};
         if (r < rows) {
             const _Float16* p = base + (size_t)r * ld + kk;
@@ -57,39 +59,59 @@ __device__ __forceinline__ void load_tile_h(const _Float16* __restrict__ base, i
     }
 }
 // the first layer: fp32 observations, normalised and clamped on the way (rl_games RunningMeanStd, eval mode)
+template <int T, int C>
 __device__ __forceinline__ void load_tile_obs(const float* __restrict__ base, int ld, int rows, int kmax, int row0, int k0, int tid,
-                                              const float* __restrict__ mean, const float* __restrict__ inv_std, float clip, h8 (&v)[4]) {
+                                              const float* __restrict__ mean, const float* __restrict__ inv_std, float clip, h8 (&v)[C]) {
+    static_assert(T % 8 == 0, "a thread's k offset inside the tile must not depend on the chunk");
+    const int kk = k0 + (tid & 7) * 8;          // the same for all of this thread's chunks: its eight statistics are fetched once
+    float mu[8], is[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int c = tid + 256 * i, r = row0 + (c >> 3), kk = k0 + (c & 7) * 8;
+    for (int j = 0; j < 8; j++) { const bool in = kk + j < kmax; mu[j] = (mean && in) ? mean[kk + j] : 0.f; is[j] = (mean && in) ? inv_std[kk + j] : 1.f; }
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0) && kk + 8 <= kmax;   // 16-byte aligned rows: two float4 per chunk
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+        const int c = tid + T * i, r = row0 + (c >> 3);
         h8 x = {0, 0, 0, 0, 0, 0, 0, 0};
         if (r < rows) {
             const float* p = base + (size_t)r * ld + kk;
+            float f[8];
+            if (vec) {
+                const f4v lo = *reinterpret_cast<const f4v*>(p), hi = *reinterpret_cast<const f4v*>(p + 4);
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (kk + j < kmax) {
-                    float f = p[j];
-                    if (mean) f = fminf(fmaxf((f - mean[kk + j]) * inv_std[kk + j], -clip), clip);
-                    x[j] = (_Float16)f;
-                }
+                for (int j = 0; j < 4; j++) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) f[j] = kk + j < kmax ? p[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float g = (f[j] - mu[j]) * is[j];
+                if (mean) g = fminf(fmaxf(g, -clip), clip);
+                x[j] = kk + j < kmax ? (_Float16)g : (_Float16)0.f;
+            }
         }
         v[i] = x;
     }
 }
-__device__ __forceinline__ void store_tile(_Float16* __restrict__ s, int tid, const h8 (&v)[4]) {
+template <int T, int C>
+__device__ __forceinline__ void store_tile(_Float16* __restrict__ s, int tid, const h8 (&v)[C]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < C; i++) {
+        const int c = tid + T * i;
         *reinterpret_cast<h8*>(&s[(c >> 3) * LDS_LD + (c & 7) * 8]) = v[i];
     }
 }
 
-template <bool OBS>
-__global__ __launch_bounds__(256) void mlp_layer_kernel(const Args a) {
+// WM x WN waves per workgroup, 64 x 64 of `out` per wave: the tile is 64 WM x 64 WN.  (2, 2): 128 x 128, 74 KB of LDS, two
+// workgroups per CU; (4, 2): 256 x 128, 111 KB, one workgroup of eight waves per CU — a third fewer operand bytes per flop.
+template <bool OBS, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
+    constexpr int T = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN, CA = BM * 8 / T, CB = BN * 8 / T;
+    static_assert(BM * 8 % T == 0 && BN * 8 % T == 0, "staging shares");
     __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, b = blockIdx.z;
     const _Float16* W = a.w + (size_t)b * a.w_stride;
     const _Float16* inh = OBS ? nullptr : reinterpret_cast<const _Float16*>(a.in) + (size_t)b * a.in_stride;
@@ -103,40 +125,91 @@ __global__ __launch_bounds__(256) void mlp_layer_kernel(const Args a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    h8 ra[4], rb[4];
+    // Operand pipeline: tile ks is in LDS, tiles ks + 1 and ks + 2 are on their way in two register sets.  A global load has two
+    // K-steps (>= 32 MFMAs per wave) to land before its registers are written to LDS — one step did not cover the latency of a
+    // load that misses L2 (measured: 18 % of the MFMA peak with a prefetch distance of one).
+    h8 ra[2][CA], rb[2][CB];
     const int ksteps = (a.k + BK - 1) / BK;
-    if (OBS) load_tile_obs(inf, a.lda, a.m, a.k, m0, 0, tid, a.mean, a.inv_std, a.clip, ra); else load_tile_h(inh, a.lda, a.m, a.k, m0, 0, tid, ra);
-    load_tile_h(W, a.ldw, a.n, a.k, n0, 0, tid, rb);
-    store_tile(sA[0], tid, ra);
-    store_tile(sB[0], tid, rb);
+    auto gload = [&](int set, int ks) {
+        if (ks >= ksteps) return;
+        if (OBS) load_tile_obs<T, CA>(inf, a.lda, a.m, a.k, m0, ks * BK, tid, a.mean, a.inv_std, a.clip, ra[set]); else load_tile_h<T, CA>(inh, a.lda, a.m, a.k, m0, ks * BK, tid, ra[set]);
+        load_tile_h<T, CB>(W, a.ldw, a.n, a.k, n0, ks * BK, tid, rb[set]);
+    };
+    gload(0, 0);
+    store_tile<T, CA>(sA[0], tid, ra[0]);
+    store_tile<T, CB>(sB[0], tid, rb[0]);
+    gload(1, 1);
+    gload(0, 2);
     __syncthreads();
     const int r = lane & 31, h = lane >> 5;
-    for (int ks = 0; ks < ksteps; ks++) {
+    auto kstep = [&](int ks, int set_next) {   // set_next: the register set that holds tile ks + 1 (and is refilled with tile ks + 3)
         const int cur = ks & 1;
-        if (ks + 1 < ksteps) {   // next step's global loads in flight during this step's MFMAs
-            if (OBS) load_tile_obs(inf, a.lda, a.m, a.k, m0, (ks + 1) * BK, tid, a.mean, a.inv_std, a.clip, ra); else load_tile_h(inh, a.lda, a.m, a.k, m0, (ks + 1) * BK, tid, ra);
-            load_tile_h(W, a.ldw, a.n, a.k, n0, (ks + 1) * BK, tid, rb);
-        }
+        // fragments of sub-step kk + 1 are read while the MFMAs of sub-step kk run (two fragment sets)
+        h8 fa[2][2], fb[2][2];
+        auto frags = [&](int set, int kk) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) fa[set][i] = *reinterpret_cast<const h8*>(&sA[cur][(wm * 64 + i * 32 + r) * LDS_LD + kk * 16 + h * 8]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) fb[set][j] = *reinterpret_cast<const h8*>(&sB[cur][(wn * 64 + j * 32 + r) * LDS_LD + kk * 16 + h * 8]);
+        };
+        frags(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK / 16; kk++) {
-            h8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) fa[i] = *reinterpret_cast<const h8*>(&sA[cur][(wm * 64 + i * 32 + r) * LDS_LD + kk * 16 + h * 8]);
-#pragma unroll
-            for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const h8*>(&sB[cur][(wn * 64 + j * 32 + r) * LDS_LD + kk * 16 + h * 8]);
+            if (kk + 1 < BK / 16) frags((kk + 1) & 1, kk + 1);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
         }
         if (ks + 1 < ksteps) {
-            store_tile(sA[cur ^ 1], tid, ra);   // the other buffer: last read before the barrier that ended step ks - 1
-            store_tile(sB[cur ^ 1], tid, rb);
+            store_tile<T, CA>(sA[cur ^ 1], tid, ra[set_next]);   // the other buffer: last read before the barrier that ended step ks - 1
+            store_tile<T, CB>(sB[cur ^ 1], tid, rb[set_next]);
         }
+        gload(set_next, ks + 3);
         __syncthreads();
+    };
+    for (int ks = 0; ks < ksteps; ks += 2) {
+        kstep(ks, 1);
+        if (ks + 1 < ksteps) kstep(ks + 1, 0);
     }
-    // epilogue: C/D layout of the 32x32 MFMA — col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // epilogue: C/D layout of the 32x32 MFMA — col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane holds ONE column,
+    // so stored straight from the accumulators every store instruction would move 2 bytes per lane.  fp16 results therefore go through
+    // the wave's own 64 x 64 patch of LDS (the operand buffers are free after the last barrier) and leave as 16 bytes per lane, 128
+    // contiguous bytes per output row.  The fp32 heads (a few columns) are stored directly.
     const _Float16* bias = a.bias ? a.bias + (size_t)b * a.bias_stride : nullptr;
+    if (!a.out_f32) {
+        _Float16* patch = &sA[0][0] + wave * (64 * LDS_LD);
+        static_assert(2 * BM * LDS_LD >= WM * WN * 64 * LDS_LD, "epilogue patches fit the A buffers");
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = n0 + wn * 64 + j * 32 + r;
+            const float bv = (bias && col < a.n) ? (float)bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    float x = acc[i][j][reg] + bv;
+                    if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
+                    patch[(i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * LDS_LD + j * 32 + r] = (_Float16)x;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();   // the patch is this wave's own: DS operations of a wave execute in order
+        _Float16* out = reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride;
+        const int rl = lane >> 3, ch = lane & 7;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int prow = it * 8 + rl, row = m0 + wm * 64 + prow, col = n0 + wn * 64 + ch * 8;
+            if (row >= a.m || col >= a.n) continue;
+            const h8 v = *reinterpret_cast<const h8*>(&patch[prow * LDS_LD + ch * 8]);
+            _Float16* dst = out + (size_t)row * a.ldo + col;
+            if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
+            else {
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (col + q < a.n) dst[q] = v[q];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int col = n0 + wn * 64 + j * 32 + r;
@@ -150,8 +223,7 @@ __global__ __launch_bounds__(256) void mlp_layer_kernel(const Args a) {
                 if (row >= a.m) continue;
                 float x = acc[i][j][reg] + bv;
                 if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
-                if (a.out_f32) (reinterpret_cast<float*>(a.out) + (size_t)b * a.out_stride)[(size_t)row * a.ldo + col] = x;
-                else (reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride)[(size_t)row * a.ldo + col] = (_Float16)x;
+                (reinterpret_cast<float*>(a.out) + (size_t)b * a.out_stride)[(size_t)row * a.ldo + col] = x;
             }
         }
     }
@@ -167,9 +239,20 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
     Args a{L->m, L->n, L->k, L->lda, L->ldw, L->ldo, L->elu, L->out_f32, L->in, (long long)L->in_stride, L->mean, L->inv_std, L->clip,
            reinterpret_cast<const _Float16*>(L->w), (long long)L->w_stride, reinterpret_cast<const _Float16*>(L->bias), (long long)L->bias_stride,
            L->out, (long long)L->out_stride};
-    const dim3 grid((L->n + BN - 1) / BN, (L->m + BM - 1) / BM, L->batch), block(256);
-    if (L->in_f32) hipLaunchKernelGGL(mlp_layer_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(mlp_layer_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    // tile choice: the 256 x 128 tile moves a third fewer operand bytes per flop but needs >= ~one workgroup per CU to pay
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("PPENV_MLP_TILE"); forced = e ? atoi(e) : 0; }   // 128 / 256: profiling
+    const long long big_wgs = (long long)((L->n + 127) / 128) * ((L->m + 255) / 256) * L->batch;
+    const bool big = forced == 256 || (forced == 0 && big_wgs >= 256 && L->m >= 256);
+    if (big) {
+        const dim3 grid((L->n + 127) / 128, (L->m + 255) / 256, L->batch), block(512);
+        if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, 4, 2>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((mlp_layer_kernel<false, 4, 2>), grid, block, 0, (hipStream_t)stream, a);
+    } else {
+        const dim3 grid((L->n + 127) / 128, (L->m + 127) / 128, L->batch), block(256);
+        if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, 2, 2>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((mlp_layer_kernel<false, 2, 2>), grid, block, 0, (hipStream_t)stream, a);
+    }
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching mlp_layer_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }
