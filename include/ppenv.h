@@ -270,6 +270,35 @@ int ppenv_pd_targets(struct ppenv* env, const float* actions_dev, float* pd_tar_
  * function the reset path feeds from its counter RNG; pinned to the reference functions by tests/golden/serve_draws.npz. */
 int ppenv_serve_from_draws(struct ppenv* env, const float* draws_dev, int32_t m, float* vel_dev, void* stream);
 
+/* Domain randomisation (cfg/task/HumanoidPingpongTiltG1.yaml:100-169, TT:849-850: apply_randomizations at reset time) for the fused
+ * step of the 3-actor variants.  The sampling — distributions, ranges, schedules, `frequency` — is host policy
+ * (isaacgym_amd/vec_task.py apply_randomizations, after upstream VecTask.apply_randomizations); what the kernel consumes is the
+ * RESULT: per-env tables in device memory, SoA [rows][num_envs] like the state, plus two noise amplitudes.  Any table pointer may be
+ * NULL (= not randomised).  While a randomisation is set, ppenv_step runs the table-reading instantiation of the step kernel; with
+ * none set (the default, and after ppenv_set_randomization(env, NULL)) it runs exactly the code it ran before — bit-identical results.
+ *   dof_stiffness_scale, dof_damping_scale [7][N]   multiply the drive gains Kp, Kd of each dof       (dof_properties, yaml:144-156)
+ *   link_mass_scale [7][N]                          multiplies mass AND inertia of each arm link      (rigid_body_properties.mass, yaml:124-131)
+ *   restitution_scale, friction_scale [N]           multiply the combined ball-vs-humanoid-shape coefficients, paddle included (yaml:132-143;
+ *                                                   the combined restitution stays clamped to restitution_max)
+ *   action_noise_sigma / observation_noise_sigma    additive Gaussian white noise on the raw actions (before the clipActions clamp) and on
+ *                                                   every observation value (yaml:106-113), drawn from the counter RNG keyed by
+ *                                                   (seed, global env id, episode, progress, index) — identical in kernel and oracle
+ * Gravity (sim_params.gravity, yaml:114-120) is one value for the whole simulation, as upstream: ppenv_set_gravity. */
+typedef struct ppenv_randomization {
+    const float* dof_stiffness_scale;   /* [7][N] or NULL */
+    const float* dof_damping_scale;     /* [7][N] or NULL */
+    const float* link_mass_scale;       /* [7][N] or NULL */
+    const float* restitution_scale;     /* [N] or NULL */
+    const float* friction_scale;        /* [N] or NULL */
+    float action_noise_sigma;           /* 0 = off */
+    float observation_noise_sigma;      /* 0 = off */
+} ppenv_randomization;
+/* The tables are NOT copied: they must stay valid (and may be rewritten in place between steps) until the randomisation is replaced or
+ * cleared.  3-actor variants only. */
+int ppenv_set_randomization(struct ppenv* env, const ppenv_randomization* dr /* NULL: off */);
+/* sim_params.gravity of the whole simulation (yaml:83,114-120; the task's own override is -9.8, TT:329-331). */
+int ppenv_set_gravity(struct ppenv* env, float gravity_z);
+
 /* The handle's device status word (PPENV_STATUS_* bits), readable at any time without synchronising (it lives in pinned
  * host memory the kernels write through).  Every entry point that touches the state checks it first and fails with
  * PPENV_EDEVICE once it is non-zero. */

@@ -83,6 +83,8 @@ def lib():
     L.ppenv_reset_idx.argtypes = [vp, vp, C.c_int32, C.c_int, vp]
     L.ppenv_pd_targets.argtypes = [vp, vp, vp, vp]
     L.ppenv_serve_from_draws.argtypes = [vp, vp, C.c_int32, vp, vp]
+    L.ppenv_set_randomization.argtypes = [vp, C.POINTER(scene.Randomization)]
+    L.ppenv_set_gravity.argtypes = [vp, C.c_float]
     L.ppenv_status.restype = C.c_uint32
     L.ppenv_status.argtypes = [vp]
     L.ppenv_ta_pd_targets.argtypes = [vp, C.c_int32, vp, vp, vp]

@@ -122,6 +122,19 @@ struct LdsRowStore {
     float* row;
     __device__ __forceinline__ void operator()(int k, float v) { row[k] = v; }
 };
+// the same with the observation noise of the domain randomisation added (yaml:106-109); index 16 + k keeps clear of the action draws
+struct NoisyRowStore {
+    float* row;
+    float sigma;
+    uint64_t seed;
+    uint32_t gid, episode, progress;
+    __device__ __forceinline__ void operator()(int k, float v) { row[k] = v + sigma * dr_gauss(seed, gid, episode, progress, 16u + (uint32_t)k); }
+};
+// device pointers of the randomisation tables (ppenv_randomization), by value in the kernel argument
+struct DRTables {
+    const float* kp; const float* kd; const float* ms; const float* es; const float* fs;
+    float act_sigma, obs_sigma;
+};
 
 // obs rows of one workgroup: LDS [kBlock][kObsStride] -> obs_buf[base*80 ...], 16 B per lane, contiguous
 __device__ __forceinline__ void flush_obs(const float* s_obs, float* obs, int base, int nvalid, int lane) {
@@ -139,8 +152,8 @@ __device__ __forceinline__ void flush_obs(const float* s_obs, float* obs, int ba
 
 // ------------------------------------------------------------------ the fused step
 // K1..K8 of SURVEY.md §2 in one launch: TT:1002-1052.
-template <class T>
-__global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on) {
+template <class T, bool DR = false>
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on, const DRTables drt = DRTables{}) {
     __shared__ float s_obs[kBlock * kObsStride];
     const int lane = threadIdx.x;
     PP_STAMP_AT(0);
@@ -171,17 +184,33 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepConsts K, DevBuf
 #pragma unroll
         for (int j = 0; j < NB; j++) { bodies[j].pos = mk(act[0], act[1], (float)j); bodies[j].lin = mk(act[2], act[3], act[4]); }
 #else
-        simulate_env<T, 1>(K, act, st, bodies, pre_vx);
+        EnvDR dr;
+        const uint32_t gid = (uint32_t)(K.env_id_offset + i), ep0 = st.episode;
+        if (DR) {   // this env's entries of the randomisation tables (a NULL table = scale 1)
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                dr.kp[d] = drt.kp ? drt.kp[(size_t)d * n + i] : 1.f;
+                dr.kd[d] = drt.kd ? drt.kd[(size_t)d * n + i] : 1.f;
+                dr.ms[d] = drt.ms ? drt.ms[(size_t)d * n + i] : 1.f;
+            }
+            dr.es = drt.es ? drt.es[i] : 1.f;
+            dr.fs = drt.fs ? drt.fs[i] : 1.f;
+            dr.act_sigma = drt.act_sigma; dr.obs_sigma = drt.obs_sigma;
+            dr.key_progress = (uint32_t)st.progress;
+        }
+        simulate_env<T, 1, DR>(K, act, st, bodies, pre_vx, &dr, gid);
 #endif
         V3 ov = mk(0, 0, 0);
         if (serve_on) ov = mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i]);
         LdsRowStore store{&s_obs[lane * kObsStride]};
+        NoisyRowStore nstore{&s_obs[lane * kObsStride], dr.obs_sigma, K.seed, gid, ep0, dr.key_progress};
 #if PP_ABLATE >= 3   // skip reward / reset / observations as well: loads + stores only
         rew = pre_vx; reset = 0;
 #pragma unroll
         for (int k = 0; k < PPENV_NUM_OBS; k++) store(k, bodies[k % NB].pos.x);
 #else
-        post_physics_env<1>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, serve_on ? &ov : nullptr, &rew, reset, &store);
+        if (DR && drt.obs_sigma > 0.f) post_physics_env<1>(K, gid, st, bodies, pre_vx, serve_on ? &ov : nullptr, &rew, reset, &nstore);
+        else post_physics_env<1>(K, gid, st, bodies, pre_vx, serve_on ? &ov : nullptr, &rew, reset, &store);
 #endif
         PP_STAMP_AT(9);
     }
@@ -942,6 +971,8 @@ struct ppenv {
     uint32_t* status_host;   // PPENV_STATUS_* bits, pinned host memory mapped into the device: kernels write it through, the host reads it without a sync
     uint32_t* status_dev;
     int dbg_drop_handoff;    // PPENV_DEBUG_DROP_HANDOFF=1 at create (tests): the arm wave withholds its last hand-off, so the partner waves time out
+    int dr_on;               // a randomisation is set: ppenv_step launches step_kernel<ModelG1, true> with these tables
+    DRTables dr;
 };
 
 namespace {
@@ -997,6 +1028,8 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
     e->arena = nullptr;
     e->owns_arena = false;
     e->status_host = e->status_dev = nullptr;
+    e->dr_on = 0;
+    e->dr = DRTables{};
     {
         const char* d = getenv("PPENV_DEBUG_DROP_HANDOFF");
         e->dbg_drop_handoff = (d && d[0] == '1') ? 1 : 0;
@@ -1075,6 +1108,12 @@ int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = check_status(e)) return rc;
     if (int rc = use_device(e)) return rc;
+    if (e->dr_on) {   // domain randomisation: the table-reading instantiation of the one-wave kernel
+        hipLaunchKernelGGL((step_kernel<ModelG1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
+                           e->serve_on, e->dr);
+        PP_HIP(hipGetLastError());
+        return PPENV_OK;
+    }
     if (e->agents == 2 && e->split == 2)
         hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
@@ -1085,8 +1124,8 @@ int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
         hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else
-        hipLaunchKernelGGL(step_kernel<ModelG1>, dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
-                           e->serve_on);
+        hipLaunchKernelGGL((step_kernel<ModelG1, false>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
+                           e->serve_on, DRTables{});
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
@@ -1102,6 +1141,25 @@ int ppenv_reset_all(ppenv* e, void* stream) {
 }
 
 uint32_t ppenv_status(ppenv* e) { return e ? *(volatile uint32_t*)e->status_host : 0u; }
+
+int ppenv_set_randomization(ppenv* e, const ppenv_randomization* dr) {
+    if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (!dr) { e->dr_on = 0; e->dr = DRTables{}; return PPENV_OK; }
+    if (e->agents != 1) { set_err("domain randomisation is wired for the 3-actor variants (no reference yaml randomises the 4-actor task)"); return PPENV_EINVAL; }
+    if (!(dr->action_noise_sigma >= 0.f) || !(dr->observation_noise_sigma >= 0.f)) { set_err("noise amplitudes must be >= 0"); return PPENV_EINVAL; }
+    e->dr = DRTables{dr->dof_stiffness_scale, dr->dof_damping_scale, dr->link_mass_scale, dr->restitution_scale, dr->friction_scale,
+                     dr->action_noise_sigma, dr->observation_noise_sigma};
+    e->dr_on = 1;
+    return PPENV_OK;
+}
+
+int ppenv_set_gravity(ppenv* e, float gravity_z) {
+    if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (!(gravity_z <= 0.f)) { set_err("gravity_z must be <= 0 (the world's up axis is z)"); return PPENV_EINVAL; }
+    e->cfg.gravity_z = gravity_z;
+    e->K = make_step_consts(e->cfg);   // host-side: the next launch carries the new constants in its kernel argument
+    return PPENV_OK;
+}
 
 int ppenv_reset_idx(ppenv* e, const int64_t* env_ids_dev, int32_t count, int refresh_obs, void* stream) {
     if (!e || (count > 0 && !env_ids_dev) || count < 0) { set_err("ppenv_reset_idx: NULL ids or negative count"); return PPENV_EINVAL; }

@@ -104,7 +104,7 @@ struct StepConsts {
     float ground_z, ground_e, ground_mu;
     ppenv_box table, net;
     float bound_r2;
-    float paddle_e, paddle_mu;
+    float paddle_e, paddle_mu, e_cap;
     float shape_e[PPENV_MAX_SHAPES], shape_mu[PPENV_MAX_SHAPES];
     // task
     float table_pos[3], table_quat[4];
@@ -327,6 +327,23 @@ PP_HD float pd_target(float action, float lo, float hi, float clip) {
     return 0.5f * (hi + lo) + 0.5f * (hi - lo) * a;
 }
 
+// Domain randomisation of one env (include/ppenv.h ppenv_randomization): the table entries of this env, fetched at the start of the step by
+// the table-reading instantiation of the step kernel (DR = true).  Every DR = false instantiation ignores it and compiles to the code it
+// was before the randomisation existed.
+struct EnvDR {
+    float kp[PPENV_NUM_DOF], kd[PPENV_NUM_DOF], ms[PPENV_NUM_DOF];   // scales of the drive gains and of the link masses (inertias with them)
+    float es, fs;                                                     // scales of the combined restitution / friction of the humanoid's shapes
+    float act_sigma, obs_sigma;
+    uint32_t key_progress;                                            // progress at the START of the step: keys the noise draws
+};
+// additive Gaussian white noise (Box-Muller on two counter-RNG draws); the oracle's dr_gauss is the same float arithmetic
+PP_HD float dr_gauss(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t progress, uint32_t index) {
+    const uint32_t k = progress * 256u + index;
+    const float u1 = rng_uniform(seed ^ 0x5DEECE66Dull, gid, episode, 2u * k), u2 = rng_uniform(seed ^ 0x5DEECE66Dull, gid, episode, 2u * k + 1u);
+    const float rad = sqrtf(-2.0f * logf(fmaxf(u1, 5.9604645e-8f)));
+    return rad * cosf(6.2831853f * u2);
+}
+
 // Per-joint constant groups of the compiled model: kinematics, PD drive, inertial.
 struct JointKin { float origin_xyz[3]; float origin_rot[9]; };
 struct JointDrive { float lower, upper, kp, kd, effort, vel_limit, armature; };
@@ -453,8 +470,8 @@ PP_HD void static_body(const ArmSite& S, BodyState& b) {   // obs_body[0]: the p
 // --------------------------------------------------- ABA passes 2 and 3 (RBDA 7.1)
 // tau / arm_eff: drive torque and joint-space inertia added on the diagonal
 // (armature + the implicit PD terms).  Returns qdd.
-template <class T>
-PP_HD void aba_solve(const ArmSite& S, JointSave* js, const float* qd, const float* tau, const float* arm_eff, float* qdd) {
+template <class T, bool DR = false>
+PP_HD void aba_solve(const ArmSite& S, JointSave* js, const float* qd, const float* tau, const float* arm_eff, float* qdd, const EnvDR* dr = nullptr) {
     // articulated inertia / bias force handed down by the child, in this link's coordinates
     S3 cA = {0, 0, 0, 0, 0, 0}, cD = {0, 0, 0, 0, 0, 0};
     M3 cB = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
@@ -466,12 +483,16 @@ PP_HD void aba_solve(const ArmSite& S, JointSave* js, const float* qd, const flo
         const int ax = T::axis(i);
         V3 w = js[i].w, v = js[i].v;
         // rigid-body inertia about the link origin: [[Io, m c x],[m c x^T, m 1]]
-        float m = J.mass;
+        const float msc = DR ? dr->ms[i] : 1.f;              // rigid_body_properties.mass scaling: mass and inertia together
+        float m = DR ? J.mass * msc : J.mass;
         V3 cm = ld3(J.com);
         V3 mc = cm * m;
         float cc = dot(cm, cm);
-        S3 A = {J.inertia[0] + m * (cc - cm.x * cm.x), J.inertia[1] + m * (cc - cm.y * cm.y), J.inertia[2] + m * (cc - cm.z * cm.z),
-                J.inertia[3] - m * cm.x * cm.y, J.inertia[4] - m * cm.x * cm.z, J.inertia[5] - m * cm.y * cm.z};
+        float Jin[6];
+#pragma unroll
+        for (int t = 0; t < 6; t++) Jin[t] = DR ? J.inertia[t] * msc : J.inertia[t];
+        S3 A = {Jin[0] + m * (cc - cm.x * cm.x), Jin[1] + m * (cc - cm.y * cm.y), Jin[2] + m * (cc - cm.z * cm.z),
+                Jin[3] - m * cm.x * cm.y, Jin[4] - m * cm.x * cm.z, Jin[5] - m * cm.y * cm.z};
         V3 h_ang = mul(A, w) + cross(mc, v);
         V3 h_lin = v * m - cross(mc, w);
         V3 pn = cross(w, h_ang) + cross(v, h_lin) + cn;
@@ -544,24 +565,26 @@ PP_HD void aba_solve(const ArmSite& S, JointSave* js, const float* qd, const flo
 // The PD terms are integrated implicitly (h Kd + h^2 Kp on the joint-space inertia diagonal) and the explicit part of the
 // torque is clamped to the effort limit: continuous at saturation, so a joint within rounding of the limit does not
 // change the step (an earlier draft switched to a constant torque without the implicit terms there).
-template <class T>
-PP_HD void arm_substep(const ArmSite& S, JointSave* js, float* q, float* qd, const float* target, float h, float* tau_drive) {
+template <class T, bool DR = false>
+PP_HD void arm_substep(const ArmSite& S, JointSave* js, float* q, float* qd, const float* target, float h, float* tau_drive, const EnvDR* dr = nullptr) {
     float tau[ND], arm[ND], qdd[ND];
 #pragma unroll
     for (int d = 0; d < ND; d++) {
         const JointDrive J = T::drive(d);
+        const float kp = DR ? J.kp * dr->kp[d] : J.kp, kd = DR ? J.kd * dr->kd[d] : J.kd;   // dof_properties.stiffness / damping scaling
         float err = target[d] - q[d];
-        tau[d] = fminf(fmaxf(J.kp * (err - h * qd[d]) - J.kd * qd[d], -J.effort), J.effort);
-        arm[d] = J.armature + h * J.kd + h * h * J.kp;
+        tau[d] = fminf(fmaxf(kp * (err - h * qd[d]) - kd * qd[d], -J.effort), J.effort);
+        arm[d] = J.armature + h * kd + h * h * kp;
     }
-    aba_solve<T>(S, js, qd, tau, arm, qdd);
+    aba_solve<T, DR>(S, js, qd, tau, arm, qdd, dr);
 #pragma unroll
     for (int d = 0; d < ND; d++) {
         const JointDrive J = T::drive(d);
+        const float kp = DR ? J.kp * dr->kp[d] : J.kp, kd = DR ? J.kd * dr->kd[d] : J.kd;
         float err = target[d] - q[d];
         float vn = qd[d] + h * qdd[d];
         // dof_force reports the drive torque at the end-of-substep velocity, within the actuator's limit
-        tau_drive[d] = fminf(fmaxf(J.kp * (err - h * vn) - J.kd * vn, -J.effort), J.effort);
+        tau_drive[d] = fminf(fmaxf(kp * (err - h * vn) - kd * vn, -J.effort), J.effort);
         vn = fminf(fmaxf(vn, -J.vel_limit), J.vel_limit);
         float qn = q[d] + h * vn;
         if (qn > J.upper) { qn = J.upper; vn = fminf(vn, 0.f); }
@@ -678,8 +701,8 @@ PP_HD V3 lerp(V3 a, V3 b, float f) { return madd(a, b - a, f); }
 // A = number of humanoids (2 for the 4-actor variant: humanoid 1's shapes are visited first, then humanoid 2's).
 // bound[arm]: centre of the humanoid's broad-phase sphere (fixed with the base here; it follows the torso of the
 // free-floating 27-DoF humanoid).
-template <class T, int A>
-PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> (&g)[A], const V3 (&bound)[A]) {
+template <class T, int A, bool DR = false>
+PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> (&g)[A], const V3 (&bound)[A], const EnvDR* dr = nullptr) {
     const int M = K.ball_substeps;
     const float hb = K.hb, h = K.h;
     BallConsts k;
@@ -695,7 +718,8 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> 
     const ppenv_box& net = K.net;
     // broad-phase spheres of the humanoid shapes for this substep
     const ModelPaddle P = T::paddle();
-    const float pad_e = K.paddle_e, pad_mu = K.paddle_mu;
+    const float e_cap = K.e_cap;   // restitution_max: a scaled coefficient stays within it
+    const float pad_e = DR ? fminf(K.paddle_e * dr->es, e_cap) : K.paddle_e, pad_mu = DR ? K.paddle_mu * dr->fs : K.paddle_mu;
     const float reach = k.r + k.contact_offset + 1e-4f;
     const float pad_rr = sqrtf(P.radius * P.radius + P.half_thickness * P.half_thickness) + reach;
     const float pad_r2 = pad_rr * pad_rr;
@@ -749,7 +773,8 @@ PP_HD void ball_substep(const StepConsts& K, Ball& b, const ArmGeom<T::kShapes> 
                 for (int s = 0; s < T::kShapes; s++) {
                     V3 dsc = b.p - madd(sc0[arm][s], svc[arm][s], t);
                     if (!(PP_BALL_SKIP & 2) && dot(dsc, dsc) < sr2[arm][s]) {
-                        const float radius = T::shape(s).radius, e = K.shape_e[s], mu = K.shape_mu[s];
+                        const float radius = T::shape(s).radius;
+                        const float e = DR ? fminf(K.shape_e[s] * dr->es, e_cap) : K.shape_e[s], mu = DR ? K.shape_mu[s] * dr->fs : K.shape_mu[s];
                         if (T::shape_link(s) < 0)
                             contact_capsule(k, b, ga.a[s], ga.b[s], mk(0, 0, 0), mk(0, 0, 0), radius, e, mu);
                         else
@@ -921,12 +946,14 @@ using EnvState = EnvStateT<1>;
 // Physics part of one VecTask.step for one env (pre_physics_step + gym.simulate):
 // updates st in place, returns the pre-reset observed-body states (bodies[a * NB + j]) and pre_vx.
 // actions: arm a's seven values at actions[a * ND ...] (rows A*e + a of the [A*N, 7] tensor are adjacent).
-template <class T, int A>
-PP_HD void simulate_env(const StepConsts& K, const float* actions, EnvStateT<A>& st, BodyState* bodies, float& pre_vx) {
+template <class T, int A, bool DR = false>
+PP_HD void simulate_env(const StepConsts& K, const float* actions, EnvStateT<A>& st, BodyState* bodies, float& pre_vx, const EnvDR* dr = nullptr, uint32_t gid = 0) {
     float target[A * ND];
 #pragma unroll
     for (int d = 0; d < A * ND; d++) {   // VecTask.step clamp + TT:1008 (offset/scale TT:664-665)
-        target[d] = pd_target(actions[d], T::drive(d % ND).lower, T::drive(d % ND).upper, K.clip_actions);
+        float act = actions[d];
+        if (DR) { if (dr->act_sigma > 0.f) act += dr->act_sigma * dr_gauss(K.seed, gid, st.episode, dr->key_progress, (uint32_t)d); }   // yaml:110-113, before the clamp
+        target[d] = pd_target(act, T::drive(d % ND).lower, T::drive(d % ND).upper, K.clip_actions);
     }
     pre_vx = st.ball.v.x;   // TT:1020
     const int substeps = K.substeps;
@@ -943,11 +970,11 @@ PP_HD void simulate_env(const StepConsts& K, const float* actions, EnvStateT<A>&
     }
     PP_STAMP_AT(2);
     for (int s = 0; s < substeps; s++) {
-        ball_substep<T, A>(K, st.ball, g, bound);                         // against the arms as they are at the substep's start
+        ball_substep<T, A, DR>(K, st.ball, g, bound, dr);                 // against the arms as they are at the substep's start
         PP_STAMP_AT(3 + 3 * s);
 #pragma unroll
         for (int a = 0; a < A; a++)
-            arm_substep<T>(K.site[a], js[a], &st.q[a * ND], &st.qd[a * ND], &target[a * ND], h, &st.dof_force[a * ND]);
+            arm_substep<T, DR>(K.site[a], js[a], &st.q[a * ND], &st.qd[a * ND], &target[a * ND], h, &st.dof_force[a * ND], dr);
         PP_STAMP_AT(4 + 3 * s);
 #pragma unroll
         for (int a = 0; a < A; a++) {
@@ -1130,7 +1157,7 @@ inline StepConsts make_step_consts(const ppenv_config& c) {
     K.ground_z = c.ground_z; K.ground_e = c.ground_restitution; K.ground_mu = c.ground_friction;
     K.table = c.table; K.net = c.net;
     K.bound_r2 = c.humanoid_bound_radius * c.humanoid_bound_radius;
-    K.paddle_e = c.paddle_restitution; K.paddle_mu = c.paddle_friction;
+    K.paddle_e = c.paddle_restitution; K.paddle_mu = c.paddle_friction; K.e_cap = c.restitution_max;
     for (int s = 0; s < PPENV_MAX_SHAPES; s++) {
         K.shape_e[s] = c.shape[s].restitution; K.shape_mu[s] = c.shape[s].friction;
     }

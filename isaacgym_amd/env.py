@@ -106,6 +106,29 @@ class PPEnv:
         _lib.check(self.L.ppenv_serve_from_draws(self.h, d.data_ptr(), d.shape[0], out.data_ptr(), self._stream()))
         return out
 
+    def set_randomization(self, dof_stiffness_scale=None, dof_damping_scale=None, link_mass_scale=None, restitution_scale=None,
+                          friction_scale=None, action_noise_sigma=0.0, observation_noise_sigma=0.0):
+        """Per-env domain-randomisation tables (ppenv_set_randomization): float32 device tensors [7, N] / [N] (None = not randomised).
+        The tensors are kept alive here and read by every following step; rewriting them in place changes the randomisation."""
+        def tab(t, rows):
+            if t is None:
+                return None
+            t = torch.as_tensor(t, dtype=torch.float32).to(self.device).contiguous()
+            assert tuple(t.shape) == ((rows, self.num_envs) if rows else (self.num_envs,)), tuple(t.shape)
+            return t
+        self._dr = [tab(dof_stiffness_scale, 7), tab(dof_damping_scale, 7), tab(link_mass_scale, 7), tab(restitution_scale, 0), tab(friction_scale, 0)]
+        r = scene.Randomization()
+        (r.dof_stiffness_scale, r.dof_damping_scale, r.link_mass_scale, r.restitution_scale, r.friction_scale) = [t.data_ptr() if t is not None else None for t in self._dr]
+        r.action_noise_sigma, r.observation_noise_sigma = float(action_noise_sigma), float(observation_noise_sigma)
+        _lib.check(self.L.ppenv_set_randomization(self.h, C.byref(r)))
+
+    def clear_randomization(self):
+        _lib.check(self.L.ppenv_set_randomization(self.h, None))
+        self._dr = None
+
+    def set_gravity(self, gravity_z):
+        _lib.check(self.L.ppenv_set_gravity(self.h, float(gravity_z)))
+
     @property
     def status(self):
         """PPENV_STATUS_* bits reported by the kernels (0 = healthy); read without synchronising."""

@@ -106,6 +106,13 @@ class Config(C.Structure):
     ]
 
 
+class Randomization(C.Structure):
+    """ctypes mirror of ppenv_randomization (include/ppenv.h): device pointers of the per-env tables + the two noise amplitudes."""
+    _fields_ = [("dof_stiffness_scale", C.c_void_p), ("dof_damping_scale", C.c_void_p), ("link_mass_scale", C.c_void_p),
+                ("restitution_scale", C.c_void_p), ("friction_scale", C.c_void_p), ("action_noise_sigma", C.c_float),
+                ("observation_noise_sigma", C.c_float)]
+
+
 class Buffers(C.Structure):
     _fields_ = [
         ("num_envs", C.c_int32), ("num_agents", C.c_int32),

@@ -74,10 +74,11 @@ class VecTask:
         self.extras = {}
         self.obs_dict = {}
         self.control_steps = 0
-        self.randomize = bool(config.get("task", {}).get("randomize", False))
-        if self.randomize:
-            raise NotImplementedError("domain randomisation is disabled in every reference config "
-                                      "(cfg/task/HumanoidPingpongTiltG1.yaml:101) and not implemented")
+        task_cfg = config.get("task", {}) or {}
+        self.randomize = bool(task_cfg.get("randomize", False))                     # cfg/task/HumanoidPingpongTiltG1.yaml:101
+        self.randomization_params = task_cfg.get("randomization_params", {}) or {}  # yaml:102-169
+        self.first_randomization, self.last_step, self.last_rand_step = True, -1, -1
+        self.stats_every = int(config.get("stats_every", 40))                       # TT:763: the reference prints the means every 40 steps
 
         self.sim = self.create_sim()       # the reference's VecTask.__init__ calls back create_sim (TT:325)
         self.allocate_buffers()
@@ -105,13 +106,90 @@ class VecTask:
         """One control step: K1..K8 in a single kernel launch (TT:1002-1052).  controlFrequencyInv = k (upstream: pre_physics_step
         once, k simulate calls, post_physics_step once) is folded into the native config at create time — k * substeps physics
         substeps of the same length ahead of one reward / reset / observation pass — so it is still one launch."""
+        if self.randomize:                   # upstream applies them from _reset_idx (TT:849-850); here once per step, gated by `frequency`
+            self.apply_randomizations(self.randomization_params)
         self.env.step(actions)              # action clamp (clipActions) happens inside the kernel
         self.control_steps += 1
+        self.last_step = self.control_steps
+        if self.stats_every > 0 and self.control_steps % self.stats_every == 0:
+            self._export_means()
         # upstream: timeout_buf = (progress_buf >= max_episode_length - 1) & (reset_buf != 0), evaluated after
         # post_physics_step.  These tasks zero progress_buf inside post_physics_step on every reset (TT:902), so
         # upstream's time_outs is identically False for them; keep the (constant) tensor instead of two launches.
         self.extras["time_outs"] = self.timeout_buf if self.rl_device == self.device else self.timeout_buf.to(self.rl_device)
         return self._obs_dict(), self._to_rl(self.rew_buf), self._to_rl(self.reset_buf), self.extras
+
+    def _export_means(self):
+        """extras['reward_mean'], extras['progress_mean'] (TT:763-768: the reference computes them every 40 steps and — its two
+        `self.extras[...] =` lines are commented out — prints them).  One reduction launch (ppenv_reduce_stats), no host
+        synchronisation: the values are 0-dim tensors on the sim device."""
+        s = self.env.reduce_stats()
+        self.extras["reward_mean"] = (s[0] / s[3]).float()
+        self.extras["progress_mean"] = (s[1] / s[3]).float()
+
+    def apply_randomizations(self, dr_params):
+        """Domain randomisation (TT:849-850 -> upstream VecTask.apply_randomizations; parameters cfg/task/HumanoidPingpongTiltG1.yaml:
+        102-169).  Every `frequency` control steps (and before the first) new values are drawn — per env, with the yaml's
+        distribution / operation / schedule — for: observation and action noise, gravity, the humanoid's link masses, shape friction
+        and restitution, dof stiffness and damping.  The draws land in per-env device tables the step kernel reads
+        (ppenv_set_randomization); gravity is one value for the simulation.  `color`, `lower` / `upper` and `setup_only`'s
+        distinction have no counterpart here and are ignored (the limits enter the compiled model)."""
+        if not dr_params:
+            return
+        freq = int(dr_params.get("frequency", 1))
+        if not self.first_randomization and (self.last_step - self.last_rand_step) < freq:
+            return
+        self.first_randomization, self.last_rand_step = False, self.last_step
+        n, dev = self.num_envs, self.device
+        gen = getattr(self, "_dr_gen", None)
+        if gen is None:
+            gen = self._dr_gen = torch.Generator(device=dev).manual_seed(int(self.cfg.get("seed", 0)) + 7919)
+
+        def sched(p):
+            if p.get("schedule") == "linear":
+                return min(max(self.last_step, 0), int(p["schedule_steps"])) / float(p["schedule_steps"])
+            if p.get("schedule") == "constant":
+                return 1.0 if self.last_step > int(p["schedule_steps"]) else 0.0
+            return 1.0
+
+        def sample(p, shape):
+            """Upstream semantics: `range` = (lo, hi) for uniform / (mu, sigma) for gaussian; a scaling is blended towards 1 and an
+            additive term towards 0 by the schedule."""
+            a, b = float(p["range"][0]), float(p["range"][1])
+            if p.get("distribution", "uniform") == "gaussian":
+                v = torch.randn(shape, device=dev, generator=gen) * b + a
+            else:
+                v = torch.rand(shape, device=dev, generator=gen) * (b - a) + a
+            s = sched(p)
+            return v * s + (1.0 - s) if p.get("operation") == "scaling" else v * s
+
+        kw = {}
+        act, obs = dr_params.get("actions"), dr_params.get("observations")
+        if act:
+            kw["action_noise_sigma"] = float(act["range"][1]) * sched(act)
+        if obs:
+            kw["observation_noise_sigma"] = float(obs["range"][1]) * sched(obs)
+        g = (dr_params.get("sim_params") or {}).get("gravity")
+        if g:
+            base = self.native_config.gravity_z
+            dz = float(sample(g, (1,)).item()) if g.get("operation") == "additive" else 0.0
+            self.env.set_gravity(min(base + dz, 0.0) if g.get("operation") == "additive" else base * float(sample(g, (1,)).item()))
+        hum = ((dr_params.get("actor_params") or {}).get("humanoid") or {})
+        mass = (hum.get("rigid_body_properties") or {}).get("mass")
+        if mass:
+            kw["link_mass_scale"] = sample(mass, (scene.NUM_DOF, n))
+        shape = hum.get("rigid_shape_properties") or {}
+        if shape.get("friction"):
+            kw["friction_scale"] = sample(shape["friction"], (n,))
+        if shape.get("restitution"):
+            kw["restitution_scale"] = sample(shape["restitution"], (n,))
+        dof = hum.get("dof_properties") or {}
+        if dof.get("stiffness"):
+            kw["dof_stiffness_scale"] = sample(dof["stiffness"], (scene.NUM_DOF, n))
+        if dof.get("damping"):
+            kw["dof_damping_scale"] = sample(dof["damping"], (scene.NUM_DOF, n))
+        self.env.set_randomization(**kw)
+        self.randomize_buf.zero_()
 
     def reset(self):
         """Observation dictionary of the current state (upstream VecTask.reset does not step the simulator)."""
@@ -310,6 +388,9 @@ class HumanoidPingpongTiltNESSparse27DOF(VecTask):
         keys = ("episodeLength", "alphaVelocityReward", "powerCoefficient", "hitTableReward", "nothitTablePenalty", "crossNetRewardFloat",
                 "diePenaltyFloat", "hitPaddleReward", "missPaddlePenaltyCoefficient")
         env = {k: self.cfg["env"][k] for k in keys if k in self.cfg["env"]}
+        if self.randomize:
+            raise NotImplementedError("task.randomize = True: the randomisation tables are wired for the fused 7-dof step (ppenv_set_randomization); "
+                                      "the 27-dof task's yaml has randomize: False (cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml)")
         if self.control_freq_inv != 1:
             raise NotImplementedError("controlFrequencyInv != 1 is not wired for the 27-dof task (its yaml has none; "
                                       "cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml)")
@@ -333,6 +414,9 @@ class HumanoidPingpongTiltNESSparse27DOF(VecTask):
     def step(self, actions):
         self.env.step(actions)              # the clipActions clamp happens inside the kernel
         self.control_steps += 1
+        if self.stats_every > 0 and self.control_steps % self.stats_every == 0:   # TA:860-866 prints the same two means every 40 steps
+            self.extras["reward_mean"] = self.rew_buf.mean()
+            self.extras["progress_mean"] = self.progress_buf.float().mean()
         self.extras["time_outs"] = self.timeout_buf if self.rl_device == self.device else self.timeout_buf.to(self.rl_device)
         return self._obs_dict(), self._to_rl(self.rew_buf), self._to_rl(self.reset_buf), self.extras
 

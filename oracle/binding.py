@@ -125,6 +125,20 @@ class OracleEnv:
     def set_threads(self, t):
         self.L.ppo_set_threads(self.h, t)
 
+    def set_randomization(self, dof_stiffness_scale=None, dof_damping_scale=None, link_mass_scale=None, restitution_scale=None,
+                          friction_scale=None, action_noise_sigma=0.0, observation_noise_sigma=0.0, on=True):
+        tabs = [None if t is None else np.ascontiguousarray(t, np.float32) for t in
+                (dof_stiffness_scale, dof_damping_scale, link_mass_scale, restitution_scale, friction_scale)]
+        self.L.ppo_set_randomization.argtypes = [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_int]
+        rc = self.L.ppo_set_randomization(self.h, *[t.ctypes.data_as(C.c_void_p) if t is not None else None for t in tabs],
+                                          C.c_float(action_noise_sigma), C.c_float(observation_noise_sigma), int(on))
+        assert rc == 0, rc
+
+    def set_gravity(self, gz):
+        self.L.ppo_set_gravity.argtypes = [C.c_void_p, C.c_float]
+        self.L.ppo_set_gravity.restype = None
+        self.L.ppo_set_gravity(self.h, C.c_float(gz))
+
     def reset_idx(self, env_ids, refresh_obs=True):
         ids = np.ascontiguousarray(env_ids, np.int64).reshape(-1)
         self.L.ppo_reset_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]

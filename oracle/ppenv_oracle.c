@@ -55,6 +55,8 @@ typedef struct ppo_env {
     uint32_t *flags, *episode;
     float *serve; /* [3][N] */
     int serve_on;
+    ppenv_config* cfg_env;   /* domain randomisation: one scaled copy of cfg per env, or NULL */
+    float dr_action_sigma, dr_obs_sigma;
     int threads;
 } ppo_env;
 
@@ -611,7 +613,7 @@ ppo_env* ppo_create(const ppenv_config* cfg) {
 void ppo_destroy(ppo_env* e) {
     if (!e) return;
     free(e->obs); free(e->rew); free(e->reset); free(e->progress); free(e->dof_pos); free(e->dof_vel);
-    free(e->dof_force); free(e->ball); free(e->flags); free(e->episode); free(e->serve); free(e);
+    free(e->dof_force); free(e->ball); free(e->flags); free(e->episode); free(e->serve); free(e->cfg_env); free(e);
 }
 void ppo_set_threads(ppo_env* e, int t) { e->threads = t > 0 ? t : 1; }
 
@@ -728,6 +730,42 @@ int ppo_reset_idx(ppo_env* e, const int64_t* ids, int count, int refresh_obs) {
     }
     return 0;
 }
+/* Domain randomisation of the fused 3-actor step (include/ppenv.h ppenv_randomization): per-env tables as host arrays (SoA [rows][N],
+ * NULL = not randomised).  The oracle gives every env its own copy of the config with the scales applied. */
+int ppo_set_randomization(ppo_env* e, const float* kp_scale, const float* kd_scale, const float* mass_scale, const float* e_scale,
+                          const float* mu_scale, float action_sigma, float obs_sigma, int on) {
+    free(e->cfg_env);
+    e->cfg_env = NULL;
+    e->dr_action_sigma = e->dr_obs_sigma = 0.f;
+    if (!on) return 0;
+    if (e->A != 1) return -1;
+    e->dr_action_sigma = action_sigma; e->dr_obs_sigma = obs_sigma;
+    if (!kp_scale && !kd_scale && !mass_scale && !e_scale && !mu_scale) return 0;
+    int n = e->n;
+    e->cfg_env = (ppenv_config*)malloc((size_t)n * sizeof(ppenv_config));
+    if (!e->cfg_env) return -2;
+    for (int i = 0; i < n; i++) {
+        ppenv_config* c = &e->cfg_env[i];
+        *c = e->cfg;
+        for (int d = 0; d < ND; d++) {
+            if (kp_scale) c->joint[d].kp *= kp_scale[(size_t)d * n + i];
+            if (kd_scale) c->joint[d].kd *= kd_scale[(size_t)d * n + i];
+            if (mass_scale) {
+                float s = mass_scale[(size_t)d * n + i];
+                c->joint[d].mass *= s;
+                for (int k = 0; k < 6; k++) c->joint[d].inertia[k] *= s;
+            }
+        }
+        float es = e_scale ? e_scale[i] : 1.f, fs = mu_scale ? mu_scale[i] : 1.f;
+        c->paddle_restitution = fminf(c->paddle_restitution * es, c->restitution_max); c->paddle_friction *= fs;
+        for (int s = 0; s < c->num_shapes; s++) { c->shape[s].restitution = fminf(c->shape[s].restitution * es, c->restitution_max); c->shape[s].friction *= fs; }
+    }
+    return 0;
+}
+void ppo_set_gravity(ppo_env* e, float gz) {
+    e->cfg.gravity_z = gz;
+    if (e->cfg_env) for (int i = 0; i < e->n; i++) e->cfg_env[i].gravity_z = gz;
+}
 void ppo_set_serve_override(ppo_env* e, const float* serve /* [N,3] */, int on) {
     e->serve_on = on;
     if (on && serve)
@@ -736,16 +774,28 @@ void ppo_set_serve_override(ppo_env* e, const float* serve /* [N,3] */, int on) 
 }
 
 /* -------------------------------------------------------------------- the step */
+/* additive Gaussian white noise of the domain randomisation (yaml:106-113): Box-Muller on two counter-RNG draws keyed by
+ * (seed, global env id, episode, progress * 256 + index); float arithmetic, the same in the kernel (ppenv_device.h dr_gauss) */
+static float dr_gauss(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t progress, uint32_t index) {
+    uint32_t k = progress * 256u + index;
+    float u1 = rng_uniform(seed ^ 0x5DEECE66Dull, gid, episode, 2u * k), u2 = rng_uniform(seed ^ 0x5DEECE66Dull, gid, episode, 2u * k + 1u);
+    float rad = sqrtf(-2.0f * logf(fmaxf(u1, 5.9604645e-8f)));
+    return rad * cosf(6.2831853f * u2);
+}
+
 static void step_env(ppo_env* e, int i, const float* actions) {
-    const ppenv_config* c = &e->cfg;
+    const ppenv_config* c = e->cfg_env ? &e->cfg_env[i] : &e->cfg;      /* domain randomisation: this env's own scaled model */
     int n = e->n;
     float qf[ND], qdf[ND], ballf[13];
     gather_env(e, i, qf, qdf, ballf);
+    const uint32_t dr_gid = (uint32_t)(c->env_id_offset + i), dr_ep = e->episode[i], dr_prog = (uint32_t)e->progress[i];
 
     /* pre_physics_step: TT:1003-1020 (clamp is VecTask.step, clipActions) */
     double target[ND];
     for (int d = 0; d < ND; d++) {
-        target[d] = pd_target(actions[(size_t)i * ND + d], c->joint[d].lower, c->joint[d].upper, c->clip_actions);   /* TT:1008 */
+        float act = actions[(size_t)i * ND + d];
+        if (e->dr_action_sigma > 0.f) act += e->dr_action_sigma * dr_gauss(c->seed, dr_gid, dr_ep, dr_prog, (uint32_t)d);   /* before the clamp, as upstream VecTask.step */
+        target[d] = pd_target(act, c->joint[d].lower, c->joint[d].upper, c->clip_actions);   /* TT:1008 */
     }
     float pre_vx = ballf[7];                                        /* TT:1020 */
 
@@ -815,6 +865,8 @@ static void step_env(ppo_env* e, int i, const float* actions) {
     e->progress[i] = progress; e->flags[i] = flags; e->rew[i] = rew; e->reset[i] = reset;
     /* TT:1039: dof / ball already show the reset state, body states are the pre-reset ones */
     compute_obs(bs, qf, qdf, ballf, &e->obs[(size_t)i * PPENV_NUM_OBS]);
+    if (e->dr_obs_sigma > 0.f)
+        for (int k = 0; k < PPENV_NUM_OBS; k++) e->obs[(size_t)i * PPENV_NUM_OBS + k] += e->dr_obs_sigma * dr_gauss(c->seed, dr_gid, dr_ep, dr_prog, 16u + (uint32_t)k);
 }
 
 static void step_env_t4(ppo_env* e, int i, const float* actions);

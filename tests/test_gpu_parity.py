@@ -479,3 +479,124 @@ def test_handoff_timeout_is_reported_not_stored(torch_cuda, monkeypatch):
     torch.cuda.synchronize()
     assert ok.status == 0
     ok.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N4: domain randomisation tables + extras
+
+
+def _dr_tables(n, rng):
+    return dict(dof_stiffness_scale=rng.uniform(0.5, 1.5, (7, n)).astype(np.float32), dof_damping_scale=rng.uniform(0.5, 1.5, (7, n)).astype(np.float32),
+                link_mass_scale=rng.uniform(0.5, 1.5, (7, n)).astype(np.float32), restitution_scale=rng.uniform(0.0, 0.7, n).astype(np.float32),
+                friction_scale=rng.uniform(0.7, 1.3, n).astype(np.float32))
+
+
+def test_randomization_off_is_bit_identical_and_unit_tables_change_nothing(torch_cuda):
+    """ppenv_set_randomization(NULL) / never set: the step kernel that ran before runs, bit for bit.  And the table-reading instantiation
+    with every scale 1 and no noise reproduces the one-wave kernel it is an instantiation of."""
+    torch = torch_cuda
+    n = 1000
+    mk = lambda: make_env(scene.build_config("TT", num_envs=n, seed=9))
+    a, b = mk(), mk()
+    b.set_randomization(**{k: np.full_like(v, 1.7) for k, v in _dr_tables(n, np.random.default_rng(0)).items()}, action_noise_sigma=0.5)
+    b.clear_randomization()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(150):
+        act = torch.rand(n, 7, device="cuda", generator=gen) * 2 - 1
+        a.step(act)
+        b.step(act)
+    for name in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "dof_pos", "dof_vel", "dof_force", "ball", "flags", "episode"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    a.close(); b.close()
+
+
+def test_unit_randomization_tables_reproduce_the_plain_kernel(torch_cuda, monkeypatch):
+    torch = torch_cuda
+    n = 512
+    monkeypatch.setenv("PPENV_STEP_KERNEL", "fused")       # the DR instantiation is the one-wave kernel with table reads
+    a, b = make_env(scene.build_config("TT", num_envs=n, seed=9)), make_env(scene.build_config("TT", num_envs=n, seed=9))
+    b.set_randomization(**{k: np.ones_like(v) for k, v in _dr_tables(n, np.random.default_rng(0)).items()})
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(40):
+        act = torch.rand(n, 7, device="cuda", generator=gen) * 2 - 1
+        b.set_state(a.get_state())
+        a.step(act)
+        b.step(act)
+        for name in ("obs_buf", "rew_buf", "dof_pos", "dof_vel", "ball"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-5), (name, t, float((x - y).abs().max()))
+        assert torch.equal(a.reset_buf, b.reset_buf)
+    a.close(); b.close()
+
+
+def test_randomized_step_matches_oracle(torch_cuda, oracle_lib):
+    """Randomisation on: per-env stiffness / damping / mass / restitution / friction tables, action and observation noise, another
+    gravity — the kernel against the oracle with the same tables, restarted from the oracle's state every step."""
+    torch = torch_cuda
+    n = 768
+    cfg = scene.build_config("TT", num_envs=n, seed=17)
+    o = oracle_lib.OracleEnv(cfg, threads=8)
+    env = make_env(scene.build_config("TT", num_envs=n, seed=17))
+    rng = np.random.default_rng(8)
+    tabs = _dr_tables(n, rng)
+    kw = dict(action_noise_sigma=0.02, observation_noise_sigma=0.002)          # yaml:106-113
+    probe = SensitivityProbe(oracle_lib, cfg)
+    for x in (o, probe.o2):
+        x.set_randomization(**tabs, **kw)
+        x.set_gravity(-9.8 - 0.3)
+    env.set_randomization(**tabs, **kw)
+    env.set_gravity(-9.8 - 0.3)
+    oa, ra = obs_atol() + 2e-6, reward_atol(cfg)
+    log = ExclusionLog("gpu randomised fused step vs oracle [TT]", bound=0.01)
+    resets = 0
+    for t in range(120):
+        actions = rng.uniform(-1.2, 1.2, (n, 7)).astype(np.float32)
+        st = o.get_state()
+        env.set_state(st)
+        o.step(actions)
+        env.step(torch.from_numpy(actions).cuda())
+        keep = ~probe.sensitive(st, actions, o)
+        log.add(keep)
+        v, om = mask_envs(DevView(env), keep), mask_envs(o, keep)
+        np.testing.assert_array_equal(v.reset_buf, om.reset_buf, err_msg=f"reset step {t}")
+        np.testing.assert_array_equal(v.flags, om.flags, err_msg=f"flags step {t}")
+        assert_state_close(v, om, f"step {t}")
+        assert_close(v.obs_buf, om.obs_buf, f"obs step {t}", atol=oa)
+        assert_close(v.rew_buf, om.rew_buf, f"rew step {t}", atol=ra)
+        resets += int(o.reset_buf.sum())
+    assert resets > 30
+    log.close()
+    # the randomisation did something: a second oracle without it ends up elsewhere
+    plain = oracle_lib.OracleEnv(cfg, threads=8)
+    plain.set_state(st)
+    plain.step(actions)
+    assert np.abs(plain.dof_vel - o.dof_vel).max() > 1e-2 and np.abs(plain.obs_buf - o.obs_buf).max() > 1e-3
+    env.close()
+
+
+def test_vectask_randomize_true_and_extras(torch_cuda):
+    """cfg task.randomize = True with the reference yaml's randomization_params block (yaml:102-169) steps; extras carries
+    reward_mean / progress_mean (TT:767-768) as device scalars."""
+    torch = torch_cuda
+    import json
+    import os
+    from helpers import GOLDEN_DIR
+    from isaacgym_amd.tasks import isaacgym_task_map
+    snap = json.load(open(os.path.join(GOLDEN_DIR, "task_cfgs.json")))["HumanoidPingpongTiltG1"]["task"]
+    assert snap["task"]["randomize"] is False and snap["task"]["randomization_params"]["frequency"] == 600
+    n = 256
+    cfg = scene.default_task_cfg("TT")
+    cfg["env"]["numEnvs"], cfg["seed"], cfg["stats_every"] = n, 3, 4
+    cfg["task"] = dict(randomize=True, randomization_params=dict(snap["task"]["randomization_params"], frequency=5))
+    task = isaacgym_task_map["HumanoidPingpongTiltG1"](cfg, "cuda:0", "cuda:0", -1, True, False, False)
+    plain = isaacgym_task_map["HumanoidPingpongTiltG1"](dict(scene.default_task_cfg("TT"), seed=3, env=dict(cfg["env"])), "cuda:0", "cuda:0", -1, True, False, False)
+    a = torch.zeros(n, 7, device="cuda")
+    for t in range(12):
+        od, rew, done, extras = task.step(a)
+        plain.step(a)
+    assert torch.isfinite(od["obs"]).all() and torch.isfinite(rew).all()
+    assert task.env._dr[0].shape == (7, n) and float(task.env._dr[0].min()) > 0.49 and float(task.env._dr[2].max()) < 1.51
+    assert not torch.equal(task.obs_buf, plain.obs_buf)                      # observation noise at the very least
+    assert extras["reward_mean"].device.type == "cuda" and extras["reward_mean"].dim() == 0
+    np.testing.assert_allclose(float(extras["reward_mean"]), float(task.rew_buf.mean()), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(float(extras["progress_mean"]), 12.0, rtol=1e-6)
