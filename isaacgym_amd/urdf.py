@@ -10,6 +10,11 @@ inertials, revolute / fixed joints with origins, axes and limits) and produces
   * `ta_model(robot, dof_joint_names, body_names, ...)`: the 28-link tree of the 27-dof task as a `scene.TAModel` — welded
     bodies (fixed joints) are merged into the link that carries them, exactly what `scene.build_ta_model` does by hand.
 
+`<collision>` geometry (box / sphere / cylinder / capsule with its origin) is read too and turned into the tables that are not
+inertial data: `ball_shapes` (the capsule / sphere shapes the ball collides with, link-attached end points + radius),
+`paddle_blade` (a cylinder on the paddle link -> blade centre, normal, radius, half thickness) and `ground_contacts` (the points
+tested against the ground plane: the bottom corners of box collisions such as the G1's feet, the low points of the others).
+
 `write_g1_urdf()` emits the placeholder model as a URDF; tests/golden/g1_27dof_placeholder.urdf is its output, and the tests
 check that parsing it reproduces the hand-built tables.  No real asset has been seen by this code.
 """
@@ -21,8 +26,35 @@ import numpy as np
 from . import scene
 
 
+class Collision:
+    """One <collision> element: `kind` in box / sphere / cylinder / capsule; `size` = (x, y, z) for a box, (radius,) for a sphere,
+    (radius, length) for a cylinder or capsule (axis = local z, URDF convention); pose in the link frame."""
+
+    def __init__(self, kind, size, xyz=(0.0, 0.0, 0.0), rpy=(0.0, 0.0, 0.0)):
+        self.kind, self.size = kind, tuple(float(v) for v in size)
+        self.xyz = np.asarray(xyz, dtype=np.float64)
+        self.rot = scene.rpy_to_rot(*rpy)
+
+    def segment(self):
+        """(a, b, radius) of a sphere / cylinder / capsule in the link frame (a == b for a sphere)."""
+        if self.kind == "sphere":
+            return self.xyz.copy(), self.xyz.copy(), self.size[0]
+        if self.kind in ("cylinder", "capsule"):
+            half = self.rot @ np.array([0.0, 0.0, 0.5 * self.size[1]])
+            return self.xyz - half, self.xyz + half, self.size[0]
+        raise ValueError(f"a {self.kind} collision has no axis segment")
+
+    def corners(self):
+        """The eight corners of a box in the link frame."""
+        if self.kind != "box":
+            raise ValueError(f"a {self.kind} collision has no corners")
+        h = 0.5 * np.asarray(self.size)
+        return [self.xyz + self.rot @ (h * np.array(s)) for s in ((-1, -1, -1), (-1, 1, -1), (1, -1, -1), (1, 1, -1), (-1, -1, 1), (-1, 1, 1), (1, -1, 1), (1, 1, 1))]
+
+
 class Link:
     def __init__(self, name, mass=0.0, com=(0.0, 0.0, 0.0), com_rpy=(0.0, 0.0, 0.0), inertia=None):
+        self.collisions = []
         self.name, self.mass = name, float(mass)
         self.com = np.asarray(com, dtype=np.float64)
         self.com_rot = scene.rpy_to_rot(*com_rpy)
@@ -65,11 +97,33 @@ def parse(text):
     if root.tag != "robot":
         raise ValueError("not a URDF: the root element is not <robot>")
     links, joints = {}, {}
+    def collisions_of(e):
+        out = []
+        for c in e.findall("collision"):
+            o, g = c.find("origin"), c.find("geometry")
+            xyz = _floats(o.get("xyz") if o is not None else None, 3, (0, 0, 0))
+            rpy = _floats(o.get("rpy") if o is not None else None, 3, (0, 0, 0))
+            if g is None or len(g) != 1:
+                raise ValueError(f"link {e.get('name')}: a <collision> needs exactly one geometry")
+            k = g[0]
+            if k.tag == "box":
+                out.append(Collision("box", _floats(k.get("size"), 3, ()), xyz, rpy))
+            elif k.tag == "sphere":
+                out.append(Collision("sphere", (float(k.get("radius")),), xyz, rpy))
+            elif k.tag in ("cylinder", "capsule"):
+                out.append(Collision(k.tag, (float(k.get("radius")), float(k.get("length"))), xyz, rpy))
+            elif k.tag == "mesh":
+                continue        # meshes carry no analytic shape: the ball-collision tables need primitives
+            else:
+                raise ValueError(f"link {e.get('name')}: collision geometry <{k.tag}> is not supported")
+        return out
+
     for e in root.findall("link"):
         name = e.get("name")
         inert = e.find("inertial")
         if inert is None:
             links[name] = Link(name)
+            links[name].collisions = collisions_of(e)
             continue
         o = inert.find("origin")
         com = _floats(o.get("xyz") if o is not None else None, 3, (0, 0, 0))
@@ -79,6 +133,7 @@ def parse(text):
         ixx, iyy, izz = (float(i.get(k, 0.0)) for k in ("ixx", "iyy", "izz"))
         ixy, ixz, iyz = (float(i.get(k, 0.0)) for k in ("ixy", "ixz", "iyz"))
         links[name] = Link(name, mass, com, rpy, [[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+        links[name].collisions = collisions_of(e)
     for e in root.findall("joint"):
         name, jtype = e.get("name"), e.get("type")
         if jtype not in ("revolute", "continuous", "fixed"):
@@ -214,6 +269,77 @@ def ta_model(robot, dof_joint_names, body_names, gains=None, armature=None, cont
         scene._set(f.rot, rot.reshape(-1))
     scene.fill_ta_contacts_and_limits(m, contacts=contacts, bound=bound)
     return m
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# <collision> geometry -> the tables that are not inertial data
+def _carrier_of(robot, movable_links):
+    """name -> (index into `movable_links`, offset, rotation): the movable link a body is (transitively) welded to."""
+    index = {n: i for i, n in enumerate(movable_links)}
+
+    def carrier(name):
+        off, rot = np.zeros(3), np.eye(3)
+        while name not in index:
+            j = robot.joint_of_child.get(name)
+            if j is None or j.type != "fixed":
+                raise ValueError(f"link {name} is not welded to one of the movable links")
+            r = scene.rpy_to_rot(*j.rpy)
+            off, rot = j.xyz + r @ off, r @ rot
+            name = j.parent
+        return index[name], off, rot
+    return carrier
+
+
+def ball_shapes(robot, movable_links, link_names=None):
+    """The capsule / sphere shapes the ball can hit, from the sphere / cylinder / capsule collisions of `link_names` (default: every
+    link that has one): [dict(link = index into movable_links, a, b, radius)], end points in that movable link's frame.  Boxes are
+    not ball shapes here (the table and the net are the scene's slabs; a box on the humanoid would need its own narrow phase)."""
+    carrier = _carrier_of(robot, movable_links)
+    out = []
+    for name in (link_names if link_names is not None else list(robot.links)):
+        for c in robot.links[name].collisions:
+            if c.kind == "box":
+                continue
+            li, off, rot = carrier(name)
+            a, b, r = c.segment()
+            out.append(dict(link=li, a=tuple(off + rot @ a), b=tuple(off + rot @ b), radius=r, body=name))
+    return out
+
+
+def paddle_blade(robot, movable_links, paddle_link):
+    """The blade from the (single) cylinder collision of `paddle_link`: centre, unit normal (the cylinder's axis), radius and half
+    thickness, in the frame of the movable link that carries the paddle — the fields of ppenv_config.paddle_*."""
+    cyl = [c for c in robot.links[paddle_link].collisions if c.kind == "cylinder"]
+    if len(cyl) != 1:
+        raise ValueError(f"link {paddle_link}: expected one cylinder collision for the blade, found {len(cyl)}")
+    li, off, rot = _carrier_of(robot, movable_links)(paddle_link)
+    c = cyl[0]
+    n = rot @ c.rot @ np.array([0.0, 0.0, 1.0])
+    return dict(link=li, center=tuple(off + rot @ c.xyz), normal=tuple(n / np.linalg.norm(n)), radius=c.size[0], half_thickness=0.5 * c.size[1])
+
+
+def ground_contacts(robot, movable_links, link_names, down=(0.0, 0.0, -1.0), max_points=scene.TA_MAX_CONTACTS):
+    """Points tested against the ground plane, [(movable link index, point in its frame)], from the collisions of `link_names`:
+    a box (the G1's feet) gives the four corners of its face that looks along `down` at the zero pose; a sphere its lowest point;
+    a cylinder / capsule the low points under its two ends."""
+    carrier = _carrier_of(robot, movable_links)
+    d = np.asarray(down, dtype=np.float64)
+    out = []
+    for name in link_names:
+        li, off, rot = carrier(name)
+        for c in robot.links[name].collisions:
+            if c.kind == "box":
+                pts = sorted((off + rot @ p for p in c.corners()), key=lambda p: -float(p @ d))[:4]
+                pts = sorted(pts, key=lambda p: (round(float(p[0]), 9), round(float(p[1]), 9)))
+            elif c.kind == "sphere":
+                pts = [off + rot @ c.xyz + d * c.size[0]]
+            else:
+                a, b, r = c.segment()
+                pts = [off + rot @ a + d * r, off + rot @ b + d * r]
+            out += [(li, tuple(float(x) for x in p)) for p in pts]
+    if len(out) > max_points:
+        raise ValueError(f"{len(out)} ground-contact points, the model holds {max_points}")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------

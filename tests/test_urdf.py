@@ -72,3 +72,81 @@ def test_importer_rejects_what_the_kernels_cannot_represent():
     names = urdf.ta_dof_joint_names()
     with pytest.raises(ValueError, match="not one of the 27 dofs"):
         urdf.ta_model(urdf.parse(urdf.write_g1_urdf(weld_right_elbow=False)), names, urdf.G1_BODY_NAMES)   # a 29-dof arm under a 27-dof list
+
+
+# A second, hand-written asset: every expected number below is typed here, not generated from scene.py.
+HAND_URDF = """<?xml version="1.0"?>
+<robot name="toy">
+  <link name="base">
+    <inertial><origin xyz="0 0 0.1"/><mass value="2.0"/><inertia ixx="0.02" iyy="0.03" izz="0.04" ixy="0" ixz="0" iyz="0"/></inertial>
+    <collision><origin xyz="0 0 0.05"/><geometry><sphere radius="0.12"/></geometry></collision>
+  </link>
+  <link name="upper">
+    <inertial><origin xyz="0.1 0 0"/><mass value="1.0"/><inertia ixx="0.001" iyy="0.01" izz="0.01" ixy="0" ixz="0" iyz="0"/></inertial>
+    <collision><origin xyz="0.15 0 0" rpy="0 1.5707963267948966 0"/><geometry><cylinder radius="0.03" length="0.2"/></geometry></collision>
+  </link>
+  <link name="foot">
+    <inertial><origin xyz="0.03 0 -0.02"/><mass value="0.5"/><inertia ixx="0.0004" iyy="0.0009" izz="0.001" ixy="0" ixz="0" iyz="0"/></inertial>
+    <collision><origin xyz="0.04 0 -0.03"/><geometry><box size="0.2 0.08 0.02"/></geometry></collision>
+  </link>
+  <link name="blade">
+    <inertial><origin xyz="0 0 0"/><mass value="0.1"/><inertia ixx="0.0001" iyy="0.0001" izz="0.0002" ixy="0" ixz="0" iyz="0"/></inertial>
+    <collision><origin xyz="0 0.01 0" rpy="1.5707963267948966 0 0"/><geometry><cylinder radius="0.075" length="0.012"/></geometry></collision>
+  </link>
+  <joint name="j1" type="revolute"><origin xyz="0 0.1 0.2"/><parent link="base"/><child link="upper"/><axis xyz="0 1 0"/><limit lower="-1" upper="2" effort="30" velocity="10"/></joint>
+  <joint name="j2" type="revolute"><origin xyz="0.3 0 0"/><parent link="upper"/><child link="foot"/><axis xyz="1 0 0"/><limit lower="-0.5" upper="0.5" effort="20" velocity="8"/></joint>
+  <joint name="weld" type="fixed"><origin xyz="0.05 0 0.02"/><parent link="foot"/><child link="blade"/></joint>
+</robot>
+"""
+
+
+def test_collision_geometry_of_a_hand_written_urdf():
+    """<collision> primitives -> ball shapes, paddle blade and ground-contact points; the expected tables are typed in, the asset is
+    not derived from scene.py."""
+    robot = urdf.parse(HAND_URDF)
+    movable = ["base", "upper", "foot"]
+    assert [c.kind for c in robot.links["foot"].collisions] == ["box"] and robot.links["upper"].collisions[0].size == (0.03, 0.2)
+    shapes = urdf.ball_shapes(robot, movable, ["base", "upper"])
+    assert [s["link"] for s in shapes] == [0, 1]
+    np.testing.assert_allclose(shapes[0]["a"], (0, 0, 0.05), atol=1e-12)
+    np.testing.assert_allclose(shapes[0]["b"], (0, 0, 0.05), atol=1e-12)                 # a sphere: a == b
+    assert shapes[0]["radius"] == 0.12
+    # the cylinder's axis is its local z, pitched by 90 degrees onto the link's x: ends at x = 0.15 -+ 0.1
+    np.testing.assert_allclose(shapes[1]["a"], (0.05, 0, 0), atol=1e-12)
+    np.testing.assert_allclose(shapes[1]["b"], (0.25, 0, 0), atol=1e-12)
+    assert shapes[1]["radius"] == 0.03
+    # the blade hangs on the foot through a fixed joint: centre = weld offset + collision origin, normal = the cylinder's axis (local z
+    # rolled by +90 degrees about x: z -> -y), half thickness = length / 2
+    blade = urdf.paddle_blade(robot, movable, "blade")
+    assert blade["link"] == 2 and blade["radius"] == 0.075 and abs(blade["half_thickness"] - 0.006) < 1e-15
+    np.testing.assert_allclose(blade["center"], (0.05, 0.01, 0.02), atol=1e-12)
+    np.testing.assert_allclose(blade["normal"], (0, -1, 0), atol=1e-12)
+    # ground contacts: the bottom face of the foot box (centre (0.04, 0, -0.03), size 0.2 x 0.08 x 0.02), then the sphere's low point
+    pts = urdf.ground_contacts(robot, movable, ["foot", "base"])
+    assert [li for li, _ in pts] == [2, 2, 2, 2, 0]
+    np.testing.assert_allclose([p for _, p in pts[:4]], [(-0.06, -0.04, -0.04), (-0.06, 0.04, -0.04), (0.14, -0.04, -0.04), (0.14, 0.04, -0.04)], atol=1e-12)
+    np.testing.assert_allclose(pts[4][1], (0, 0, 0.05 - 0.12), atol=1e-12)
+    with pytest.raises(ValueError, match="not supported"):
+        urdf.parse(HAND_URDF.replace('<sphere radius="0.12"/>', '<cone radius="0.1"/>'))
+    with pytest.raises(ValueError, match="one cylinder"):
+        urdf.paddle_blade(robot, movable, "foot")
+
+
+def test_foot_contact_points_of_the_27dof_model_from_collision_boxes():
+    """The placeholder G1's sole corners (scene.TA_FOOT['points'], typed in scene.py) come out of a foot <collision> box of the same
+    extent, through ground_contacts -> ta_model(contacts=...)."""
+    text = urdf.write_g1_urdf()
+    box = '<collision><origin xyz="0.035 0 -0.03"/><geometry><box size="0.17 0.06 0.01"/></geometry></collision>'
+    for side in ("left", "right"):
+        text = text.replace(f'<link name="{side}_ankle_roll_link"><inertial>', f'<link name="{side}_ankle_roll_link">{box}<inertial>')
+    robot = urdf.parse(text)
+    names = urdf.ta_dof_joint_names()
+    movable = [robot.root()] + [robot.joints[n].child for n in names]
+    feet = urdf.ground_contacts(robot, movable, ["left_ankle_roll_link", "right_ankle_roll_link"])
+    assert [li for li, _ in feet] == [6] * 4 + [12] * 4
+    np.testing.assert_allclose([p for _, p in feet[:4]], [(-0.05, -0.03, -0.035), (-0.05, 0.03, -0.035), (0.12, -0.03, -0.035), (0.12, 0.03, -0.035)], atol=1e-12)
+    m = urdf.ta_model(robot, names, urdf.G1_BODY_NAMES, contacts=feet + list(scene.TA_BODY_CONTACTS))
+    want = scene.build_ta_model()
+    assert m.num_contacts == want.num_contacts
+    np.testing.assert_allclose(np.array([list(m.contact_point[k]) for k in range(m.num_contacts)]),
+                               np.array([list(want.contact_point[k]) for k in range(want.num_contacts)]), atol=1e-7)
