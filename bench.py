@@ -88,6 +88,49 @@ def cpu_baseline(num_envs, target_seconds=12.0, variant=VARIANT):
             "sample": f"{steps} steps of the {variant} variant at num_envs={num_envs}, OpenMP over envs, {dt:.1f} s"}
 
 
+def cpu_baseline_rows(cores, seconds=2.5):
+    """The rows BASELINE.md §3 promises next to the main cpu_baseline object, each on a bounded sample (`seconds` of CPU work):
+    the oracle (fp64 Newton-Euler + dense solve — a different algorithm and precision from the kernel) at BASELINE
+    config 1's shape (N = 64, T3 semantics: the runnable stand-in for tasks/humanoid_pingpong.py) and at N = 16384 TT,
+    with 1 thread and with all cores; and the kernel's OWN arithmetic (csrc/ppenv_device.h compiled for the host: tests/csrc/host_shim.cpp,
+    fp32 ABA, scalar, 1 thread) at N = 16384 TT."""
+    import numpy as np
+    from isaacgym_amd import scene
+    from oracle import binding as ob
+    rows = []
+
+    def timed(step, n, label, kind_note, threads):
+        rng = np.random.default_rng(0)
+        acts = [rng.uniform(-1, 1, (n, 7)).astype(np.float32) for _ in range(4)]
+        step(acts[0])
+        t0, k = time.perf_counter(), 0
+        while True:
+            step(acts[k % 4])
+            k += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or k >= 4000:
+                break
+        rows.append({"what": label, "value": n * k / dt, "unit": "env-steps/s", "cores": threads, "kind": "port", "arithmetic": kind_note,
+                     "sample": f"{k} steps at num_envs={n}, {dt:.1f} s"})
+
+    for variant, n in (("T3", 64), ("TT", 16384)):
+        for threads in sorted({1, cores}):
+            env = ob.OracleEnv(scene.build_config(variant, num_envs=n, seed=0), threads=threads)
+            timed(env.step, n, f"oracle, {variant}, N={n}, {threads} thread(s)", "fp64 recursive Newton-Euler + dense solve (oracle/ppenv_oracle.c)", threads)
+            env.close()
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import shim_binding as sb
+        shim = sb.ShimEnv(scene.build_config("TT", num_envs=16384, seed=0))
+        o = ob.OracleEnv(scene.build_config("TT", num_envs=16384, seed=0))
+        shim.copy_state_from(o)
+        o.close()
+        timed(shim.step, 16384, "kernel arithmetic on the host, TT, N=16384, 1 thread", "fp32 articulated-body algorithm: csrc/ppenv_device.h via tests/csrc/host_shim.cpp", 1)
+    except Exception as e:   # noqa: BLE001 - the host shim needs g++ on the box; the oracle rows stand without it
+        rows.append({"what": "kernel arithmetic on the host", "error": f"{type(e).__name__}: {e}"})
+    return rows
+
+
 def cpu_baseline_ta(num_envs, cores, target_seconds):
     """27-dof variant: the oracle's rigid-body step (OpenMP over envs) + its post_physics_step (one thread)."""
     import numpy as np
@@ -411,6 +454,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, variant=args.variant)
+            if args.variant == VARIANT:
+                out["cpu_baseline_rows"] = cpu_baseline_rows(out["cpu_baseline"]["cores"])
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:
