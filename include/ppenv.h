@@ -376,6 +376,12 @@ typedef struct ppenv_ta_params {
     float serve_tilt_lo_deg, serve_tilt_hi_deg;      /* -8 .. 3      (TA:130) */
     float serve_tilt_z_lo_deg, serve_tilt_z_hi_deg;  /* 14 .. 24     (TA:131) */
     float ball_y_lo, ball_y_hi, ball_z_lo, ball_z_hi; /* (-0.5, 0.1), (0.96, 1.05)  (TA:133-134) */
+    /* 1: initial_rb_states_dev holds ONE env's [42,13] block that every env is compared with.  The task creates every humanoid in
+     * the same pose (TA:578-579), so the 23 balance bodies' initial states (TA:200, 1152) are the same in every env; with this set
+     * the step reads 2 KB once instead of gathering 52-byte rows at a 2184-byte stride from an [N,42,13] tensor (the gathers cost
+     * more HBM traffic than everything else the 27-dof step moves).  0: a full [N,42,13] tensor, per env, as the reference keeps it. */
+    int32_t initial_rb_shared;
+    int32_t pad_;
 } ppenv_ta_params;
 
 /* One post_physics_step (TA:1145-1192).  Tensors in the reference's layouts, all device pointers:

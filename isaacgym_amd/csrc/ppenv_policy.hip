@@ -102,14 +102,18 @@ __device__ __forceinline__ void store_tile(_Float16* __restrict__ s, int tid, co
     }
 }
 
-// WM x WN waves per workgroup, 64 x 64 of `out` per wave: the tile is 64 WM x 64 WN.  (2, 2): 128 x 128, 74 KB of LDS, two
-// workgroups per CU; (4, 2): 256 x 128, 111 KB, one workgroup of eight waves per CU — a third fewer operand bytes per flop.
-template <bool OBS, int WM, int WN>
+// WM x WN waves per workgroup, (32 TI) x (32 TJ) of `out` per wave (TI x TJ MFMA tiles, 16 accumulator registers each): the
+// workgroup's tile is BM = 32 TI WM rows by BN = 32 TJ WN columns.  A K sub-step of 16 costs a wave TI + TJ fragment reads (16 bytes
+// per lane each) for TI TJ MFMAs: 1 read per MFMA at 2 x 2, 0.75 at 4 x 2, 0.5 at 4 x 4 — the LDS read traffic, not the global
+// traffic, is what the small wave tile pays for.
+template <bool OBS, int WM, int WN, int TI, int TJ>
 __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
-    constexpr int T = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN, CA = BM * 8 / T, CB = BN * 8 / T;
+    constexpr int T = 64 * WM * WN, BM = 32 * TI * WM, BN = 32 * TJ * WN, CA = BM * 8 / T, CB = BN * 8 / T;
     static_assert(BM * 8 % T == 0 && BN * 8 % T == 0, "staging shares");
+    static_assert(TI % 2 == 0 && TJ % 2 == 0, "the epilogue works on 64 x 64 blocks");
     __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * LDS_LD];
+    static_assert(2 * BM * LDS_LD >= WM * WN * 64 * LDS_LD, "epilogue patches fit the A buffers");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, b = blockIdx.z;
@@ -117,17 +121,16 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
     const _Float16* inh = OBS ? nullptr : reinterpret_cast<const _Float16*>(a.in) + (size_t)b * a.in_stride;
     const float* inf = OBS ? reinterpret_cast<const float*>(a.in) + (size_t)b * a.in_stride : nullptr;
 
-    f16v acc[2][2];
+    f16v acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TJ; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     // Operand pipeline: tile ks is in LDS, tiles ks + 1 and ks + 2 are on their way in two register sets.  A global load has two
-    // K-steps (>= 32 MFMAs per wave) to land before its registers are written to LDS — one step did not cover the latency of a
-    // load that misses L2 (measured: 18 % of the MFMA peak with a prefetch distance of one).
+    // K-steps to land before its registers are written to LDS.
     h8 ra[2][CA], rb[2][CB];
     const int ksteps = (a.k + BK - 1) / BK;
     auto gload = [&](int set, int ks) {
@@ -145,21 +148,21 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
     auto kstep = [&](int ks, int set_next) {   // set_next: the register set that holds tile ks + 1 (and is refilled with tile ks + 3)
         const int cur = ks & 1;
         // fragments of sub-step kk + 1 are read while the MFMAs of sub-step kk run (two fragment sets)
-        h8 fa[2][2], fb[2][2];
+        h8 fa[2][TI], fb[2][TJ];
         auto frags = [&](int set, int kk) {
 #pragma unroll
-            for (int i = 0; i < 2; i++) fa[set][i] = *reinterpret_cast<const h8*>(&sA[cur][(wm * 64 + i * 32 + r) * LDS_LD + kk * 16 + h * 8]);
+            for (int i = 0; i < TI; i++) fa[set][i] = *reinterpret_cast<const h8*>(&sA[cur][(wm * 32 * TI + i * 32 + r) * LDS_LD + kk * 16 + h * 8]);
 #pragma unroll
-            for (int j = 0; j < 2; j++) fb[set][j] = *reinterpret_cast<const h8*>(&sB[cur][(wn * 64 + j * 32 + r) * LDS_LD + kk * 16 + h * 8]);
+            for (int j = 0; j < TJ; j++) fb[set][j] = *reinterpret_cast<const h8*>(&sB[cur][(wn * 32 * TJ + j * 32 + r) * LDS_LD + kk * 16 + h * 8]);
         };
         frags(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK / 16; kk++) {
             if (kk + 1 < BK / 16) frags((kk + 1) & 1, kk + 1);
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < TI; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
         }
         if (ks + 1 < ksteps) {
             store_tile<T, CA>(sA[cur ^ 1], tid, ra[set_next]);   // the other buffer: last read before the barrier that ended step ks - 1
@@ -174,52 +177,58 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
     }
     // epilogue: C/D layout of the 32x32 MFMA — col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane holds ONE column,
     // so stored straight from the accumulators every store instruction would move 2 bytes per lane.  fp16 results therefore go through
-    // the wave's own 64 x 64 patch of LDS (the operand buffers are free after the last barrier) and leave as 16 bytes per lane, 128
-    // contiguous bytes per output row.  The fp32 heads (a few columns) are stored directly.
+    // the wave's own 64 x 64 patch of LDS (the operand buffers are free after the last barrier), one 64 x 64 block of the wave's tile at
+    // a time, and leave as 16 bytes per lane, 128 contiguous bytes per output row.  The fp32 heads (a few columns) are stored directly.
     const _Float16* bias = a.bias ? a.bias + (size_t)b * a.bias_stride : nullptr;
+    const int wrow0 = m0 + wm * 32 * TI, wcol0 = n0 + wn * 32 * TJ;
     if (!a.out_f32) {
         _Float16* patch = &sA[0][0] + wave * (64 * LDS_LD);
-        static_assert(2 * BM * LDS_LD >= WM * WN * 64 * LDS_LD, "epilogue patches fit the A buffers");
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int col = n0 + wn * 64 + j * 32 + r;
-            const float bv = (bias && col < a.n) ? (float)bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) {
-                    float x = acc[i][j][reg] + bv;
-                    if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
-                    patch[(i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * LDS_LD + j * 32 + r] = (_Float16)x;
-                }
-        }
-        __builtin_amdgcn_wave_barrier();   // the patch is this wave's own: DS operations of a wave execute in order
         _Float16* out = reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride;
         const int rl = lane >> 3, ch = lane & 7;
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int prow = it * 8 + rl, row = m0 + wm * 64 + prow, col = n0 + wn * 64 + ch * 8;
-            if (row >= a.m || col >= a.n) continue;
-            const h8 v = *reinterpret_cast<const h8*>(&patch[prow * LDS_LD + ch * 8]);
-            _Float16* dst = out + (size_t)row * a.ldo + col;
-            if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
-            else {
+        for (int ib = 0; ib < TI; ib += 2)
 #pragma unroll
-                for (int q = 0; q < 8; q++) if (col + q < a.n) dst[q] = v[q];
+            for (int jb = 0; jb < TJ; jb += 2) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int col = wcol0 + (jb + j) * 32 + r;
+                    const float bv = (bias && col < a.n) ? (float)bias[col] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg++) {
+                            float x = acc[ib + i][jb + j][reg] + bv;
+                            if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
+                            patch[(i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * LDS_LD + j * 32 + r] = (_Float16)x;
+                        }
+                }
+                __builtin_amdgcn_wave_barrier();   // the patch is this wave's own: DS operations of a wave execute in order
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int prow = it * 8 + rl, row = wrow0 + ib * 32 + prow, col = wcol0 + jb * 32 + ch * 8;
+                    if (row >= a.m || col >= a.n) continue;
+                    const h8 v = *reinterpret_cast<const h8*>(&patch[prow * LDS_LD + ch * 8]);
+                    _Float16* dst = out + (size_t)row * a.ldo + col;
+                    if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) if (col + q < a.n) dst[q] = v[q];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-        }
         return;
     }
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int col = n0 + wn * 64 + j * 32 + r;
+    for (int j = 0; j < TJ; j++) {
+        const int col = wcol0 + j * 32 + r;
         if (col >= a.n) continue;
         const float bv = bias ? (float)bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < TI; i++) {
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
-                const int row = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int row = wrow0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 if (row >= a.m) continue;
                 float x = acc[i][j][reg] + bv;
                 if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
@@ -239,20 +248,24 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
     Args a{L->m, L->n, L->k, L->lda, L->ldw, L->ldo, L->elu, L->out_f32, L->in, (long long)L->in_stride, L->mean, L->inv_std, L->clip,
            reinterpret_cast<const _Float16*>(L->w), (long long)L->w_stride, reinterpret_cast<const _Float16*>(L->bias), (long long)L->bias_stride,
            L->out, (long long)L->out_stride};
-    // tile choice: the 256 x 128 tile moves a third fewer operand bytes per flop but needs >= ~one workgroup per CU to pay
+    // tile choice (PPENV_MLP_TILE forces one: 128 = 128 x 128 / 4 waves of 64 x 64; 256 = 256 x 128 / 4 waves of 128 x 64;
+    // 512 = 256 x 256 / 4 waves of 128 x 128; 384 = 256 x 256 / 8 waves of 128 x 64)
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("PPENV_MLP_TILE"); forced = e ? atoi(e) : 0; }   // 128 / 256: profiling
-    const long long big_wgs = (long long)((L->n + 127) / 128) * ((L->m + 255) / 256) * L->batch;
-    const bool big = forced == 256 || (forced == 0 && big_wgs >= 256 && L->m >= 256);
-    if (big) {
-        const dim3 grid((L->n + 127) / 128, (L->m + 255) / 256, L->batch), block(512);
-        if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, 4, 2>), grid, block, 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((mlp_layer_kernel<false, 4, 2>), grid, block, 0, (hipStream_t)stream, a);
-    } else {
-        const dim3 grid((L->n + 127) / 128, (L->m + 127) / 128, L->batch), block(256);
-        if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, 2, 2>), grid, block, 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((mlp_layer_kernel<false, 2, 2>), grid, block, 0, (hipStream_t)stream, a);
-    }
+    if (forced < 0) { const char* e = getenv("PPENV_MLP_TILE"); forced = e ? atoi(e) : 0; }
+    auto wgs = [&](int bm, int bn) { return (long long)((L->n + bn - 1) / bn) * ((L->m + bm - 1) / bm) * L->batch; };
+    int cfg = forced;
+    if (cfg == 0) cfg = (wgs(256, 256) >= 256 && L->m >= 256 && L->n >= 256) ? 512 : ((wgs(256, 128) >= 256 && L->m >= 256) ? 256 : 128);
+#define PP_LAUNCH(WM_, WN_, TI_, TJ_)                                                                                                         \
+    do {                                                                                                                                      \
+        const dim3 grid((L->n + 32 * TJ_ * WN_ - 1) / (32 * TJ_ * WN_), (L->m + 32 * TI_ * WM_ - 1) / (32 * TI_ * WM_), L->batch), block(64 * WM_ * WN_); \
+        if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, WM_, WN_, TI_, TJ_>), grid, block, 0, (hipStream_t)stream, a);             \
+        else hipLaunchKernelGGL((mlp_layer_kernel<false, WM_, WN_, TI_, TJ_>), grid, block, 0, (hipStream_t)stream, a);                       \
+    } while (0)
+    if (cfg == 512) PP_LAUNCH(2, 2, 4, 4);
+    else if (cfg == 384) PP_LAUNCH(2, 4, 4, 2);
+    else if (cfg == 256) PP_LAUNCH(2, 2, 4, 2);
+    else PP_LAUNCH(2, 2, 2, 2);
+#undef PP_LAUNCH
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching mlp_layer_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kTaBlock) void ta_post_physics_kernel(const ppenv_t
     const int n = p.num_envs;
     const int i = blockIdx.x * kTaBlock + threadIdx.x;
     if (i >= n) return;
-    tatask::ta_task_env<1>(p, i, rb_states + (size_t)i * PPENV_NUM_BODIES * 13, initial_rb_states + (size_t)i * PPENV_NUM_BODIES * 13,
+    tatask::ta_task_env<1>(p, i, rb_states + (size_t)i * PPENV_NUM_BODIES * 13, initial_rb_states + (size_t)(p.initial_rb_shared ? 0 : i) * PPENV_NUM_BODIES * 13,
                         root_states + (size_t)i * PPENV_NUM_ACTORS * 13, dof_states + (size_t)i * tatask::TA_ND * 2, dof_force + (size_t)i * tatask::TA_ND,
                         pre_ball_vx[i], reset_override ? reset_override + (size_t)i * 5 : nullptr, &flags[i], &episode[i], &progress[i],
                         obs + (size_t)i * PPENV_TA_NUM_OBS, &rew[i], &reset_out[i], any_reset, 0, true);

@@ -269,7 +269,8 @@ template <int BODY>
 __device__ __forceinline__ void prefetch_body(TaskCtx& c) {
     constexpr int jb = tatask::ta_bal_index(BODY);
     if constexpr (jb >= 0) {
-        const float* r = c.a.initial_rb + ((size_t)c.env * PPENV_NUM_BODIES + BODY) * 13;
+        // (a shared block: the address is the same in every lane, so these are scalar loads)
+        const float* r = c.a.initial_rb + ((size_t)(c.a.p.initial_rb_shared ? 0 : c.env) * PPENV_NUM_BODIES + BODY) * 13;
         c.irb[jb][0] = r[0]; c.irb[jb][1] = r[1]; c.irb[jb][2] = r[2]; c.irb[jb][3] = r[7]; c.irb[jb][4] = r[8]; c.irb[jb][5] = r[9];
     }
 }

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64) void ta_sim_quad_kernel(const TAConsts* __restr
         if (FUSE) {
             {   // the four lanes of the quad share the env's task arithmetic (lanes past the last env compute on env n - 1, store nothing)
                 const int ec = live ? e : n - 1;
-                tatask::ta_task_env<4>(s_tp, ec, t_rb + es * kRb, task.initial_rb + (size_t)ec * kRb, t_root + es * kRoot, t_dofs + es * kDofs,
+                tatask::ta_task_env<4>(s_tp, ec, t_rb + es * kRb, task.initial_rb + (size_t)(s_tp.initial_rb_shared ? 0 : ec) * kRb, t_root + es * kRoot, t_dofs + es * kDofs,
                                        t_frc + es * NDOF, t_pvx[es], task.reset_override ? task.reset_override + (size_t)ec * 5 : nullptr, &task.flags[ec],
                                        &task.episode[ec], &task.progress[ec], t_obs + es * PPENV_TA_NUM_OBS, &task.rew[ec], &task.reset[ec], task.any_reset,
                                        role, live);

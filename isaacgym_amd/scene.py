@@ -138,6 +138,7 @@ class TAParams(C.Structure):
         ("serve_speed_lo", C.c_float), ("serve_speed_hi", C.c_float), ("serve_tilt_lo_deg", C.c_float), ("serve_tilt_hi_deg", C.c_float),
         ("serve_tilt_z_lo_deg", C.c_float), ("serve_tilt_z_hi_deg", C.c_float),
         ("ball_y_lo", C.c_float), ("ball_y_hi", C.c_float), ("ball_z_lo", C.c_float), ("ball_z_hi", C.c_float),
+        ("initial_rb_shared", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

@@ -32,7 +32,8 @@ class TAState:
 
     def post_physics_step(self, rb_states, initial_rb_states, root_states, dof_states, dof_force, pre_ball_vx, reset_override=None):
         n = self.num_envs
-        for t, numel in ((rb_states, n * 42 * 13), (initial_rb_states, n * 42 * 13), (root_states, n * 39), (dof_states, n * 54),
+        irb_n = 1 if self.params.initial_rb_shared else n
+        for t, numel in ((rb_states, n * 42 * 13), (initial_rb_states, irb_n * 42 * 13), (root_states, n * 39), (dof_states, n * 54),
                          (dof_force, n * 27), (pre_ball_vx, n)):
             assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device and t.numel() == numel
         ov = None
@@ -101,7 +102,8 @@ class TASim:
         """ppenv_ta_step: simulate + post_physics_step (on `state`: a TAState) in one launch.  rb_states may be None with the
         chain-wave kernel: rigid_body_states [N,42,13] is then not materialised."""
         n = self.num_envs
-        for t, k in ((actions, n * 27), (initial_rb_states, n * 42 * 13), (root_states, n * 39), (dof_states, n * 54),
+        irb_n = 1 if state.params.initial_rb_shared else n
+        for t, k in ((actions, n * 27), (initial_rb_states, irb_n * 42 * 13), (root_states, n * 39), (dof_states, n * 54),
                      (dof_force, n * 27), (pre_ball_vx, n)) + (((rb_states, n * 42 * 13),) if rb_states is not None else ()):
             self._check(t, k)
         ov = None
@@ -142,7 +144,7 @@ class TAEnv:
     (ppenv_ta_step) plus the tiny count-flag clear; `fused=False` keeps the two launches (ppenv_ta_simulate +
     ppenv_ta_post_physics_step).  Surface: obs_buf [N,313], rew_buf, reset_buf, progress_buf, 27 actions."""
 
-    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_offset=0, env=None, fused=True, materialize_rb=None):
+    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_offset=0, env=None, fused=True, materialize_rb=None, share_initial_rb=True):
         """materialize_rb: write rigid_body_states [N,42,13] in every step (the reference's refresh_rigid_body_state_tensor, pre-reset
         body states).  Default: only where the kernel needs the tensor itself (the two-launch path and the table-driven kernels);
         the chain-wave kernel keeps the body states in registers and `rb_states` is then produced on demand by forward kinematics
@@ -165,7 +167,14 @@ class TAEnv:
         self.root_states[:, 2, 1:3] = ov[:, 0:2].to(self.device)
         self.root_states[:, 2, 7:10] = ov[:, 2:5].to(self.device)
         self.sim.forward_kinematics(self.root_states, self.dof_states, self._rb_states)
-        self.initial_rb_states = self._rb_states.clone()                      # TA:1152 initial_body_states
+        # TA:1152 initial_body_states.  Every env is created in the same pose (TA:578-579), so the rows the task reads — the 23 balance
+        # bodies, all on the humanoid — are the same in every env: one shared [1,42,13] block serves all of them (ppenv_ta_params.
+        # initial_rb_shared); share_initial_rb=False keeps the reference's per-env tensor.
+        self.initial_rb_states = self._rb_states.clone()
+        if share_initial_rb:
+            assert torch.equal(self.initial_rb_states[:, :40], self.initial_rb_states[:1, :40].expand(n, 40, 13))
+            self.initial_rb_states = self.initial_rb_states[:1].contiguous()
+            self.params.initial_rb_shared = 1
         self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf = self.state.obs_buf, self.state.rew_buf, self.state.reset_buf, self.state.progress_buf
         self.reset_buf.fill_(1)   # upstream VecTask.allocate_buffers
 

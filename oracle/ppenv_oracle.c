@@ -1111,7 +1111,7 @@ void ppo_ta_post_physics_step(const ppenv_ta_params* p, const float* rb_states, 
     int any_reset = 0;
     for (int i = 0; i < n; i++) {
         const float* rb = &rb_states[(size_t)i * PPENV_NUM_BODIES * 13];
-        const float* irb = &initial_rb_states[(size_t)i * PPENV_NUM_BODIES * 13];
+        const float* irb = &initial_rb_states[(size_t)(p->initial_rb_shared ? 0 : i) * PPENV_NUM_BODIES * 13];
         float* root = &root_states[(size_t)i * PPENV_NUM_ACTORS * 13];
         float* dofs = &dof_states[(size_t)i * TA_ND * 2];
         float* ball = &root[2 * 13];

@@ -275,8 +275,8 @@ def test_ta_chain_kernel_step_matches_oracle(oracle_lib, monkeypatch, n):
     from isaacgym_amd.tensor_api import TAEnv
     monkeypatch.setenv("PPENV_TA_KERNEL", "chain")
     cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
-    env = TAEnv(n, device="cuda:0", seed=11, env={"episodeLength": 40}, materialize_rb=True)
-    assert env.sim.kernel == "chain"
+    env = TAEnv(n, device="cuda:0", seed=11, env={"episodeLength": 40}, materialize_rb=True, share_initial_rb=(n != 50))   # n = 50: the reference's per-env [N,42,13]
+    assert env.sim.kernel == "chain" and env.initial_rb_states.shape[0] == (n if n == 50 else 1)
     p = env.params
     root, dof = env.root_states.cpu().numpy().copy(), env.dof_states.cpu().numpy().copy()
     irb = env.initial_rb_states.cpu().numpy().copy()
