@@ -24,7 +24,7 @@
 void ppenv_set_error(const char* msg);   // ppenv.hip
 
 namespace {
-constexpr int BK = 64, LDS_LD = BK + 8;   // K step; fp16 elements per LDS row (padded)
+constexpr int PATCH_LD = 72;   // row stride (fp16) of the epilogue patch; the operand tiles use BK + 8 (BK = K step, a template parameter)
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -39,13 +39,14 @@ struct Args {
     void* out; long long out_stride;
 };
 
-// global -> registers: this thread's share of a ROWS x 64 fp16 tile (rows row0.., k from k0), zero outside [rows, kmax).
-// ROWS rows x 8 chunks of 8 fp16, C = ROWS * 8 / T per thread: chunk c = tid + T i -> row c >> 3, k-chunk c & 7.
-template <int T, int C>
+// global -> registers: this thread's share of a ROWS x BK fp16 tile (rows row0.., k from k0), zero outside [rows, kmax).
+// ROWS rows x BK / 8 chunks of 8 fp16, C = ROWS * (BK / 8) / T per thread: chunk c = tid + T i -> row c / (BK / 8), k-chunk c % (BK / 8).
+template <int T, int C, int BK>
 __device__ __forceinline__ void load_tile_h(const _Float16* __restrict__ base, int ld, int rows, int kmax, int row0, int k0, int tid, h8 (&v)[C]) {
+    constexpr int CPR = BK / 8;
 #pragma unroll
     for (int i = 0; i < C; i++) {
-        const int c = tid + T * i, r = row0 + (c >> 3), kk = k0 + (c & 7) * 8;
+        const int c = tid + T * i, r = row0 + c / CPR, kk = k0 + (c % CPR) * 8;
         h8 x = {0, 0, 0, 0, 0, 0, 0, 0};
         if (r < rows) {
             const _Float16* p = base + (size_t)r * ld + kk;
@@ -59,18 +60,19 @@ __device__ __forceinline__ void load_tile_h(const _Float16* __restrict__ base, i
     }
 }
 // the first layer: fp32 observations, normalised and clamped on the way (rl_games RunningMeanStd, eval mode)
-template <int T, int C>
+template <int T, int C, int BK>
 __device__ __forceinline__ void load_tile_obs(const float* __restrict__ base, int ld, int rows, int kmax, int row0, int k0, int tid,
                                               const float* __restrict__ mean, const float* __restrict__ inv_std, float clip, h8 (&v)[C]) {
-    static_assert(T % 8 == 0, "a thread's k offset inside the tile must not depend on the chunk");
-    const int kk = k0 + (tid & 7) * 8;          // the same for all of this thread's chunks: its eight statistics are fetched once
+    constexpr int CPR = BK / 8;
+    static_assert(T % CPR == 0, "a thread's k offset inside the tile must not depend on the chunk");
+    const int kk = k0 + (tid % CPR) * 8;          // the same for all of this thread's chunks: its eight statistics are fetched once
     float mu[8], is[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { const bool in = kk + j < kmax; mu[j] = (mean && in) ? mean[kk + j] : 0.f; is[j] = (mean && in) ? inv_std[kk + j] : 1.f; }
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0) && kk + 8 <= kmax;   // 16-byte aligned rows: two float4 per chunk
 #pragma unroll
     for (int i = 0; i < C; i++) {
-        const int c = tid + T * i, r = row0 + (c >> 3);
+        const int c = tid + T * i, r = row0 + c / CPR;
         h8 x = {0, 0, 0, 0, 0, 0, 0, 0};
         if (r < rows) {
             const float* p = base + (size_t)r * ld + kk;
@@ -93,12 +95,13 @@ __device__ __forceinline__ void load_tile_obs(const float* __restrict__ base, in
         v[i] = x;
     }
 }
-template <int T, int C>
+template <int T, int C, int BK>
 __device__ __forceinline__ void store_tile(_Float16* __restrict__ s, int tid, const h8 (&v)[C]) {
+    constexpr int CPR = BK / 8, LDS_LD = BK + 8;
 #pragma unroll
     for (int i = 0; i < C; i++) {
         const int c = tid + T * i;
-        *reinterpret_cast<h8*>(&s[(c >> 3) * LDS_LD + (c & 7) * 8]) = v[i];
+        *reinterpret_cast<h8*>(&s[(c / CPR) * LDS_LD + (c % CPR) * 8]) = v[i];
     }
 }
 
@@ -106,14 +109,15 @@ __device__ __forceinline__ void store_tile(_Float16* __restrict__ s, int tid, co
 // workgroup's tile is BM = 32 TI WM rows by BN = 32 TJ WN columns.  A K sub-step of 16 costs a wave TI + TJ fragment reads (16 bytes
 // per lane each) for TI TJ MFMAs: 1 read per MFMA at 2 x 2, 0.75 at 4 x 2, 0.5 at 4 x 4 — the LDS read traffic, not the global
 // traffic, is what the small wave tile pays for.
-template <bool OBS, int WM, int WN, int TI, int TJ>
+template <bool OBS, int WM, int WN, int TI, int TJ, int BK>
 __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
-    constexpr int T = 64 * WM * WN, BM = 32 * TI * WM, BN = 32 * TJ * WN, CA = BM * 8 / T, CB = BN * 8 / T;
-    static_assert(BM * 8 % T == 0 && BN * 8 % T == 0, "staging shares");
+    constexpr int T = 64 * WM * WN, BM = 32 * TI * WM, BN = 32 * TJ * WN, CPR = BK / 8, CA = BM * CPR / T, CB = BN * CPR / T, LDS_LD = BK + 8;
+    static_assert(BM * CPR % T == 0 && BN * CPR % T == 0, "staging shares");
     static_assert(TI % 2 == 0 && TJ % 2 == 0, "the epilogue works on 64 x 64 blocks");
-    __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * LDS_LD];
-    static_assert(2 * BM * LDS_LD >= WM * WN * 64 * LDS_LD, "epilogue patches fit the A buffers");
+    constexpr int kOperand = 2 * (BM + BN) * LDS_LD, kPatch = WM * WN * 64 * PATCH_LD;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];   // [A buf 0 | A buf 1 | B buf 0 | B buf 1]; afterwards the epilogue patches
+    _Float16* const sA[2] = {smem, smem + BM * LDS_LD};
+    _Float16* const sB[2] = {smem + 2 * BM * LDS_LD, smem + 2 * BM * LDS_LD + BN * LDS_LD};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, b = blockIdx.z;
@@ -135,12 +139,12 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
     const int ksteps = (a.k + BK - 1) / BK;
     auto gload = [&](int set, int ks) {
         if (ks >= ksteps) return;
-        if (OBS) load_tile_obs<T, CA>(inf, a.lda, a.m, a.k, m0, ks * BK, tid, a.mean, a.inv_std, a.clip, ra[set]); else load_tile_h<T, CA>(inh, a.lda, a.m, a.k, m0, ks * BK, tid, ra[set]);
-        load_tile_h<T, CB>(W, a.ldw, a.n, a.k, n0, ks * BK, tid, rb[set]);
+        if (OBS) load_tile_obs<T, CA, BK>(inf, a.lda, a.m, a.k, m0, ks * BK, tid, a.mean, a.inv_std, a.clip, ra[set]); else load_tile_h<T, CA, BK>(inh, a.lda, a.m, a.k, m0, ks * BK, tid, ra[set]);
+        load_tile_h<T, CB, BK>(W, a.ldw, a.n, a.k, n0, ks * BK, tid, rb[set]);
     };
     gload(0, 0);
-    store_tile<T, CA>(sA[0], tid, ra[0]);
-    store_tile<T, CB>(sB[0], tid, rb[0]);
+    store_tile<T, CA, BK>(sA[0], tid, ra[0]);
+    store_tile<T, CB, BK>(sB[0], tid, rb[0]);
     gload(1, 1);
     gload(0, 2);
     __syncthreads();
@@ -165,8 +169,8 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
                 for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
         }
         if (ks + 1 < ksteps) {
-            store_tile<T, CA>(sA[cur ^ 1], tid, ra[set_next]);   // the other buffer: last read before the barrier that ended step ks - 1
-            store_tile<T, CB>(sB[cur ^ 1], tid, rb[set_next]);
+            store_tile<T, CA, BK>(sA[cur ^ 1], tid, ra[set_next]);   // the other buffer: last read before the barrier that ended step ks - 1
+            store_tile<T, CB, BK>(sB[cur ^ 1], tid, rb[set_next]);
         }
         gload(set_next, ks + 3);
         __syncthreads();
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
     const _Float16* bias = a.bias ? a.bias + (size_t)b * a.bias_stride : nullptr;
     const int wrow0 = m0 + wm * 32 * TI, wcol0 = n0 + wn * 32 * TJ;
     if (!a.out_f32) {
-        _Float16* patch = &sA[0][0] + wave * (64 * LDS_LD);
+        __syncthreads();                                   // every wave is done with the operand buffers: the patches overlay them
+        _Float16* patch = smem + wave * (64 * PATCH_LD);
         _Float16* out = reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride;
         const int rl = lane >> 3, ch = lane & 7;
 #pragma unroll
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
                         for (int reg = 0; reg < 16; reg++) {
                             float x = acc[ib + i][jb + j][reg] + bv;
                             if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
-                            patch[(i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * LDS_LD + j * 32 + r] = (_Float16)x;
+                            patch[(i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * PATCH_LD + j * 32 + r] = (_Float16)x;
                         }
                 }
                 __builtin_amdgcn_wave_barrier();   // the patch is this wave's own: DS operations of a wave execute in order
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
                 for (int it = 0; it < 8; it++) {
                     const int prow = it * 8 + rl, row = wrow0 + ib * 32 + prow, col = wcol0 + jb * 32 + ch * 8;
                     if (row >= a.m || col >= a.n) continue;
-                    const h8 v = *reinterpret_cast<const h8*>(&patch[prow * LDS_LD + ch * 8]);
+                    const h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
                     _Float16* dst = out + (size_t)row * a.ldo + col;
                     if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
                     else {
@@ -248,23 +253,32 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
     Args a{L->m, L->n, L->k, L->lda, L->ldw, L->ldo, L->elu, L->out_f32, L->in, (long long)L->in_stride, L->mean, L->inv_std, L->clip,
            reinterpret_cast<const _Float16*>(L->w), (long long)L->w_stride, reinterpret_cast<const _Float16*>(L->bias), (long long)L->bias_stride,
            L->out, (long long)L->out_stride};
-    // tile choice (PPENV_MLP_TILE forces one: 128 = 128 x 128 / 4 waves of 64 x 64; 256 = 256 x 128 / 4 waves of 128 x 64;
-    // 512 = 256 x 256 / 4 waves of 128 x 128; 384 = 256 x 256 / 8 waves of 128 x 64)
+    // Tile choice.  Measured on the reference's layers (tools/gpu_mlp_layers.py, M = 16384, TFLOP/s on the 2048 -> 1536 layer):
+    //   128 x 128, 4 waves of 64 x 64, BK 64 (two workgroups per CU)            600
+    //   256 x 128, 4 waves of 128 x 64 (one workgroup of four waves per CU)      507   too few waves to hide anything
+    //   256 x 256, 4 waves of 128 x 128                                          157   512 registers and still spilling
+    //   256 x 256, 8 waves of 128 x 64, BK 64 (one workgroup of 8 waves per CU)  727
+    // so: the big tile whenever it still gives most CUs a workgroup, else the small one.  PPENV_MLP_TILE = 128 | 384 | 385 (BK 32) forces one.
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("PPENV_MLP_TILE"); forced = e ? atoi(e) : 0; }
     auto wgs = [&](int bm, int bn) { return (long long)((L->n + bn - 1) / bn) * ((L->m + bm - 1) / bm) * L->batch; };
     int cfg = forced;
-    if (cfg == 0) cfg = (wgs(256, 256) >= 256 && L->m >= 256 && L->n >= 256) ? 512 : ((wgs(256, 128) >= 256 && L->m >= 256) ? 256 : 128);
-#define PP_LAUNCH(WM_, WN_, TI_, TJ_)                                                                                                         \
+    if (cfg == 0) {
+        // the first layer (fp32 observations, K = 80 or 313) converts its obs tile once per column tile: wide tiles and a K step of 32
+        // (less zero padding of K) — 54 us against 86 (256 x 256 / BK 32 vs 128 x 128 / BK 64, M = 4096, K = 313)
+        if (L->in_f32) cfg = (wgs(256, 256) >= 128 && L->n >= 256) ? 385 : 129;
+        else cfg = (wgs(256, 256) >= 192 && L->n >= 256) ? 384 : 128;
+    }
+#define PP_LAUNCH(WM_, WN_, TI_, TJ_, BK_)                                                                                                    \
     do {                                                                                                                                      \
         const dim3 grid((L->n + 32 * TJ_ * WN_ - 1) / (32 * TJ_ * WN_), (L->m + 32 * TI_ * WM_ - 1) / (32 * TI_ * WM_), L->batch), block(64 * WM_ * WN_); \
-        if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, WM_, WN_, TI_, TJ_>), grid, block, 0, (hipStream_t)stream, a);             \
-        else hipLaunchKernelGGL((mlp_layer_kernel<false, WM_, WN_, TI_, TJ_>), grid, block, 0, (hipStream_t)stream, a);                       \
+        if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);        \
+        else hipLaunchKernelGGL((mlp_layer_kernel<false, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);                  \
     } while (0)
-    if (cfg == 512) PP_LAUNCH(2, 2, 4, 4);
-    else if (cfg == 384) PP_LAUNCH(2, 4, 4, 2);
-    else if (cfg == 256) PP_LAUNCH(2, 2, 4, 2);
-    else PP_LAUNCH(2, 2, 2, 2);
+    if (cfg == 384) PP_LAUNCH(2, 4, 4, 2, 64);
+    else if (cfg == 385) PP_LAUNCH(2, 4, 4, 2, 32);
+    else if (cfg == 129) PP_LAUNCH(2, 2, 2, 2, 32);
+    else PP_LAUNCH(2, 2, 2, 2, 64);
 #undef PP_LAUNCH
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching mlp_layer_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;

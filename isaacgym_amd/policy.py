@@ -75,9 +75,19 @@ class NativeMLP:
     def load(self, actor, critic):
         """fp32 master weights -> the fp16 operand images (actor | critic stacked per layer)."""
         h = lambda t: t.detach().to(self.device, torch.float16).contiguous()
+
+        def hw(t):   # weight rows padded to a multiple of 8 fp16: every row starts 16-byte aligned, so the kernel stages it with 16-byte loads
+            t = h(t)   # (num_obs = 313 gives 626-byte rows; unpadded, the first layer fell back to element loads and ran at a third of the speed)
+            k = t.shape[1]
+            kp = (k + 7) // 8 * 8
+            if kp == k:
+                return t
+            out = torch.zeros((t.shape[0], kp), dtype=torch.float16, device=self.device)
+            out[:, :k] = t
+            return out
         self.w, self.b = [], []
         for (wa, ba), (wc, bc) in zip(actor[:-1], critic[:-1]):
-            self.w.append(torch.stack([h(wa), h(wc)]).contiguous())       # [2, n, k]
+            self.w.append(torch.stack([hw(wa), hw(wc)]).contiguous())     # [2, n, k (padded)]
             self.b.append(torch.stack([h(ba), h(bc)]).contiguous())       # [2, n]
         self.head_w = [h(actor[-1][0]), h(critic[-1][0])]
         self.head_b = [h(actor[-1][1]), h(critic[-1][1])]
@@ -104,8 +114,8 @@ class NativeMLP:
         assert obs.dtype == torch.float32 and obs.device == self.device and obs.stride(1) == 1 and obs.shape[1] == self.num_obs
         u = self.units
         # layer 1: both networks read the same rows -> one N = 2 u0 GEMM over the stacked weights
-        w0 = self.w[0].view(2 * u[0], self.num_obs)
-        layer_forward(self.h[0], obs, w0, self.b[0].view(-1), elu=True, mean=self.mean, inv_std=self.inv_std, clip=self.clip)
+        w0 = self.w[0].view(2 * u[0], self.w[0].shape[-1])
+        layer_forward(self.h[0], obs, w0, self.b[0].view(-1), elu=True, mean=self.mean, inv_std=self.inv_std, clip=self.clip, k=self.num_obs)
         for i in range(1, len(u)):
             layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * u[i - 1],
                           bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])

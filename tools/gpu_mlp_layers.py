@@ -33,17 +33,20 @@ mean, istd = torch.zeros(k0, device=dev), torch.ones(k0, device=dev)
 prev = None
 tot_n = tot_t = 0.0
 for i, (kin, n) in enumerate(zip(dims[:-1], dims[1:])):
-    w = (torch.randn(2, n, kin, device=dev) / kin ** 0.5).half()
+    kp = (kin + 7) // 8 * 8                                     # rows padded to 16 bytes, as NativeMLP.load does
+    w = torch.zeros(2, n, kp, device=dev, dtype=torch.float16)
+    w[:, :, :kin] = (torch.randn(2, n, kin, device=dev) / kin ** 0.5).half()
     b = torch.zeros(2, n, device=dev).half()
     out = torch.empty(m, 2 * n, device=dev, dtype=torch.float16)
     if i == 0:
-        fn = lambda: layer_forward(out, obs, w.view(2 * n, kin), b.view(-1), elu=True, mean=mean, inv_std=istd)
+        fn = lambda: layer_forward(out, obs, w.view(2 * n, kp), b.view(-1), elu=True, mean=mean, inv_std=istd, k=kin)
         x16 = obs.half()
-        ft = lambda: torch.nn.functional.elu(torch.nn.functional.linear(x16, w.view(2 * n, kin), b.view(-1)))
+        wt = w[:, :, :kin].reshape(2 * n, kin).contiguous()
+        ft = lambda: torch.nn.functional.elu(torch.nn.functional.linear(x16, wt, b.view(-1)))
     else:
         x = prev
         fn = lambda: layer_forward(out, x, w, b, elu=True, batch=2, in_stride=kin, w_stride=n * kin, bias_stride=n, out_stride=n, m=m, n=n, k=kin)
-        ft = lambda: [torch.nn.functional.elu(torch.nn.functional.linear(x[:, j * kin:(j + 1) * kin], w[j], b[j])) for j in range(2)]
+        ft = lambda: [torch.nn.functional.elu(torch.nn.functional.linear(x[:, j * kin:(j + 1) * kin], w[j][:, :kin], b[j])) for j in range(2)]
     tn, tt = timeit(fn), timeit(ft)
     fl = 2 * 2 * m * kin * n
     tot_n += tn
