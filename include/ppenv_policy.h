@@ -6,8 +6,9 @@
  * once per env step, on the observation rows the step kernel has just written.  This entry is one dense layer of it on the
  * matrix cores (v_mfma_f32_32x32x16_f16: fp16 operands, fp32 accumulation — what autocast does to nn.Linear), with the work that
  * surrounds a layer fused in:
- *   - layer 1 reads obs_buf [M, K] fp32 IN PLACE and applies rl_games' RunningMeanStd in eval mode while staging the tile:
- *     x = clamp((obs - mean) * inv_std, -clip, clip), cast to fp16 (no normalised copy of the observations is written);
+ *   - layer 1 can read obs_buf [M, K] fp32 IN PLACE and apply rl_games' RunningMeanStd in eval mode while staging the tile:
+ *     x = clamp((obs - mean) * inv_std, -clip, clip), cast to fp16 (in_f32 = 1; no normalised copy of the observations is written) —
+ *     or take that as a separate small launch (ppenv_mlp_prepare_input, 2 M K bytes) and run on the faster LDS-DMA tile kernels;
  *   - bias add and ELU run on the accumulators; the activations leave as fp16.
  * Plain C, device pointers, caller's HIP stream, no synchronisation; returns 0 or a negative PPENV_E* code (ppenv.h) with the
  * message in ppenv_last_error().
@@ -36,8 +37,17 @@ typedef struct ppenv_mlp_layer {
     void* out;                int64_t out_stride; int32_t ldo;   int32_t out_f32;   /* fp16 (or fp32 for the heads) [m, ldo] */
 } ppenv_mlp_layer;
 
-/* One layer (x batch) in one launch. */
+/* One layer (x batch) in one launch.  Tile choice: fp16 inputs with k % 64 == 0 and 16-byte aligned rows (lda, ldw, strides multiples
+ * of 8, base pointers 16-byte aligned) and n >= 128 take the LDS-DMA kernels (256 x 256, 128 x 256 or 128 x 128 of `out` per
+ * workgroup, the largest that still gives three quarters of the CUs a workgroup); everything else the register-staged ones. */
 int ppenv_mlp_layer_forward(const ppenv_mlp_layer* layer, void* stream);
+
+/* The first layer's input as its own small launch, so that layer 1 runs on the LDS-DMA kernels too:
+ * out[m, ld_out] (fp16) = clamp((obs[m, k] - mean) * inv_std, -clip, clip) in columns < k, zero in columns k .. ld_out - 1
+ * (ld_out: k rounded up to a multiple of 64; layer 1's weight rows are zero-padded to the same length).  mean / inv_std NULL: cast
+ * only.  rl_games RunningMeanStd in eval mode, as the in_f32 path of ppenv_mlp_layer_forward applies while staging. */
+int ppenv_mlp_prepare_input(const float* obs, int32_t m, int32_t k, int32_t ld_obs, const float* mean, const float* inv_std, float clip,
+                            void* out, int32_t ld_out, void* stream);
 
 #ifdef __cplusplus
 }

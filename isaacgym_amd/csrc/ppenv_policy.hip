@@ -105,6 +105,74 @@ __device__ __forceinline__ void store_tile(_Float16* __restrict__ s, int tid, co
     }
 }
 
+// Epilogue on the accumulators.  C/D layout of the 32x32 MFMA — col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane
+// holds ONE column, so stored straight from the accumulators every store instruction would move 2 bytes per lane.  fp16 results
+// therefore go through the wave's own 64 x 64 patch of LDS (the operand buffers are free after the barrier in here), one 64 x 64 block
+// of the wave's tile at a time, and leave as 16 bytes per lane, 128 contiguous bytes per output row.  The fp32 heads (a few columns)
+// are stored directly.  wrow0 / wcol0: the wave's first row / column of `out`.
+template <int TI, int TJ>
+__device__ __forceinline__ void epilogue(const Args& a, f16v (&acc)[TI][TJ], _Float16* smem, int wrow0, int wcol0, int b) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const _Float16* bias = a.bias ? a.bias + (size_t)b * a.bias_stride : nullptr;
+    if (!a.out_f32) {
+        __syncthreads();                                   // every wave is done with the operand buffers: the patches overlay them
+        _Float16* patch = smem + wave * (64 * PATCH_LD);
+        _Float16* out = reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride;
+        constexpr int JW = TJ >= 2 ? 2 : 1, CH = 4 * JW;        // the block is 64 x 32 JW: CH 16-byte chunks per row, 64 / CH rows per store pass
+        const int rl = lane / CH, ch = lane % CH;
+#pragma unroll
+        for (int ib = 0; ib < TI; ib += 2)
+#pragma unroll
+            for (int jb = 0; jb < TJ; jb += JW) {
+#pragma unroll
+                for (int j = 0; j < JW; j++) {
+                    const int col = wcol0 + (jb + j) * 32 + r;
+                    const float bv = (bias && col < a.n) ? (float)bias[col] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg++) {
+                            float x = acc[ib + i][jb + j][reg] + bv;
+                            if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
+                            patch[(i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * PATCH_LD + j * 32 + r] = (_Float16)x;
+                        }
+                }
+                __builtin_amdgcn_wave_barrier();   // the patch is this wave's own: DS operations of a wave execute in order
+#pragma unroll
+                for (int it = 0; it < CH; it++) {
+                    const int prow = it * (64 / CH) + rl, row = wrow0 + ib * 32 + prow, col = wcol0 + jb * 32 + ch * 8;
+                    if (row >= a.m || col >= a.n) continue;
+                    const h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
+                    _Float16* dst = out + (size_t)row * a.ldo + col;
+                    if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) if (col + q < a.n) dst[q] = v[q];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+        const int col = wcol0 + j * 32 + r;
+        if (col >= a.n) continue;
+        const float bv = bias ? (float)bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; i++) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int row = wrow0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (row >= a.m) continue;
+                float x = acc[i][j][reg] + bv;
+                if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
+                (reinterpret_cast<float*>(a.out) + (size_t)b * a.out_stride)[(size_t)row * a.ldo + col] = x;
+            }
+        }
+    }
+}
+
 // WM x WN waves per workgroup, (32 TI) x (32 TJ) of `out` per wave (TI x TJ MFMA tiles, 16 accumulator registers each): the
 // workgroup's tile is BM = 32 TI WM rows by BN = 32 TJ WN columns.  A K sub-step of 16 costs a wave TI + TJ fragment reads (16 bytes
 // per lane each) for TI TJ MFMAs: 1 read per MFMA at 2 x 2, 0.75 at 4 x 2, 0.5 at 4 x 4 — the LDS read traffic, not the global
@@ -113,7 +181,7 @@ template <bool OBS, int WM, int WN, int TI, int TJ, int BK>
 __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
     constexpr int T = 64 * WM * WN, BM = 32 * TI * WM, BN = 32 * TJ * WN, CPR = BK / 8, CA = BM * CPR / T, CB = BN * CPR / T, LDS_LD = BK + 8;
     static_assert(BM * CPR % T == 0 && BN * CPR % T == 0, "staging shares");
-    static_assert(TI % 2 == 0 && TJ % 2 == 0, "the epilogue works on 64 x 64 blocks");
+    static_assert(TI % 2 == 0 && (TJ % 2 == 0 || TJ == 1), "the epilogue works on 64 x 64 (or 64 x 32) blocks");
     constexpr int kOperand = 2 * (BM + BN) * LDS_LD, kPatch = WM * WN * 64 * PATCH_LD;
     __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];   // [A buf 0 | A buf 1 | B buf 0 | B buf 1]; afterwards the epilogue patches
     _Float16* const sA[2] = {smem, smem + BM * LDS_LD};
@@ -179,70 +247,316 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
         kstep(ks, 1);
         if (ks + 1 < ksteps) kstep(ks + 1, 0);
     }
-    // epilogue: C/D layout of the 32x32 MFMA — col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane holds ONE column,
-    // so stored straight from the accumulators every store instruction would move 2 bytes per lane.  fp16 results therefore go through
-    // the wave's own 64 x 64 patch of LDS (the operand buffers are free after the last barrier), one 64 x 64 block of the wave's tile at
-    // a time, and leave as 16 bytes per lane, 128 contiguous bytes per output row.  The fp32 heads (a few columns) are stored directly.
-    const _Float16* bias = a.bias ? a.bias + (size_t)b * a.bias_stride : nullptr;
-    const int wrow0 = m0 + wm * 32 * TI, wcol0 = n0 + wn * 32 * TJ;
-    if (!a.out_f32) {
-        __syncthreads();                                   // every wave is done with the operand buffers: the patches overlay them
-        _Float16* patch = smem + wave * (64 * PATCH_LD);
-        _Float16* out = reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride;
-        const int rl = lane >> 3, ch = lane & 7;
+    epilogue<TI, TJ>(a, acc, smem, m0 + wm * 32 * TI, n0 + wn * 32 * TJ, b);
+}
+
+// ---- the 256 x 256 tile for the wide layers: LDS-DMA staging and two wave groups taking turns on the matrix cores ----
+//
+// 512 threads = 8 waves as 2 (M) x 4 (N), 128 x 64 of `out` per wave (4 x 2 MFMA tiles, 128 accumulator registers), K in tiles of 64.
+// The two waves of a SIMD belong to different groups (wm = wave >> 2), and group 1 runs one barrier behind group 0: while one group
+// issues its eight MFMAs of a phase the other reads its next fragments from LDS, so a SIMD's matrix core is fed by one wave while the
+// other waits for the LDS — neither needs a second fragment set.  A K tile is two phases, 64 rows of the wave's tile each (the B
+// fragments are kept for the second):
+//
+//      phase   LDS reads (16 B per lane)           global -> LDS, next K tile (1 KiB pieces per wave)          MFMAs
+//      A       A rows 0-63 (8), B cols 0-63 (8)    A rows 0-63 of both wave rows (2), B (4)                     16
+//      B       A rows 64-127 (8)                   A rows 64-127 (2); all but these two have landed after it    16
+//
+// (Four phases of eight MFMAs — one 64 x 32 quadrant each — measured 3940 cycles per K tile against 2375 for the 64 MFMAs of a SIMD's
+// two waves alone: 600 of the difference were the eight barriers.)
+//
+// Operands go global -> LDS by global_load_lds_dwordx4 (no registers, no ds_write pass).  One such instruction writes the wave's
+// 64 x 16 bytes contiguously (eight 128-byte tile rows), so the LDS image cannot be padded; the bank conflicts of 128-byte rows are
+// avoided by an XOR swizzle instead, applied on the SOURCE address: 16-byte slot s of row r holds k-chunk s ^ ((r >> 1) & 7), and a
+// fragment read of k-chunk c of row r looks in slot c ^ ((r >> 1) & 7).  A ds_read_b128 is served in four groups of 16 lanes
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32), each group wanting 16 distinct 16-byte slots of the 256-byte bank
+// row = two tile rows: row parity picks the half, and (r >> 1) & 7 takes eight distinct values over the eight row pairs of a group.
+//
+// Ordering.  Tile t + 1 is issued during tile t into the other buffer, whose last readers (phase 3 of tile t - 1, the lagging group)
+// have waited for their reads (lgkmcnt) and passed two barriers before the first piece is issued.  The vector-memory counter retires in
+// issue order, so a counted wait says which pieces have landed: vmcnt(2) before the barrier that ends tile t for group 0 leaves only
+// the two pieces nobody reads before phase B in flight, and vmcnt(6) before the barrier that ends group 0's phase A (six younger pieces
+// issued by then) retires those.  A piece is read only after such a wait by its issuing waves AND a barrier the reader
+// has passed.  Barriers are raw s_barrier: a __syncthreads() would drain the DMAs at every phase.
+//
+// Needs fp16 input, K a multiple of 64 and 16-byte aligned rows; rows beyond M / N are clamped on load and never stored.
+// Diagnostic builds only (-DPP_STAMP, tools/gpu_mlp_stamps.py): shader-clock stamps per workgroup and wave.
+#if defined(PP_STAMP)
+__device__ unsigned long long pp_stamp_buf[256 * 8 * 32];
+#define PP_STAMP_AT(k)                                                                                \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (lane == 0 && blockIdx.x < 256 && blockIdx.y == 0) pp_stamp_buf[(blockIdx.x * 8 + wave) * 32 + (k)] = t_; \
+    } while (0)
+#else
+#define PP_STAMP_AT(k) do { } while (0)
+#endif
+#ifndef PP_EXP
+#define PP_EXP 0          // timing experiments (diagnostic builds): 1 no fragment reads, 2 no DMA, 4 no barriers in the K loop — results are wrong
+#endif
+#define PP_TILE_STAMP(j) do { if (t == 8) PP_STAMP_AT(j); else if (t == 9) PP_STAMP_AT(9 + (j)); } while (0)
+
+__global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const int tiles_n, const int tiles_m) {
+    constexpr int BM = 256, BN = 256, BK = 64, TI = 4, TJ = 2;
+    constexpr int kOperand = 2 * (BM + BN) * BK, kPatch = 8 * 64 * PATCH_LD;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];   // [A 0 | B 0 | A 1 | B 1]; afterwards the epilogue patches
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;   // wave: scalar
+    // consecutive workgroup ids go round the eight XCDs: give each XCD a contiguous run of tiles (neighbours share rows of `in`)
+    const int nwg = tiles_n * tiles_m, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int n0 = (id % tiles_n) * BN, m0 = (id / tiles_n) * BM, b = blockIdx.y;
+    const _Float16* W = a.w + (size_t)b * a.w_stride;
+    const _Float16* in = reinterpret_cast<const _Float16*>(a.in) + (size_t)b * a.in_stride;
+
+    // staging: thread -> (row tid >> 3 (+ 64 per issue), slot tid & 7) of the tile; its source k-chunk is slot ^ ((row >> 1) & 7)
+    const int srow = tid >> 3, kc = (lane & 7) ^ ((srow >> 1) & 7);
+    const _Float16* pa[4];
+    const _Float16* pb[4];
 #pragma unroll
-        for (int ib = 0; ib < TI; ib += 2)
-#pragma unroll
-            for (int jb = 0; jb < TJ; jb += 2) {
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int col = wcol0 + (jb + j) * 32 + r;
-                    const float bv = (bias && col < a.n) ? (float)bias[col] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < 2; i++)
-#pragma unroll
-                        for (int reg = 0; reg < 16; reg++) {
-                            float x = acc[ib + i][jb + j][reg] + bv;
-                            if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
-                            patch[(i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * PATCH_LD + j * 32 + r] = (_Float16)x;
-                        }
-                }
-                __builtin_amdgcn_wave_barrier();   // the patch is this wave's own: DS operations of a wave execute in order
-#pragma unroll
-                for (int it = 0; it < 8; it++) {
-                    const int prow = it * 8 + rl, row = wrow0 + ib * 32 + prow, col = wcol0 + jb * 32 + ch * 8;
-                    if (row >= a.m || col >= a.n) continue;
-                    const h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
-                    _Float16* dst = out + (size_t)row * a.ldo + col;
-                    if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
-                    else {
-#pragma unroll
-                        for (int q = 0; q < 8; q++) if (col + q < a.n) dst[q] = v[q];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        return;
+    for (int i = 0; i < 4; i++) {
+        const int ra = m0 + i * 64 + srow, rb = n0 + i * 64 + srow;
+        pa[i] = in + (size_t)(ra < a.m ? ra : a.m - 1) * a.lda + kc * 8;
+        pb[i] = W + (size_t)(rb < a.n ? rb : a.n - 1) * a.ldw + kc * 8;
     }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    // piece i of a tile = its rows 64 i .. 64 i + 63 (A: rows 0-63 / 64-127 of wave row i >> 1; B: the 64 columns of wave column i)
+    auto stage_a = [&](int buf, int k0, int i) {
+        __builtin_amdgcn_global_load_lds((glb_ptr)(pa[i] + k0), (lds_ptr)(smem + buf * (BM + BN) * BK + (i * 512 + wave * 64) * 8), 16, 0, 0);
+    };
+    auto stage_b = [&](int buf, int k0, int i) {
+        __builtin_amdgcn_global_load_lds((glb_ptr)(pb[i] + k0), (lds_ptr)(smem + buf * (BM + BN) * BK + BM * BK + (i * 512 + wave * 64) * 8), 16, 0, 0);
+    };
+
+    f16v acc[TI][TJ];
 #pragma unroll
-    for (int j = 0; j < TJ; j++) {
-        const int col = wcol0 + j * 32 + r;
-        if (col >= a.n) continue;
-        const float bv = bias ? (float)bias[col] : 0.f;
+    for (int i = 0; i < TI; i++)
 #pragma unroll
-        for (int i = 0; i < TI; i++) {
+        for (int j = 0; j < TJ; j++)
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int row = wrow0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (row >= a.m) continue;
-                float x = acc[i][j][reg] + bv;
-                if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
-                (reinterpret_cast<float*>(a.out) + (size_t)b * a.out_stride)[(size_t)row * a.ldo + col] = x;
-            }
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    int swz[4];                                                    // slot (in fp16) of k-chunk 2 kk + h in this lane's rows (all = r mod 32)
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) swz[kk] = ((2 * kk + h) ^ ((r >> 1) & 7)) * 8;
+    const int arow = (wm * 128 + r) * BK, brow = BM * BK + (wn * 64 + r) * BK;
+    int tcur = 0;
+    h8 fa[2][4], fb[2][4];                                         // A: the current 64-row half, [tile][kk]; B: [column tile][kk]
+    auto read_a = [&](const _Float16* t, int half) {
+        if ((PP_EXP & 1) && tcur > 0) return;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) fa[i][kk] = *reinterpret_cast<const h8*>(&t[arow + (half * 2 + i) * 32 * BK + swz[kk]]);
+    };
+    auto read_b = [&](const _Float16* t, int j) {
+        if ((PP_EXP & 1) && tcur > 0) return;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) fb[j][kk] = *reinterpret_cast<const h8*>(&t[brow + j * 32 * BK + swz[kk]]);
+    };
+    auto mfmas = [&](int half) {                                   // 64 x 64 x 64: four accumulators in turn
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[half * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][kk], acc[half * 2 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); if (!(PP_EXP & 4)) __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PP_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+    const int ktiles = a.k / BK;
+    PP_STAMP_AT(30);
+    stage_a(0, 0, 0); stage_a(0, 0, 2);                            // the order of every tile: what phase A reads first, A rows 64-127 last
+    stage_b(0, 0, 0); stage_b(0, 0, 1);
+    stage_b(0, 0, 2); stage_b(0, 0, 3);
+    stage_a(0, 0, 1); stage_a(0, 0, 3);
+    PP_VM(2);
+    PP_BARRIER();
+    if (wm == 1) PP_BARRIER();                                     // group 1 runs one barrier behind
+    for (int t = 0; t < ktiles; t++) {
+        const _Float16* tile = smem + (t & 1) * (BM + BN) * BK;
+        const bool more = t + 1 < ktiles && !(PP_EXP & 2);
+        tcur = t;
+        const int nbuf = (t + 1) & 1, nk0 = (t + 1) * BK;
+        PP_TILE_STAMP(0);
+        // phase A: rows 0-63 of the wave's tile
+        read_a(tile, 0);
+        read_b(tile, 0);
+        read_b(tile, 1);
+        if (more) { stage_a(nbuf, nk0, 0); stage_a(nbuf, nk0, 2); stage_b(nbuf, nk0, 0); stage_b(nbuf, nk0, 1); stage_b(nbuf, nk0, 2); stage_b(nbuf, nk0, 3); }
+        // rows 64-127 of THIS tile's A (issued last, a tile ago) are read in phase B: all but the six pieces issued since must have
+        // landed before the barrier that ends group 0's MFMAs / group 1's reads of phase A
+        if (wm == 1) { if (more) PP_VM(6); else PP_VM(0); }
+        PP_BARRIER();
+        PP_TILE_STAMP(1);
+        PP_LGKM0();
+        mfmas(0);
+        if (wm == 0) { if (more) PP_VM(6); else PP_VM(0); }
+        PP_BARRIER();
+        PP_TILE_STAMP(2);
+        // phase B: rows 64-127.  The barrier after group 0's MFMAs is the one after group 1's reads: before it both wait for all of
+        // the next tile but its last two pieces.
+        read_a(tile, 1);
+        if (more) { stage_a(nbuf, nk0, 1); stage_a(nbuf, nk0, 3); }
+        if (wm == 1) PP_VM(2);
+        PP_BARRIER();
+        PP_TILE_STAMP(3);
+        PP_LGKM0();
+        mfmas(1);
+        if (wm == 0) PP_VM(2);
+        PP_BARRIER();
+        PP_TILE_STAMP(4);
+    }
+    if (wm == 0) PP_BARRIER();                                     // as many barriers as group 1
+#undef PP_BARRIER
+#undef PP_LGKM0
+#undef PP_VM
+    PP_STAMP_AT(31);
+    epilogue<TI, TJ>(a, acc, smem, m0 + wm * 128, n0 + wn * 64, b);
+    PP_STAMP_AT(29);
+}
+
+// ---- the same scheme on 128-row tiles, for the layers whose 256 x 256 grid would leave CUs idle (M = 4096: SURVEY.md §8(f)) ----
+//
+// 128 x (128 TJ) of `out` per workgroup, 64 x (32 TJ) per wave: the whole K tile is ONE phase (8 + 4 TJ fragment reads, then 8 TJ MFMAs),
+// two barriers per K tile.  With a single phase the lagging group issues tile t + 1's DMAs in the last interval before the leading
+// group reads them, so the ring is three tiles deep and a phase issues tile t + 2: vmcnt(pieces of one tile) before the barrier that
+// ends tile t leaves exactly tile t + 2 in flight.  The buffer written in phase t is the one read in phase t - 1, one barrier
+// earlier for the other group: every wave therefore waits for its fragment reads (lgkmcnt(0)) BEFORE its barrier, not after.
+template <int TJ>
+__global__ __launch_bounds__(512) void mlp_layer_pp1_kernel(const Args a, const int tiles_n, const int tiles_m) {
+    constexpr int BM = 128, BN = 128 * TJ, BK = 64, TI = 2, NA = 2, NB = 2 * TJ, P = NA + NB, TILE = (BM + BN) * BK;
+    constexpr int kOperand = 3 * TILE, kPatch = 8 * 64 * PATCH_LD;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];   // three [A | B] tiles; afterwards the epilogue patches
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int nwg = tiles_n * tiles_m, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int n0 = (id % tiles_n) * BN, m0 = (id / tiles_n) * BM, b = blockIdx.y;
+    const _Float16* W = a.w + (size_t)b * a.w_stride;
+    const _Float16* in = reinterpret_cast<const _Float16*>(a.in) + (size_t)b * a.in_stride;
+
+    const int srow = tid >> 3, kc = (lane & 7) ^ ((srow >> 1) & 7);
+    const _Float16* pa[NA];
+    const _Float16* pb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; i++) { const int ra = m0 + i * 64 + srow; pa[i] = in + (size_t)(ra < a.m ? ra : a.m - 1) * a.lda + kc * 8; }
+#pragma unroll
+    for (int i = 0; i < NB; i++) { const int rb = n0 + i * 64 + srow; pb[i] = W + (size_t)(rb < a.n ? rb : a.n - 1) * a.ldw + kc * 8; }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) __builtin_amdgcn_global_load_lds((glb_ptr)(pa[i] + k0), (lds_ptr)(smem + buf * TILE + (i * 512 + wave * 64) * 8), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; i++) __builtin_amdgcn_global_load_lds((glb_ptr)(pb[i] + k0), (lds_ptr)(smem + buf * TILE + BM * BK + (i * 512 + wave * 64) * 8), 16, 0, 0);
+    };
+
+    f16v acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    int swz[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) swz[kk] = ((2 * kk + h) ^ ((r >> 1) & 7)) * 8;
+    const int arow = (wm * 64 + r) * BK, brow = BM * BK + (wn * 32 * TJ + r) * BK;
+    h8 fa[TI][4], fb[TJ][4];
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_WAIT_TILE(more) do { if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+    const int ktiles = a.k / BK;
+    stage(0, 0);
+    if (ktiles > 1) stage(1, BK);
+    PP_WAIT_TILE(ktiles > 1);
+    PP_BARRIER();
+    if (wm == 1) PP_BARRIER();                                     // group 1 runs one barrier behind
+    int buf = 0;
+    for (int t = 0; t < ktiles; t++) {
+        const _Float16* tile = smem + buf * TILE;
+        const bool more = t + 2 < ktiles;
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) fa[i][kk] = *reinterpret_cast<const h8*>(&tile[arow + i * 32 * BK + swz[kk]]);
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) fb[j][kk] = *reinterpret_cast<const h8*>(&tile[brow + j * 32 * BK + swz[kk]]);
+        const int wbuf = buf == 0 ? 2 : buf - 1;                   // (t + 2) % 3: the buffer read in phase t - 1
+        if (more) stage(wbuf, (t + 2) * BK);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (wm == 1) PP_WAIT_TILE(more);
+        PP_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+            for (int i = 0; i < TI; i++)
+#pragma unroll
+                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (wm == 0) PP_WAIT_TILE(more);
+        PP_BARRIER();
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (wm == 0) PP_BARRIER();
+#undef PP_BARRIER
+#undef PP_WAIT_TILE
+    epilogue<TI, TJ>(a, acc, smem, m0 + wm * 64, n0 + wn * 32 * TJ, b);
+}
+
+// obs [m, k] fp32 -> out [m, ld_out] fp16, normalised and clamped, zero beyond k.  One thread per eight output columns.
+__global__ __launch_bounds__(256) void prepare_input_kernel(const float* __restrict__ obs, int m, int k, int ld_obs, const float* __restrict__ mean,
+                                                            const float* __restrict__ inv_std, float clip, _Float16* __restrict__ out, int ld_out) {
+    const int cpr = ld_out / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)m * cpr) return;
+    const int row = (int)(idx / cpr), c0 = (int)(idx % cpr) * 8;
+    const float* p = obs + (size_t)row * ld_obs + c0;
+    h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float g = 0.f;
+        if (c0 + j < k) {
+            g = p[j];
+            if (mean) g = fminf(fmaxf((g - mean[c0 + j]) * inv_std[c0 + j], -clip), clip);
         }
+        v[j] = (_Float16)g;
     }
+    *reinterpret_cast<h8*>(out + (size_t)row * ld_out + c0) = v;
 }
 }  // namespace
+
+#if defined(PP_STAMP)
+extern "C" int ppenv_mlp_debug_read_stamps(unsigned long long* dst, size_t count) {
+    if (hipDeviceSynchronize() != hipSuccess) return PPENV_EHIP;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pp_stamp_buf), count * sizeof(unsigned long long)) == hipSuccess ? 0 : PPENV_EHIP;
+}
+#endif
+
+extern "C" int ppenv_mlp_prepare_input(const float* obs, int32_t m, int32_t k, int32_t ld_obs, const float* mean, const float* inv_std, float clip,
+                                       void* out, int32_t ld_out, void* stream) {
+    if (!obs || !out || m <= 0 || k <= 0 || ld_obs < k || ld_out < k || (ld_out & 7) || (reinterpret_cast<uintptr_t>(out) & 15) || ((mean == nullptr) != (inv_std == nullptr))) {
+        ppenv_set_error("ppenv_mlp_prepare_input: NULL pointer or inconsistent sizes (need ld_obs >= k, ld_out >= k and a multiple of 8, out 16-byte aligned, mean and inv_std together)");
+        return PPENV_EINVAL;
+    }
+    const long long chunks = (long long)m * (ld_out / 8);
+    hipLaunchKernelGGL(prepare_input_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, m, k, ld_obs, mean, inv_std, clip,
+                       reinterpret_cast<_Float16*>(out), ld_out);
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching prepare_input_kernel failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
 
 extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
     if (!L || !L->in || !L->w || !L->out || L->m <= 0 || L->n <= 0 || L->k <= 0 || L->batch <= 0 || L->lda < L->k || L->ldw < L->k || L->ldo < L->n) {
@@ -254,20 +568,26 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
            reinterpret_cast<const _Float16*>(L->w), (long long)L->w_stride, reinterpret_cast<const _Float16*>(L->bias), (long long)L->bias_stride,
            L->out, (long long)L->out_stride};
     // Tile choice.  Measured on the reference's layers (tools/gpu_mlp_layers.py, M = 16384, TFLOP/s on the 2048 -> 1536 layer):
-    //   128 x 128, 4 waves of 64 x 64, BK 64 (two workgroups per CU)            600
-    //   256 x 128, 4 waves of 128 x 64 (one workgroup of four waves per CU)      507   too few waves to hide anything
-    //   256 x 256, 4 waves of 128 x 128                                          157   512 registers and still spilling
-    //   256 x 256, 8 waves of 128 x 64, BK 64 (one workgroup of 8 waves per CU)  727
-    // so: the big tile whenever it still gives most CUs a workgroup, else the small one.  PPENV_MLP_TILE = 128 | 384 | 385 (BK 32) forces one.
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("PPENV_MLP_TILE"); forced = e ? atoi(e) : 0; }
+    //   128 x 128, 4 waves of 64 x 64, BK 64, register staging (two workgroups per CU)            600
+    //   256 x 128, 4 waves of 128 x 64 (one workgroup of four waves per CU)                        507   too few waves to hide anything
+    //   256 x 256, 4 waves of 128 x 128                                                            157   512 registers and still spilling
+    //   256 x 256, 8 waves of 128 x 64, BK 64, register staging (one workgroup of 8 waves per CU)  727
+    //   256 x 256, 8 waves in two alternating groups, LDS-DMA staging (mlp_layer_pp_kernel)         910-960   (hipBLASLt + a separate ELU: 880)
+    // and at M = 4096, where the 256 x 256 grid of the narrower layers covers half the chip or less (us per layer, 256^2 / 128 x 256 / 128^2):
+    //   1536 -> 1024: 47.6 / 33.3 / 38.3      1024 -> 1024: 33.9 / 24.5 / 27.2      1024 -> 512: 30.5 / 20.1 / 14.6      512 -> 512: 19.9 / 13.6 / 10.0
+    // so: among the LDS-DMA kernels the largest tile that still gives three quarters of the CUs a workgroup, else the smallest; the
+    // register-staged kernels for what those cannot take (fp32 input, ragged K, unaligned rows, the narrow heads).
+    // PPENV_MLP_TILE = 128 | 129 | 384 | 385 | 512 | 513 | 514 forces one.
+    const char* env = getenv("PPENV_MLP_TILE");   // read per call: the tests switch it inside one process
+    const int forced = env ? atoi(env) : 0;
     auto wgs = [&](int bm, int bn) { return (long long)((L->n + bn - 1) / bn) * ((L->m + bm - 1) / bm) * L->batch; };
     int cfg = forced;
     if (cfg == 0) {
         // the first layer (fp32 observations, K = 80 or 313) converts its obs tile once per column tile: wide tiles and a K step of 32
         // (less zero padding of K) — 54 us against 86 (256 x 256 / BK 32 vs 128 x 128 / BK 64, M = 4096, K = 313)
         if (L->in_f32) cfg = (wgs(256, 256) >= 128 && L->n >= 256) ? 385 : 129;
-        else cfg = (wgs(256, 256) >= 192 && L->n >= 256) ? 384 : 128;
+        else if (L->n >= 128) cfg = wgs(256, 256) >= 192 ? 512 : wgs(128, 256) >= 192 ? 513 : 514;    // falls back below when the operands do not qualify
+        else cfg = 128;
     }
 #define PP_LAUNCH(WM_, WN_, TI_, TJ_, BK_)                                                                                                    \
     do {                                                                                                                                      \
@@ -275,7 +595,21 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
         if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);        \
         else hipLaunchKernelGGL((mlp_layer_kernel<false, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);                  \
     } while (0)
-    if (cfg == 384) PP_LAUNCH(2, 4, 4, 2, 64);
+    if (cfg == 512 || cfg == 513 || cfg == 514) {
+        const bool ok = !L->in_f32 && L->k % 64 == 0 && L->lda % 8 == 0 && L->ldw % 8 == 0 && L->in_stride % 8 == 0 && L->w_stride % 8 == 0 &&
+                        (reinterpret_cast<uintptr_t>(L->in) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->w) & 15) == 0;
+        if (!ok) cfg = (wgs(256, 256) >= 192 && L->n >= 256) ? 384 : 128;
+    }
+    if (cfg == 512) {
+        const int tn = (L->n + 255) / 256, tm = (L->m + 255) / 256;
+        hipLaunchKernelGGL(mlp_layer_pp_kernel, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+    } else if (cfg == 513) {
+        const int tn = (L->n + 255) / 256, tm = (L->m + 127) / 128;
+        hipLaunchKernelGGL(mlp_layer_pp1_kernel<2>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+    } else if (cfg == 514) {
+        const int tn = (L->n + 127) / 128, tm = (L->m + 127) / 128;
+        hipLaunchKernelGGL(mlp_layer_pp1_kernel<1>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+    } else if (cfg == 384) PP_LAUNCH(2, 4, 4, 2, 64);
     else if (cfg == 385) PP_LAUNCH(2, 4, 4, 2, 32);
     else if (cfg == 129) PP_LAUNCH(2, 2, 2, 2, 32);
     else PP_LAUNCH(2, 2, 2, 2, 64);

@@ -2,10 +2,11 @@
 
 rl_games' a2c_continuous network of the reference (cfg/train/HumanoidPingpongTiltG1PPO.yaml:10-31,50-51): separate actor and critic
 MLPs, units [2048, 1536, 1024, 1024, 512, 512], ELU, a linear mu head (fixed sigma) and a linear value head, inputs normalised by a
-RunningMeanStd (clamped to +-5), mixed precision.  `NativeMLP.forward(obs_buf)` runs it as eight launches of ONE hand-written MFMA
+RunningMeanStd (clamped to +-5), mixed precision.  `NativeMLP.forward(obs_buf)` runs it as nine launches — a normalise-and-pad pass, then eight of the hand-written MFMA
 kernel (v_mfma_f32_32x32x16_f16, fp32 accumulation):
 
-    layer 1     reads obs_buf [M, num_obs] fp32 in place, normalises / clamps / casts while staging, actor | critic as one N = 4096 GEMM
+    input       obs_buf [M, num_obs] fp32 -> normalised, clamped fp16, K padded to a multiple of 64 (or fused into layer 1: fuse_input)
+    layer 1     actor | critic as one N = 4096 GEMM
     layers 2-6  actor and critic as the two problems of one batched launch, bias + ELU on the accumulators, fp16 activations
     heads       mu [M, num_actions] and value [M, 1] in fp32
 
@@ -33,7 +34,16 @@ class MLPLayer(C.Structure):
 def _lib_policy():
     L = _lib.lib()
     L.ppenv_mlp_layer_forward.argtypes = [C.POINTER(MLPLayer), C.c_void_p]
+    L.ppenv_mlp_prepare_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
     return L
+
+
+def prepare_input(out, obs, mean=None, inv_std=None, clip=5.0):
+    """ppenv_mlp_prepare_input on torch tensors: obs fp32 [M, K] -> out fp16 [M, Kpad] normalised, clamped, zero-padded."""
+    L = _lib_policy()
+    _lib.check(L.ppenv_mlp_prepare_input(obs.data_ptr(), obs.shape[0], obs.shape[1], obs.stride(0), mean.data_ptr() if mean is not None else None,
+                                         inv_std.data_ptr() if inv_std is not None else None, clip, out.data_ptr(), out.stride(0),
+                                         torch.cuda.current_stream(obs.device).cuda_stream))
 
 
 def layer_forward(out, x, w, bias, elu, batch=1, in_stride=0, w_stride=0, bias_stride=0, out_stride=0, mean=None, inv_std=None, clip=5.0,
@@ -60,8 +70,12 @@ class NativeMLP:
     """Actor + critic forward on the MFMA kernel.  `actor` / `critic`: lists of (weight [out, in], bias [out]) fp32 tensors, hidden
     layers first, the head last (what `[m for m in net if isinstance(m, nn.Linear)]` yields for the reference's architecture)."""
 
-    def __init__(self, actor, critic, num_obs, device, mean=None, var=None, eps=1e-5, clip=5.0, max_rows=None):
+    def __init__(self, actor, critic, num_obs, device, mean=None, var=None, eps=1e-5, clip=5.0, max_rows=None, fuse_input=False):
+        """fuse_input: layer 1 reads the fp32 observations in place and normalises while staging (one launch fewer, but the
+        register-staged kernel); default: a small normalise-and-pad launch first, then layer 1 on the LDS-DMA kernel like the rest
+        (M = 4096, 313 observations: 54 us fused, see DESIGN.md §5a for the split path)."""
         self.device = torch.device(device)
+        self.fuse_input = bool(fuse_input)
         assert len(actor) == len(critic) and all(a[0].shape[0] == c[0].shape[0] for a, c in zip(actor[:-1], critic[:-1]))
         self.num_obs, self.clip = int(num_obs), float(clip)
         self.units = [a[0].shape[0] for a in actor[:-1]]
@@ -76,10 +90,10 @@ class NativeMLP:
         """fp32 master weights -> the fp16 operand images (actor | critic stacked per layer)."""
         h = lambda t: t.detach().to(self.device, torch.float16).contiguous()
 
-        def hw(t):   # weight rows padded to a multiple of 8 fp16: every row starts 16-byte aligned, so the kernel stages it with 16-byte loads
-            t = h(t)   # (num_obs = 313 gives 626-byte rows; unpadded, the first layer fell back to element loads and ran at a third of the speed)
+        def hw(t):   # weight rows zero-padded to a multiple of 64 fp16 (one K tile): every row starts 16-byte aligned and layer 1
+            t = h(t)   # qualifies for the LDS-DMA kernels (num_obs = 313 gives 626-byte rows; unpadded, it fell back to element loads)
             k = t.shape[1]
-            kp = (k + 7) // 8 * 8
+            kp = (k + 63) // 64 * 64
             if kp == k:
                 return t
             out = torch.zeros((t.shape[0], kp), dtype=torch.float16, device=self.device)
@@ -104,6 +118,7 @@ class NativeMLP:
         z = lambda n, dt: torch.empty((m, n), dtype=dt, device=self.device)
         self.h = [z(2 * u, torch.float16) for u in self.units]            # actor columns first, critic after
         self.mu, self.value = z(self.num_actions, torch.float32), z(1, torch.float32)
+        self.x16 = None if self.fuse_input else z(self.w[0].shape[-1], torch.float16)   # normalised observations, K padded like the weights
         self._rows = m
 
     def forward(self, obs):
@@ -115,9 +130,13 @@ class NativeMLP:
         u = self.units
         # layer 1: both networks read the same rows -> one N = 2 u0 GEMM over the stacked weights
         w0 = self.w[0].view(2 * u[0], self.w[0].shape[-1])
-        layer_forward(self.h[0], obs, w0, self.b[0].view(-1), elu=True, mean=self.mean, inv_std=self.inv_std, clip=self.clip, k=self.num_obs)
+        if self.fuse_input:
+            layer_forward(self.h[0], obs, w0, self.b[0].view(-1), elu=True, mean=self.mean, inv_std=self.inv_std, clip=self.clip, k=self.num_obs)
+        else:
+            prepare_input(self.x16, obs, self.mean, self.inv_std, self.clip)
+            layer_forward(self.h[0], self.x16, w0, self.b[0].view(-1), elu=True)
         for i in range(1, len(u)):
-            layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * u[i - 1],
+            layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],
                           bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])
         last = self.h[-1]
         layer_forward(self.mu, last, self.head_w[0], self.head_b[0], elu=False, m=m, n=self.num_actions, k=u[-1])

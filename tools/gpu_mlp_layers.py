@@ -7,7 +7,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from isaacgym_amd.policy import UNITS, layer_forward  # noqa: E402
+from isaacgym_amd.policy import UNITS, layer_forward, prepare_input  # noqa: E402
 
 dev = torch.device("cuda", 0)
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -33,13 +33,18 @@ mean, istd = torch.zeros(k0, device=dev), torch.ones(k0, device=dev)
 prev = None
 tot_n = tot_t = 0.0
 for i, (kin, n) in enumerate(zip(dims[:-1], dims[1:])):
-    kp = (kin + 7) // 8 * 8                                     # rows padded to 16 bytes, as NativeMLP.load does
+    kp = (kin + 63) // 64 * 64                                  # rows padded to a K tile, as NativeMLP.load does
     w = torch.zeros(2, n, kp, device=dev, dtype=torch.float16)
     w[:, :, :kin] = (torch.randn(2, n, kin, device=dev) / kin ** 0.5).half()
     b = torch.zeros(2, n, device=dev).half()
     out = torch.empty(m, 2 * n, device=dev, dtype=torch.float16)
     if i == 0:
-        fn = lambda: layer_forward(out, obs, w.view(2 * n, kp), b.view(-1), elu=True, mean=mean, inv_std=istd, k=kin)
+        x16p = torch.empty(m, kp, device=dev, dtype=torch.float16)
+        fused = lambda: layer_forward(out, obs, w.view(2 * n, kp), b.view(-1), elu=True, mean=mean, inv_std=istd, k=kin)
+        prep = lambda: prepare_input(x16p, obs, mean, istd)
+        gemm = lambda: layer_forward(out, x16p, w.view(2 * n, kp), b.view(-1), elu=True)
+        print("layer 1 fused (fp32 obs staged by the layer kernel) %.1f us; split: normalise + pad %.1f us, layer %.1f us" % (timeit(fused), timeit(prep), timeit(gemm)))
+        fn = lambda: (prep(), gemm())
         x16 = obs.half()
         wt = w[:, :, :kin].reshape(2 * n, kin).contiguous()
         ft = lambda: torch.nn.functional.elu(torch.nn.functional.linear(x16, wt, b.view(-1)))
@@ -53,4 +58,5 @@ for i, (kin, n) in enumerate(zip(dims[:-1], dims[1:])):
     tot_t += tt
     print("layer %d: [%d x %d] x [%d]^T x2  native %7.1f us %6.0f TF   torch(linear+elu) %7.1f us %6.0f TF" % (i + 1, m, kin, n, tn, fl / tn / 1e6, tt, fl / tt / 1e6))
     prev = out
+print("PPENV_MLP_TILE=%s" % os.environ.get("PPENV_MLP_TILE", "auto"), end=" ")
 print("sum native %.1f us, torch %.1f us" % (tot_n, tot_t))
