@@ -49,6 +49,15 @@ int ppenv_mlp_layer_forward(const ppenv_mlp_layer* layer, void* stream);
 int ppenv_mlp_prepare_input(const float* obs, int32_t m, int32_t k, int32_t ld_obs, const float* mean, const float* inv_std, float clip,
                             void* out, int32_t ld_out, void* stream);
 
+/* The step between the heads and env.step in a rollout (rl_games a2c_continuous, fixed sigma: action ~ Normal(mu, sigma), its
+ * negative log-probability for PPO; the clamp is VecTask.step's clip_actions): one launch instead of five elementwise ones.
+ *   raw = mu[i, j] + sigma[j] * g,  g = the counter RNG's standard normal at (seed, counter, i, j)   (ppenv_device.h dr_gauss)
+ *   actions[i, j] = clamp(raw, lo, hi)            (lo >= hi: no clamp)        [m, a] contiguous
+ *   neglogp[i]    = sum_j (0.5 g^2 + log sigma[j]) + 0.5 a log(2 pi)          (NULL: not wanted)
+ * The same (seed, counter) gives the same draws; the caller advances `counter` every step.  a <= 256. */
+int ppenv_mlp_sample_actions(const float* mu, int32_t m, int32_t a, int32_t ld_mu, const float* sigma, uint64_t seed, uint64_t counter,
+                             float lo, float hi, float* actions, float* neglogp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@
 
 #include "../../include/ppenv.h"
 #include "../../include/ppenv_policy.h"
+#include "ppenv_device.h"   // dr_gauss: the counter RNG's standard normal
 
 void ppenv_set_error(const char* msg);   // ppenv.hip
 
@@ -173,6 +174,65 @@ __device__ __forceinline__ void epilogue(const Args& a, f16v (&acc)[TI][TJ], _Fl
     }
 }
 
+// The same for accumulators of v_mfma_f32_16x16x32_f16 issued with the operands swapped (A := the W fragment, B := the `in` fragment),
+// i.e. holding out^T: lane l has out[row l & 15][columns 4 (l >> 4) .. + 3] of each 16 x 16 tile — four consecutive columns, one
+// 8-byte patch store per tile.  MT x NT tiles per wave (MT, NT multiples of 4: 64 x 64 blocks as above).
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue16(const Args& a, f4v (&acc)[MT][NT], _Float16* smem, int wrow0, int wcol0, int b) {
+    static_assert(MT % 4 == 0 && NT % 4 == 0, "64 x 64 blocks");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const _Float16* bias = a.bias ? a.bias + (size_t)b * a.bias_stride : nullptr;
+    if (!a.out_f32) __syncthreads();                       // every wave is done with the operand buffers: the patches overlay them
+    _Float16* patch = smem + wave * (64 * PATCH_LD);
+    const int rl = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int mb = 0; mb < MT; mb += 4)
+#pragma unroll
+        for (int nb = 0; nb < NT; nb += 4) {
+#pragma unroll
+            for (int jn = 0; jn < 4; jn++) {
+                const int col = wcol0 + (nb + jn) * 16 + 4 * q;
+                float bv[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) bv[e] = (bias && col + e < a.n) ? (float)bias[col + e] : 0.f;
+#pragma unroll
+                for (int im = 0; im < 4; im++) {
+                    float x[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        x[e] = acc[mb + im][nb + jn][e] + bv[e];
+                        if (a.elu) x[e] = x[e] > 0.f ? x[e] : __expf(x[e]) - 1.0f;
+                    }
+                    if (!a.out_f32) {
+                        const h4 v = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+                        *reinterpret_cast<h4*>(&patch[(im * 16 + r) * PATCH_LD + jn * 16 + 4 * q]) = v;
+                    } else {
+                        const int row = wrow0 + (mb + im) * 16 + r;
+                        float* dst = reinterpret_cast<float*>(a.out) + (size_t)b * a.out_stride + (size_t)row * a.ldo + col;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (row < a.m && col + e < a.n) dst[e] = x[e];
+                    }
+                }
+            }
+            if (a.out_f32) continue;
+            _Float16* out = reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int prow = it * 8 + rl, row = wrow0 + mb * 16 + prow, col = wcol0 + nb * 16 + ch * 8;
+                if (row >= a.m || col >= a.n) continue;
+                const h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
+                _Float16* dst = out + (size_t)row * a.ldo + col;
+                if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) if (col + e < a.n) dst[e] = v[e];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
 // WM x WN waves per workgroup, (32 TI) x (32 TJ) of `out` per wave (TI x TJ MFMA tiles, 16 accumulator registers each): the
 // workgroup's tile is BM = 32 TI WM rows by BN = 32 TJ WN columns.  A K sub-step of 16 costs a wave TI + TJ fragment reads (16 bytes
 // per lane each) for TI TJ MFMAs: 1 read per MFMA at 2 x 2, 0.75 at 4 x 2, 0.5 at 4 x 4 — the LDS read traffic, not the global
@@ -299,6 +359,10 @@ __device__ unsigned long long pp_stamp_buf[256 * 8 * 32];
 #endif
 #define PP_TILE_STAMP(j) do { if (t == 8) PP_STAMP_AT(j); else if (t == 9) PP_STAMP_AT(9 + (j)); } while (0)
 
+// M16: the same tile on v_mfma_f32_16x16x32_f16 (8 x 4 tiles of 16 x 16 per wave, operands swapped so the accumulators hold out^T, see
+// epilogue16) instead of v_mfma_f32_32x32x16_f16 (4 x 2 tiles of 32 x 32): same fragment reads, same flops, half the K depth per
+// instruction pair.
+template <bool M16>
 __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const int tiles_n, const int tiles_m) {
     constexpr int BM = 256, BN = 256, BK = 64, TI = 4, TJ = 2;
     constexpr int kOperand = 2 * (BM + BN) * BK, kPatch = 8 * 64 * PATCH_LD;
@@ -331,41 +395,59 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
         __builtin_amdgcn_global_load_lds((glb_ptr)(pb[i] + k0), (lds_ptr)(smem + buf * (BM + BN) * BK + BM * BK + (i * 512 + wave * 64) * 8), 16, 0, 0);
     };
 
-    f16v acc[TI][TJ];
+    // accumulators: 4 x 2 tiles of 32 x 32 (16 registers each), or 8 x 4 tiles of 16 x 16 (4 each): 128 registers either way
+    f16v acc[M16 ? 1 : TI][M16 ? 1 : TJ];
+    f4v acc16[M16 ? 8 : 1][M16 ? 4 : 1];
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < TI; i++)
+        for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int j = 0; j < TJ; j++)
+            for (int j = 0; j < 4; j++) acc16[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJ; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    }
 
-    const int r = lane & 31, h = lane >> 5;
-    int swz[4];                                                    // slot (in fp16) of k-chunk 2 kk + h in this lane's rows (all = r mod 32)
+    // fragment reads: lane -> row r of its MFMA tile, 16-byte k-chunk KH kk + h of the K tile (32 x 32 x 16: 32 rows, 2 chunks per
+    // instruction, 4 instructions deep; 16 x 16 x 32: 16 rows, 4 chunks, 2 deep).  Tile origins are multiples of 16 rows, so a lane's
+    // swizzle term (row >> 1) & 7 is that of r.
+    constexpr int TR = M16 ? 16 : 32, KH = M16 ? 4 : 2, KD = M16 ? 2 : 4, TPH = 64 / TR;   // rows per tile; chunks per instruction; depth; tiles per 64 rows
+    const int r = lane & (TR - 1), h = lane / TR;
+    int swz[KD];
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) swz[kk] = ((2 * kk + h) ^ ((r >> 1) & 7)) * 8;
+    for (int kk = 0; kk < KD; kk++) swz[kk] = ((KH * kk + h) ^ ((r >> 1) & 7)) * 8;
     const int arow = (wm * 128 + r) * BK, brow = BM * BK + (wn * 64 + r) * BK;
     int tcur = 0;
-    h8 fa[2][4], fb[2][4];                                         // A: the current 64-row half, [tile][kk]; B: [column tile][kk]
+    h8 fa[TPH][KD], fb[2][TPH / 2][KD];                            // A: the current 64-row half, [tile][kk]; B: [32-column half][tile][kk] — 8 + 8 reads
     auto read_a = [&](const _Float16* t, int half) {
         if ((PP_EXP & 1) && tcur > 0) return;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < TPH; i++)
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) fa[i][kk] = *reinterpret_cast<const h8*>(&t[arow + (half * 2 + i) * 32 * BK + swz[kk]]);
+            for (int kk = 0; kk < KD; kk++) fa[i][kk] = *reinterpret_cast<const h8*>(&t[arow + (half * TPH + i) * TR * BK + swz[kk]]);
     };
     auto read_b = [&](const _Float16* t, int j) {
         if ((PP_EXP & 1) && tcur > 0) return;
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) fb[j][kk] = *reinterpret_cast<const h8*>(&t[brow + j * 32 * BK + swz[kk]]);
+        for (int i = 0; i < TPH / 2; i++)
+#pragma unroll
+            for (int kk = 0; kk < KD; kk++) fb[j][i][kk] = *reinterpret_cast<const h8*>(&t[brow + (j * (TPH / 2) + i) * TR * BK + swz[kk]]);
     };
-    auto mfmas = [&](int half) {                                   // 64 x 64 x 64: four accumulators in turn
+    auto mfmas = [&](int half) {                                   // 64 x 64 x 64: every accumulator of the half in turn
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++)
+        for (int kk = 0; kk < KD; kk++)
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < TPH; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[half * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][kk], acc[half * 2 + i][j], 0, 0, 0);
+                for (int j = 0; j < TPH; j++) {
+                    if constexpr (M16) acc16[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j >> 1][j & 1][kk], fa[i][kk], acc16[half * 4 + i][j], 0, 0, 0);
+                    else acc[half * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][0][kk], acc[half * 2 + i][j], 0, 0, 0);
+                }
         __builtin_amdgcn_s_setprio(0);
     };
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); if (!(PP_EXP & 4)) __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -420,7 +502,8 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
 #undef PP_LGKM0
 #undef PP_VM
     PP_STAMP_AT(31);
-    epilogue<TI, TJ>(a, acc, smem, m0 + wm * 128, n0 + wn * 64, b);
+    if constexpr (M16) epilogue16<8, 4>(a, acc16, smem, m0 + wm * 128, n0 + wn * 64, b);
+    else epilogue<TI, TJ>(a, acc, smem, m0 + wm * 128, n0 + wn * 64, b);
     PP_STAMP_AT(29);
 }
 
@@ -536,6 +619,24 @@ __global__ __launch_bounds__(256) void prepare_input_kernel(const float* __restr
     }
     *reinterpret_cast<h8*>(out + (size_t)row * ld_out + c0) = v;
 }
+
+// one thread per row: a draws, the clamp, the row's negative log-probability
+__global__ __launch_bounds__(256) void sample_actions_kernel(const float* __restrict__ mu, int m, int a, int ld_mu, const float* __restrict__ sigma,
+                                                             unsigned long long seed, unsigned long long counter, float lo, float hi,
+                                                             float* __restrict__ actions, float* __restrict__ neglogp) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= m) return;
+    float nl = 0.9189385332f * (float)a;                          // 0.5 log(2 pi) per action
+    for (int j = 0; j < a; j++) {
+        const float sg = sigma[j];
+        const float g = pp::dr_gauss(seed, (uint32_t)row, (uint32_t)(counter >> 24), (uint32_t)(counter & 0xFFFFFFu), (uint32_t)j);
+        float x = mu[(size_t)row * ld_mu + j] + sg * g;
+        nl += 0.5f * g * g + logf(sg);
+        if (lo < hi) x = fminf(fmaxf(x, lo), hi);
+        actions[(size_t)row * a + j] = x;
+    }
+    if (neglogp) neglogp[row] = nl;
+}
 }  // namespace
 
 #if defined(PP_STAMP)
@@ -558,6 +659,18 @@ extern "C" int ppenv_mlp_prepare_input(const float* obs, int32_t m, int32_t k, i
     return PPENV_OK;
 }
 
+extern "C" int ppenv_mlp_sample_actions(const float* mu, int32_t m, int32_t a, int32_t ld_mu, const float* sigma, uint64_t seed, uint64_t counter,
+                                        float lo, float hi, float* actions, float* neglogp, void* stream) {
+    if (!mu || !sigma || !actions || m <= 0 || a <= 0 || a > 256 || ld_mu < a) {
+        ppenv_set_error("ppenv_mlp_sample_actions: NULL pointer or inconsistent sizes (need 0 < a <= 256, ld_mu >= a)");
+        return PPENV_EINVAL;
+    }
+    hipLaunchKernelGGL(sample_actions_kernel, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, m, a, ld_mu, sigma,
+                       (unsigned long long)seed, (unsigned long long)counter, lo, hi, actions, neglogp);
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching sample_actions_kernel failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
+
 extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
     if (!L || !L->in || !L->w || !L->out || L->m <= 0 || L->n <= 0 || L->k <= 0 || L->batch <= 0 || L->lda < L->k || L->ldw < L->k || L->ldo < L->n) {
         ppenv_set_error("ppenv_mlp_layer_forward: NULL pointer or inconsistent sizes (need lda >= k, ldw >= k, ldo >= n)");
@@ -575,9 +688,12 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
     //   256 x 256, 8 waves in two alternating groups, LDS-DMA staging (mlp_layer_pp_kernel)         910-960   (hipBLASLt + a separate ELU: 880)
     // and at M = 4096, where the 256 x 256 grid of the narrower layers covers half the chip or less (us per layer, 256^2 / 128 x 256 / 128^2):
     //   1536 -> 1024: 47.6 / 33.3 / 38.3      1024 -> 1024: 33.9 / 24.5 / 27.2      1024 -> 512: 30.5 / 20.1 / 14.6      512 -> 512: 19.9 / 13.6 / 10.0
+    // The 256 x 256 tile on v_mfma_f32_16x16x32_f16 instead of 32x32x16 (516): 986 / 979 / 855 TF against 924 / 936 / 832 on the K = 2048 /
+    // 1536 / 1024 layers at M = 16384 (the chip runs these kernels at its power limit — the shader clock sags from 1.95 to 1.6 GHz as the
+    // K loop gets denser — and the smaller instruction costs less per flop), but a slower epilogue: only where K >= 1024 amortises it.
     // so: among the LDS-DMA kernels the largest tile that still gives three quarters of the CUs a workgroup, else the smallest; the
     // register-staged kernels for what those cannot take (fp32 input, ragged K, unaligned rows, the narrow heads).
-    // PPENV_MLP_TILE = 128 | 129 | 384 | 385 | 512 | 513 | 514 forces one.
+    // PPENV_MLP_TILE = 128 | 129 | 384 | 385 | 512 | 513 | 514 | 516 forces one.
     const char* env = getenv("PPENV_MLP_TILE");   // read per call: the tests switch it inside one process
     const int forced = env ? atoi(env) : 0;
     auto wgs = [&](int bm, int bn) { return (long long)((L->n + bn - 1) / bn) * ((L->m + bm - 1) / bm) * L->batch; };
@@ -586,7 +702,7 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
         // the first layer (fp32 observations, K = 80 or 313) converts its obs tile once per column tile: wide tiles and a K step of 32
         // (less zero padding of K) — 54 us against 86 (256 x 256 / BK 32 vs 128 x 128 / BK 64, M = 4096, K = 313)
         if (L->in_f32) cfg = (wgs(256, 256) >= 128 && L->n >= 256) ? 385 : 129;
-        else if (L->n >= 128) cfg = wgs(256, 256) >= 192 ? 512 : wgs(128, 256) >= 192 ? 513 : 514;    // falls back below when the operands do not qualify
+        else if (L->n >= 128) cfg = wgs(256, 256) >= 192 ? (L->k >= 1024 ? 516 : 512) : wgs(128, 256) >= 192 ? 513 : 514;    // falls back below when the operands do not qualify
         else cfg = 128;
     }
 #define PP_LAUNCH(WM_, WN_, TI_, TJ_, BK_)                                                                                                    \
@@ -595,14 +711,17 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
         if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);        \
         else hipLaunchKernelGGL((mlp_layer_kernel<false, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);                  \
     } while (0)
-    if (cfg == 512 || cfg == 513 || cfg == 514) {
+    if (cfg == 512 || cfg == 513 || cfg == 514 || cfg == 516) {
         const bool ok = !L->in_f32 && L->k % 64 == 0 && L->lda % 8 == 0 && L->ldw % 8 == 0 && L->in_stride % 8 == 0 && L->w_stride % 8 == 0 &&
                         (reinterpret_cast<uintptr_t>(L->in) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->w) & 15) == 0;
         if (!ok) cfg = (wgs(256, 256) >= 192 && L->n >= 256) ? 384 : 128;
     }
     if (cfg == 512) {
         const int tn = (L->n + 255) / 256, tm = (L->m + 255) / 256;
-        hipLaunchKernelGGL(mlp_layer_pp_kernel, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+        hipLaunchKernelGGL(mlp_layer_pp_kernel<false>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+    } else if (cfg == 516) {
+        const int tn = (L->n + 255) / 256, tm = (L->m + 255) / 256;
+        hipLaunchKernelGGL(mlp_layer_pp_kernel<true>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
     } else if (cfg == 513) {
         const int tn = (L->n + 255) / 256, tm = (L->m + 127) / 128;
         hipLaunchKernelGGL(mlp_layer_pp1_kernel<2>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);

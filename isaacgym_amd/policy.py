@@ -2,13 +2,13 @@
 
 rl_games' a2c_continuous network of the reference (cfg/train/HumanoidPingpongTiltG1PPO.yaml:10-31,50-51): separate actor and critic
 MLPs, units [2048, 1536, 1024, 1024, 512, 512], ELU, a linear mu head (fixed sigma) and a linear value head, inputs normalised by a
-RunningMeanStd (clamped to +-5), mixed precision.  `NativeMLP.forward(obs_buf)` runs it as nine launches — a normalise-and-pad pass, then eight of the hand-written MFMA
+RunningMeanStd (clamped to +-5), mixed precision.  `NativeMLP.forward(obs_buf)` runs it as eight launches — a normalise-and-pad pass, then seven of the hand-written MFMA
 kernel (v_mfma_f32_32x32x16_f16, fp32 accumulation):
 
     input       obs_buf [M, num_obs] fp32 -> normalised, clamped fp16, K padded to a multiple of 64 (or fused into layer 1: fuse_input)
     layer 1     actor | critic as one N = 4096 GEMM
     layers 2-6  actor and critic as the two problems of one batched launch, bias + ELU on the accumulators, fp16 activations
-    heads       mu [M, num_actions] and value [M, 1] in fp32
+    heads       mu [M, num_actions] and value [M, 1] in fp32, one block-diagonal layer over [actor | critic] features
 
 PyTorch is only the owner of the device buffers here.  Weights are cast to fp16 once (`load`), as autocast does per call.
 """
@@ -35,7 +35,19 @@ def _lib_policy():
     L = _lib.lib()
     L.ppenv_mlp_layer_forward.argtypes = [C.POINTER(MLPLayer), C.c_void_p]
     L.ppenv_mlp_prepare_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
+    L.ppenv_mlp_sample_actions.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_float, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
     return L
+
+
+def sample_actions(actions, mu, sigma, seed, counter, lo=-1.0, hi=1.0, neglogp=None):
+    """ppenv_mlp_sample_actions on torch tensors: actions [M, A] = clamp(mu + sigma * N(0, 1), lo, hi), neglogp [M] of the unclamped
+    draw (rl_games a2c_continuous with fixed sigma); deterministic in (seed, counter)."""
+    L = _lib_policy()
+    assert actions.is_contiguous() and mu.stride(1) == 1 and sigma.is_contiguous()
+    _lib.check(L.ppenv_mlp_sample_actions(mu.data_ptr(), mu.shape[0], mu.shape[1], mu.stride(0), sigma.data_ptr(), seed, counter, lo, hi,
+                                          actions.data_ptr(), neglogp.data_ptr() if neglogp is not None else None,
+                                          torch.cuda.current_stream(mu.device).cuda_stream))
 
 
 def prepare_input(out, obs, mean=None, inv_std=None, clip=5.0):
@@ -103,8 +115,12 @@ class NativeMLP:
         for (wa, ba), (wc, bc) in zip(actor[:-1], critic[:-1]):
             self.w.append(torch.stack([hw(wa), hw(wc)]).contiguous())     # [2, n, k (padded)]
             self.b.append(torch.stack([h(ba), h(bc)]).contiguous())       # [2, n]
-        self.head_w = [h(actor[-1][0]), h(critic[-1][0])]
-        self.head_b = [h(actor[-1][1]), h(critic[-1][1])]
+        # the two heads as ONE block-diagonal layer over the stacked features [actor | critic]: rows 0 .. A-1 read the actor half, row A the critic half
+        ul, na = self.units[-1], actor[-1][0].shape[0]
+        self.head_w = torch.zeros((na + 1, 2 * ul), dtype=torch.float16, device=self.device)
+        self.head_w[:na, :ul] = h(actor[-1][0])
+        self.head_w[na:, ul:] = h(critic[-1][0])
+        self.head_b = torch.cat([h(actor[-1][1]), h(critic[-1][1])]).contiguous()
 
     def set_normalization(self, mean, var, eps=1e-5):
         """rl_games RunningMeanStd in eval mode: (x - mean) / sqrt(var + eps), then clamp(+-clip)."""
@@ -117,7 +133,8 @@ class NativeMLP:
     def _alloc(self, m):
         z = lambda n, dt: torch.empty((m, n), dtype=dt, device=self.device)
         self.h = [z(2 * u, torch.float16) for u in self.units]            # actor columns first, critic after
-        self.mu, self.value = z(self.num_actions, torch.float32), z(1, torch.float32)
+        self.head_out = z(self.num_actions + 1, torch.float32)
+        self.mu, self.value = self.head_out[:, :self.num_actions], self.head_out[:, self.num_actions:]       # views: [M, A] and [M, 1]
         self.x16 = None if self.fuse_input else z(self.w[0].shape[-1], torch.float16)   # normalised observations, K padded like the weights
         self._rows = m
 
@@ -138,9 +155,7 @@ class NativeMLP:
         for i in range(1, len(u)):
             layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],
                           bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])
-        last = self.h[-1]
-        layer_forward(self.mu, last, self.head_w[0], self.head_b[0], elu=False, m=m, n=self.num_actions, k=u[-1])
-        layer_forward(self.value, last[:, u[-1]:], self.head_w[1], self.head_b[1], elu=False, m=m, n=1, k=u[-1])
+        layer_forward(self.head_out, self.h[-1], self.head_w, self.head_b, elu=False)
         return self.mu, self.value
 
     @staticmethod

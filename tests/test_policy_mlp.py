@@ -73,7 +73,7 @@ def test_layer_kernel_exact_on_integer_data():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", [128, 384, 512, 513, 514])
+@pytest.mark.parametrize("tile", [128, 384, 512, 513, 514, 516])
 @pytest.mark.parametrize("out_f32", [False, True])
 def test_every_tile_exact_on_integer_data(tile, out_f32, monkeypatch):
     """The same bit-for-bit check for each tile configuration the launcher can pick (PPENV_MLP_TILE forces one), as the batched
@@ -113,3 +113,34 @@ def test_prepare_input_matches_torch():
     prepare_input(out, obs)                                         # no statistics: cast only
     want[:, :k] = obs.half()
     assert torch.equal(out, want)
+
+
+@pytest.mark.gpu
+def test_sample_actions_distribution_clamp_and_neglogp():
+    """ppenv_mlp_sample_actions: Normal(mu, sigma) draws from the counter RNG (the reference samples with torch's generator: the stream
+    is not pinnable, the distribution is), the clamp, the negative log-probability rl_games computes, determinism in (seed, counter)."""
+    import torch
+    from isaacgym_amd.policy import sample_actions
+    m, a = 20000, 27
+    gen = torch.Generator().manual_seed(3)
+    head = torch.zeros(m, a + 1, device="cuda")                       # mu as NativeMLP hands it over: a view with row stride a + 1
+    head[:, :a] = (torch.rand(m, a, generator=gen) - 0.5).cuda()
+    mu = head[:, :a]
+    sigma = (torch.rand(a, generator=gen) * 0.5 + 0.2).cuda()
+    raw, nl = torch.zeros(m, a, device="cuda"), torch.zeros(m, device="cuda")
+    sample_actions(raw, mu, sigma, 7, 1, 0.0, 0.0, nl)                  # lo >= hi: unclamped
+    g = (raw - mu) / sigma
+    assert abs(float(g.mean())) < 0.01 and abs(float(g.std()) - 1.0) < 0.01
+    assert abs(float((g ** 3).mean())) < 0.03 and abs(float((g ** 4).mean()) - 3.0) < 0.1          # skewness 0, kurtosis 3
+    cols = g.t() @ g / m                                                # independent across actions
+    assert float((cols - torch.eye(a, device="cuda")).abs().max()) < 0.05
+    want_nl = 0.5 * (g ** 2).sum(1) + torch.log(sigma).sum() + 0.5 * a * np.log(2 * np.pi)
+    assert torch.allclose(nl, want_nl, rtol=1e-5, atol=1e-3)
+    clamped = torch.zeros_like(raw)
+    sample_actions(clamped, mu, sigma, 7, 1, -1.0, 1.0)
+    assert torch.equal(clamped, raw.clamp(-1.0, 1.0))                   # same (seed, counter): same draws
+    other = torch.zeros_like(raw)
+    sample_actions(other, mu, sigma, 7, 2, 0.0, 0.0)
+    assert float((other - raw).abs().mean()) > 0.1                      # next counter: new draws
+    rows = (raw[1:] - mu[1:]) / sigma - (raw[:-1] - mu[:-1]) / sigma    # and rows are not copies of each other
+    assert float(rows.abs().mean()) > 0.5

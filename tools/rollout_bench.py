@@ -63,7 +63,7 @@ def main():
     inv_std = torch.ones(num_obs, device=dev)
     native = None
     if args.policy == "native":
-        from isaacgym_amd.policy import NativeMLP
+        from isaacgym_amd.policy import NativeMLP, sample_actions
         lin = lambda net: [(m.weight, m.bias) for m in net if isinstance(m, torch.nn.Linear)]
         native = NativeMLP(lin(actor), lin(critic), num_obs, dev, mean=mean, var=torch.ones(num_obs, device=dev) - 1e-5, max_rows=n)
     actor, critic = actor.half(), critic.half()   # weights cast once (rl_games' autocast re-casts the fp32 master weights in every call)
@@ -73,13 +73,22 @@ def main():
     @torch.no_grad()
     def forward():
         if native is not None:
-            return native.forward(obs_buf)                                # normalisation fused into layer 1; obs_buf read in place
+            return native.forward(obs_buf)
         x = torch.clamp((obs_buf - mean) * inv_std, -5.0, 5.0).half()     # rl_games RunningMeanStd in eval mode
         return actor(x).float(), critic(x).float()
+
+    action_buf = torch.zeros(n, num_act, device=dev)
+    neglogp = torch.zeros(n, device=dev)
+    counter = [0]
 
     @torch.no_grad()
     def rollout_step():
         mu, v = forward()
+        if native is not None:   # the value is already where the learner reads it (a view of the heads' output); one launch samples, clamps and scores
+            counter[0] += 1
+            sample_actions(action_buf, mu, sigma, 0, counter[0], -1.0, 1.0, neglogp)
+            step(action_buf)
+            return
         values.copy_(v)
         action = torch.clamp(mu + sigma * torch.randn_like(mu), -1.0, 1.0).contiguous()
         step(action)
@@ -128,7 +137,7 @@ def main():
         "policy_mfma_frac_of_dense_peak": flops / t_pol / 1e12 / MFMA_PEAK_TFLOPS, "policy_gflop_per_step": flops / 1e9,
         "us_env_step_eager": t_env * 1e6,
         "policy": "actor + critic MLP [2048,1536,1024,1024,512,512] ELU, fp16 operands / fp32 accumulation, random init; "
-                  + ("hand-written MFMA kernel (8 launches, obs normalisation fused)" if native is not None else "PyTorch / hipBLASLt"),
+                  + ("hand-written MFMA kernels (normalise-and-pad pass + 7 layer launches + one sampling launch)" if native is not None else "PyTorch / hipBLASLt"),
     }))
 
 
