@@ -179,58 +179,59 @@ __device__ __forceinline__ void epilogue(const Args& a, f16v (&acc)[TI][TJ], _Fl
 // 8-byte patch store per tile.  MT x NT tiles per wave (MT, NT multiples of 4: 64 x 64 blocks as above).
 template <int MT, int NT>
 __device__ __forceinline__ void epilogue16(const Args& a, f4v (&acc)[MT][NT], _Float16* smem, int wrow0, int wcol0, int b) {
-    static_assert(MT % 4 == 0 && NT % 4 == 0, "64 x 64 blocks");
+    static_assert(MT % 4 == 0 && NT <= 4, "blocks of 64 rows x 16 NT <= 64 columns");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
     const _Float16* bias = a.bias ? a.bias + (size_t)b * a.bias_stride : nullptr;
     if (!a.out_f32) __syncthreads();                       // every wave is done with the operand buffers: the patches overlay them
     _Float16* patch = smem + wave * (64 * PATCH_LD);
-    const int rl = lane >> 3, ch = lane & 7;
+    float bv[NT][4];
 #pragma unroll
-    for (int mb = 0; mb < MT; mb += 4)
+    for (int jn = 0; jn < NT; jn++)
 #pragma unroll
-        for (int nb = 0; nb < NT; nb += 4) {
+        for (int e = 0; e < 4; e++) { const int col = wcol0 + jn * 16 + 4 * q + e; bv[jn][e] = (bias && col < a.n) ? (float)bias[col] : 0.f; }
 #pragma unroll
-            for (int jn = 0; jn < 4; jn++) {
-                const int col = wcol0 + (nb + jn) * 16 + 4 * q;
-                float bv[4];
+    for (int mb = 0; mb < MT; mb += 4) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) bv[e] = (bias && col + e < a.n) ? (float)bias[col + e] : 0.f;
+        for (int jn = 0; jn < NT; jn++) {
+            const int col = wcol0 + jn * 16 + 4 * q;
 #pragma unroll
-                for (int im = 0; im < 4; im++) {
-                    float x[4];
+            for (int im = 0; im < 4; im++) {
+                float x[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        x[e] = acc[mb + im][nb + jn][e] + bv[e];
-                        if (a.elu) x[e] = x[e] > 0.f ? x[e] : __expf(x[e]) - 1.0f;
-                    }
-                    if (!a.out_f32) {
-                        const h4 v = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
-                        *reinterpret_cast<h4*>(&patch[(im * 16 + r) * PATCH_LD + jn * 16 + 4 * q]) = v;
-                    } else {
-                        const int row = wrow0 + (mb + im) * 16 + r;
-                        float* dst = reinterpret_cast<float*>(a.out) + (size_t)b * a.out_stride + (size_t)row * a.ldo + col;
+                for (int e = 0; e < 4; e++) {
+                    x[e] = acc[mb + im][jn][e] + bv[jn][e];
+                    if (a.elu) x[e] = x[e] > 0.f ? x[e] : __expf(x[e]) - 1.0f;
+                }
+                if (!a.out_f32) {
+                    const h4 v = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+                    *reinterpret_cast<h4*>(&patch[(im * 16 + r) * PATCH_LD + jn * 16 + 4 * q]) = v;
+                } else {
+                    const int row = wrow0 + (mb + im) * 16 + r;
+                    float* dst = reinterpret_cast<float*>(a.out) + (size_t)b * a.out_stride + (size_t)row * a.ldo + col;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) if (row < a.m && col + e < a.n) dst[e] = x[e];
-                    }
+                    for (int e = 0; e < 4; e++) if (row < a.m && col + e < a.n) dst[e] = x[e];
                 }
             }
-            if (a.out_f32) continue;
-            _Float16* out = reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int prow = it * 8 + rl, row = wrow0 + mb * 16 + prow, col = wcol0 + nb * 16 + ch * 8;
-                if (row >= a.m || col >= a.n) continue;
-                const h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
-                _Float16* dst = out + (size_t)row * a.ldo + col;
-                if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) if (col + e < a.n) dst[e] = v[e];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
         }
+        if (a.out_f32) continue;
+        _Float16* out = reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride;
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CPR = 2 * NT;                        // 16-byte chunks per patch row
+#pragma unroll
+        for (int it = 0; it < CPR; it++) {                 // 64 rows x CPR chunks = 64 CPR chunks, 64 per pass
+            const int c = it * 64 + lane, prow = c / CPR, ch = c % CPR;
+            const int row = wrow0 + mb * 16 + prow, col = wcol0 + ch * 8;
+            if (row >= a.m || col >= a.n) continue;
+            const h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
+            _Float16* dst = out + (size_t)row * a.ldo + col;
+            if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) if (col + e < a.n) dst[e] = v[e];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // WM x WN waves per workgroup, (32 TI) x (32 TJ) of `out` per wave (TI x TJ MFMA tiles, 16 accumulator registers each): the
@@ -362,9 +363,12 @@ __device__ unsigned long long pp_stamp_buf[256 * 8 * 32];
 // M16: the same tile on v_mfma_f32_16x16x32_f16 (8 x 4 tiles of 16 x 16 per wave, operands swapped so the accumulators hold out^T, see
 // epilogue16) instead of v_mfma_f32_32x32x16_f16 (4 x 2 tiles of 32 x 32): same fragment reads, same flops, half the K depth per
 // instruction pair.
-template <bool M16>
+// NT (M16 only): 16-column tiles per wave — 4: 256 columns per workgroup; 3: 192, for the layer whose 256 x 256 grid would leave a
+// quarter of the CUs without a workgroup (2048 -> 1536 at M = 4096: 192 tiles of 256 x 256, 256 of 256 x 192).
+template <bool M16, int NT = 4>
 __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const int tiles_n, const int tiles_m) {
-    constexpr int BM = 256, BN = 256, BK = 64, TI = 4, TJ = 2;
+    static_assert(M16 ? (NT == 3 || NT == 4) : NT == 4, "wave tile 128 x 16 NT");
+    constexpr int BM = 256, BN = 64 * NT, BK = 64, TI = 4, TJ = 2, NB = BN / 64;   // NB: 1 KiB-per-wave pieces of a B tile
     constexpr int kOperand = 2 * (BM + BN) * BK, kPatch = 8 * 64 * PATCH_LD;
     __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];   // [A 0 | B 0 | A 1 | B 1]; afterwards the epilogue patches
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;   // wave: scalar
@@ -378,31 +382,31 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
     // staging: thread -> (row tid >> 3 (+ 64 per issue), slot tid & 7) of the tile; its source k-chunk is slot ^ ((row >> 1) & 7)
     const int srow = tid >> 3, kc = (lane & 7) ^ ((srow >> 1) & 7);
     const _Float16* pa[4];
-    const _Float16* pb[4];
+    const _Float16* pb[NB];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int ra = m0 + i * 64 + srow, rb = n0 + i * 64 + srow;
-        pa[i] = in + (size_t)(ra < a.m ? ra : a.m - 1) * a.lda + kc * 8;
-        pb[i] = W + (size_t)(rb < a.n ? rb : a.n - 1) * a.ldw + kc * 8;
-    }
+    for (int i = 0; i < 4; i++) { const int ra = m0 + i * 64 + srow; pa[i] = in + (size_t)(ra < a.m ? ra : a.m - 1) * a.lda + kc * 8; }
+#pragma unroll
+    for (int i = 0; i < NB; i++) { const int rb = n0 + i * 64 + srow; pb[i] = W + (size_t)(rb < a.n ? rb : a.n - 1) * a.ldw + kc * 8; }
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
-    // piece i of a tile = its rows 64 i .. 64 i + 63 (A: rows 0-63 / 64-127 of wave row i >> 1; B: the 64 columns of wave column i)
+    // piece i of a tile = its rows 64 i .. 64 i + 63 (A: rows 0-63 / 64-127 of wave row i >> 1; B: 64 columns)
     auto stage_a = [&](int buf, int k0, int i) {
         __builtin_amdgcn_global_load_lds((glb_ptr)(pa[i] + k0), (lds_ptr)(smem + buf * (BM + BN) * BK + (i * 512 + wave * 64) * 8), 16, 0, 0);
     };
-    auto stage_b = [&](int buf, int k0, int i) {
-        __builtin_amdgcn_global_load_lds((glb_ptr)(pb[i] + k0), (lds_ptr)(smem + buf * (BM + BN) * BK + BM * BK + (i * 512 + wave * 64) * 8), 16, 0, 0);
+    auto stage_b = [&](int buf, int k0) {                          // the whole B tile
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(pb[i] + k0), (lds_ptr)(smem + buf * (BM + BN) * BK + BM * BK + (i * 512 + wave * 64) * 8), 16, 0, 0);
     };
 
     // accumulators: 4 x 2 tiles of 32 x 32 (16 registers each), or 8 x 4 tiles of 16 x 16 (4 each): 128 registers either way
     f16v acc[M16 ? 1 : TI][M16 ? 1 : TJ];
-    f4v acc16[M16 ? 8 : 1][M16 ? 4 : 1];
+    f4v acc16[M16 ? 8 : 1][M16 ? NT : 1];
     if constexpr (M16) {
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc16[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NT; j++) acc16[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
         for (int i = 0; i < TI; i++)
@@ -420,9 +424,10 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
     int swz[KD];
 #pragma unroll
     for (int kk = 0; kk < KD; kk++) swz[kk] = ((KH * kk + h) ^ ((r >> 1) & 7)) * 8;
-    const int arow = (wm * 128 + r) * BK, brow = BM * BK + (wn * 64 + r) * BK;
+    constexpr int TB = M16 ? NT : 2;                               // B tiles per wave (of TR columns)
+    const int arow = (wm * 128 + r) * BK, brow = BM * BK + (wn * TB * TR + r) * BK;
     int tcur = 0;
-    h8 fa[TPH][KD], fb[2][TPH / 2][KD];                            // A: the current 64-row half, [tile][kk]; B: [32-column half][tile][kk] — 8 + 8 reads
+    h8 fa[TPH][KD], fb[TB][KD];                                    // A: the current 64-row half, [tile][kk]; B: [tile][kk] — 8 + 2 TB (8 or 6) reads
     auto read_a = [&](const _Float16* t, int half) {
         if ((PP_EXP & 1) && tcur > 0) return;
 #pragma unroll
@@ -430,12 +435,12 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
 #pragma unroll
             for (int kk = 0; kk < KD; kk++) fa[i][kk] = *reinterpret_cast<const h8*>(&t[arow + (half * TPH + i) * TR * BK + swz[kk]]);
     };
-    auto read_b = [&](const _Float16* t, int j) {
+    auto read_b = [&](const _Float16* t) {
         if ((PP_EXP & 1) && tcur > 0) return;
 #pragma unroll
-        for (int i = 0; i < TPH / 2; i++)
+        for (int j = 0; j < TB; j++)
 #pragma unroll
-            for (int kk = 0; kk < KD; kk++) fb[j][i][kk] = *reinterpret_cast<const h8*>(&t[brow + (j * (TPH / 2) + i) * TR * BK + swz[kk]]);
+            for (int kk = 0; kk < KD; kk++) fb[j][kk] = *reinterpret_cast<const h8*>(&t[brow + j * TR * BK + swz[kk]]);
     };
     auto mfmas = [&](int half) {                                   // 64 x 64 x 64: every accumulator of the half in turn
         __builtin_amdgcn_s_setprio(1);
@@ -444,21 +449,20 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
 #pragma unroll
             for (int i = 0; i < TPH; i++)
 #pragma unroll
-                for (int j = 0; j < TPH; j++) {
-                    if constexpr (M16) acc16[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j >> 1][j & 1][kk], fa[i][kk], acc16[half * 4 + i][j], 0, 0, 0);
-                    else acc[half * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][0][kk], acc[half * 2 + i][j], 0, 0, 0);
+                for (int j = 0; j < TB; j++) {
+                    if constexpr (M16) acc16[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][kk], fa[i][kk], acc16[half * 4 + i][j], 0, 0, 0);
+                    else acc[half * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][kk], acc[half * 2 + i][j], 0, 0, 0);
                 }
         __builtin_amdgcn_s_setprio(0);
     };
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); if (!(PP_EXP & 4)) __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define PP_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define PP_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
 
     const int ktiles = a.k / BK;
     PP_STAMP_AT(30);
     stage_a(0, 0, 0); stage_a(0, 0, 2);                            // the order of every tile: what phase A reads first, A rows 64-127 last
-    stage_b(0, 0, 0); stage_b(0, 0, 1);
-    stage_b(0, 0, 2); stage_b(0, 0, 3);
+    stage_b(0, 0);
     stage_a(0, 0, 1); stage_a(0, 0, 3);
     PP_VM(2);
     PP_BARRIER();
@@ -471,17 +475,16 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
         PP_TILE_STAMP(0);
         // phase A: rows 0-63 of the wave's tile
         read_a(tile, 0);
-        read_b(tile, 0);
-        read_b(tile, 1);
-        if (more) { stage_a(nbuf, nk0, 0); stage_a(nbuf, nk0, 2); stage_b(nbuf, nk0, 0); stage_b(nbuf, nk0, 1); stage_b(nbuf, nk0, 2); stage_b(nbuf, nk0, 3); }
-        // rows 64-127 of THIS tile's A (issued last, a tile ago) are read in phase B: all but the six pieces issued since must have
+        read_b(tile);
+        if (more) { stage_a(nbuf, nk0, 0); stage_a(nbuf, nk0, 2); stage_b(nbuf, nk0); }
+        // rows 64-127 of THIS tile's A (issued last, a tile ago) are read in phase B: all but the 2 + NB pieces issued since must have
         // landed before the barrier that ends group 0's MFMAs / group 1's reads of phase A
-        if (wm == 1) { if (more) PP_VM(6); else PP_VM(0); }
+        if (wm == 1) { if (more) PP_VM(2 + NB); else PP_VM(0); }
         PP_BARRIER();
         PP_TILE_STAMP(1);
         PP_LGKM0();
         mfmas(0);
-        if (wm == 0) { if (more) PP_VM(6); else PP_VM(0); }
+        if (wm == 0) { if (more) PP_VM(2 + NB); else PP_VM(0); }
         PP_BARRIER();
         PP_TILE_STAMP(2);
         // phase B: rows 64-127.  The barrier after group 0's MFMAs is the one after group 1's reads: before it both wait for all of
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
 #undef PP_LGKM0
 #undef PP_VM
     PP_STAMP_AT(31);
-    if constexpr (M16) epilogue16<8, 4>(a, acc16, smem, m0 + wm * 128, n0 + wn * 64, b);
+    if constexpr (M16) epilogue16<8, NT>(a, acc16, smem, m0 + wm * 128, n0 + wn * 16 * NT, b);
     else epilogue<TI, TJ>(a, acc, smem, m0 + wm * 128, n0 + wn * 64, b);
     PP_STAMP_AT(29);
 }
@@ -599,43 +602,83 @@ __global__ __launch_bounds__(512) void mlp_layer_pp1_kernel(const Args a, const 
     epilogue<TI, TJ>(a, acc, smem, m0 + wm * 64, n0 + wn * 32 * TJ, b);
 }
 
-// obs [m, k] fp32 -> out [m, ld_out] fp16, normalised and clamped, zero beyond k.  One thread per eight output columns.
+// obs [m, k] fp32 -> out [m, ld_out] fp16, normalised and clamped, zero beyond k.  One thread per two output columns: every load is
+// unconditional (clamped index), so a thread has one round trip to memory, not one per element.
 __global__ __launch_bounds__(256) void prepare_input_kernel(const float* __restrict__ obs, int m, int k, int ld_obs, const float* __restrict__ mean,
                                                             const float* __restrict__ inv_std, float clip, _Float16* __restrict__ out, int ld_out) {
-    const int cpr = ld_out / 8;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int ppr = ld_out / 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)m * cpr) return;
-    const int row = (int)(idx / cpr), c0 = (int)(idx % cpr) * 8;
-    const float* p = obs + (size_t)row * ld_obs + c0;
-    h8 v;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        float g = 0.f;
-        if (c0 + j < k) {
-            g = p[j];
-            if (mean) g = fminf(fmaxf((g - mean[c0 + j]) * inv_std[c0 + j], -clip), clip);
-        }
-        v[j] = (_Float16)g;
+    if (idx >= (long long)m * ppr) return;
+    const int row = (int)(idx / ppr), c0 = (int)(idx % ppr) * 2;
+    const int i0 = c0 < k ? c0 : k - 1, i1 = c0 + 1 < k ? c0 + 1 : k - 1;
+    float g0 = obs[(size_t)row * ld_obs + i0], g1 = obs[(size_t)row * ld_obs + i1];
+    if (mean) {
+        g0 = fminf(fmaxf((g0 - mean[i0]) * inv_std[i0], -clip), clip);
+        g1 = fminf(fmaxf((g1 - mean[i1]) * inv_std[i1], -clip), clip);
     }
-    *reinterpret_cast<h8*>(out + (size_t)row * ld_out + c0) = v;
+    const h2 v = {(_Float16)(c0 < k ? g0 : 0.f), (_Float16)(c0 + 1 < k ? g1 : 0.f)};
+    *reinterpret_cast<h2*>(out + (size_t)row * ld_out + c0) = v;
 }
 
-// one thread per row: a draws, the clamp, the row's negative log-probability
+// 32 lanes per row (lane j draws actions j, j + 32, ...), eight rows per workgroup: the draws of a row are independent; its negative
+// log-probability is a 32-lane butterfly sum
 __global__ __launch_bounds__(256) void sample_actions_kernel(const float* __restrict__ mu, int m, int a, int ld_mu, const float* __restrict__ sigma,
                                                              unsigned long long seed, unsigned long long counter, float lo, float hi,
                                                              float* __restrict__ actions, float* __restrict__ neglogp) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= m) return;
-    float nl = 0.9189385332f * (float)a;                          // 0.5 log(2 pi) per action
-    for (int j = 0; j < a; j++) {
-        const float sg = sigma[j];
-        const float g = pp::dr_gauss(seed, (uint32_t)row, (uint32_t)(counter >> 24), (uint32_t)(counter & 0xFFFFFFu), (uint32_t)j);
-        float x = mu[(size_t)row * ld_mu + j] + sg * g;
-        nl += 0.5f * g * g + logf(sg);
-        if (lo < hi) x = fminf(fmaxf(x, lo), hi);
-        actions[(size_t)row * a + j] = x;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), j0 = threadIdx.x & 31;
+    const bool live = row < m;
+    float nl = 0.f;
+    if (live)
+        for (int j = j0; j < a; j += 32) {
+            const float sg = sigma[j];
+            const float g = pp::dr_gauss(seed, (uint32_t)row, (uint32_t)(counter >> 24), (uint32_t)(counter & 0xFFFFFFu), (uint32_t)j);
+            float x = mu[(size_t)row * ld_mu + j] + sg * g;
+            nl += 0.5f * g * g + logf(sg);
+            if (lo < hi) x = fminf(fmaxf(x, lo), hi);
+            actions[(size_t)row * a + j] = x;
+        }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) nl += __shfl_xor(nl, d, 32);
+    if (live && j0 == 0 && neglogp) neglogp[row] = nl + 0.9189385332f * (float)a;     // + 0.5 log(2 pi) per action
+}
+
+// The heads: out[m, n <= 32] (fp32) = in[m, k] * W[n, k]^T + bias — a skinny layer that is all input traffic (8 MB of features for
+// 0.2 GFLOP).  A workgroup of four waves owns 32 rows; wave w takes the K steps w, w + 4, ... with both MFMA operands loaded straight
+// from global memory as fragments (16 bytes per lane; W is 56 KB and stays in L2), and the four partial 32 x 32 tiles are summed
+// through LDS.  Rows of W beyond n are clamped on load and never stored.
+__global__ __launch_bounds__(256) void mlp_heads_kernel(const Args a) {
+    __shared__ float part[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    const int row = m0 + r < a.m ? m0 + r : a.m - 1, wr = r < a.n ? r : a.n - 1;
+    const _Float16* pa = reinterpret_cast<const _Float16*>(a.in) + (size_t)row * a.lda + h * 8;
+    const _Float16* pw = a.w + (size_t)wr * a.ldw + h * 8;
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    const int ksteps = a.k / 16;
+    int ks = wave;
+    for (; ks + 12 < ksteps; ks += 16) {                         // four K steps of this wave per trip: eight loads in flight
+        h8 fa[4], fb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { fa[u] = *reinterpret_cast<const h8*>(pa + (ks + 4 * u) * 16); fb[u] = *reinterpret_cast<const h8*>(pw + (ks + 4 * u) * 16); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb[u], acc, 0, 0, 0);
     }
-    if (neglogp) neglogp[row] = nl;
+    for (; ks < ksteps; ks += 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(pa + ks * 16), *reinterpret_cast<const h8*>(pw + ks * 16), acc, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) part[wave][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] = acc[reg];
+    __syncthreads();
+    float* out = reinterpret_cast<float*>(a.out);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int idx = tid + 256 * e, orow = idx >> 5, col = idx & 31;
+        if (m0 + orow >= a.m || col >= a.n) continue;
+        float x = part[0][orow][col] + part[1][orow][col] + part[2][orow][col] + part[3][orow][col] + (a.bias ? (float)a.bias[col] : 0.f);
+        if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
+        out[(size_t)(m0 + orow) * a.ldo + col] = x;
+    }
 }
 }  // namespace
 
@@ -652,7 +695,7 @@ extern "C" int ppenv_mlp_prepare_input(const float* obs, int32_t m, int32_t k, i
         ppenv_set_error("ppenv_mlp_prepare_input: NULL pointer or inconsistent sizes (need ld_obs >= k, ld_out >= k and a multiple of 8, out 16-byte aligned, mean and inv_std together)");
         return PPENV_EINVAL;
     }
-    const long long chunks = (long long)m * (ld_out / 8);
+    const long long chunks = (long long)m * (ld_out / 2);
     hipLaunchKernelGGL(prepare_input_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, m, k, ld_obs, mean, inv_std, clip,
                        reinterpret_cast<_Float16*>(out), ld_out);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching prepare_input_kernel failed"); return PPENV_EHIP; }
@@ -665,7 +708,7 @@ extern "C" int ppenv_mlp_sample_actions(const float* mu, int32_t m, int32_t a, i
         ppenv_set_error("ppenv_mlp_sample_actions: NULL pointer or inconsistent sizes (need 0 < a <= 256, ld_mu >= a)");
         return PPENV_EINVAL;
     }
-    hipLaunchKernelGGL(sample_actions_kernel, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, m, a, ld_mu, sigma,
+    hipLaunchKernelGGL(sample_actions_kernel, dim3((m + 7) / 8), dim3(256), 0, (hipStream_t)stream, mu, m, a, ld_mu, sigma,
                        (unsigned long long)seed, (unsigned long long)counter, lo, hi, actions, neglogp);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching sample_actions_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
@@ -693,7 +736,9 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
     // K loop gets denser — and the smaller instruction costs less per flop), but a slower epilogue: only where K >= 1024 amortises it.
     // so: among the LDS-DMA kernels the largest tile that still gives three quarters of the CUs a workgroup, else the smallest; the
     // register-staged kernels for what those cannot take (fp32 input, ragged K, unaligned rows, the narrow heads).
-    // PPENV_MLP_TILE = 128 | 129 | 384 | 385 | 512 | 513 | 514 | 516 forces one.
+    // 517: the 16x16x32 kernel on 256 x 192 tiles, where the 256 x 256 grid is a single partial round that 192-column tiles fill
+    // (2048 -> 1536 at M = 4096: 192 -> 256 workgroups).
+    // PPENV_MLP_TILE = 128 | 129 | 384 | 385 | 512 | 513 | 514 | 516 | 517 forces one.
     const char* env = getenv("PPENV_MLP_TILE");   // read per call: the tests switch it inside one process
     const int forced = env ? atoi(env) : 0;
     auto wgs = [&](int bm, int bn) { return (long long)((L->n + bn - 1) / bn) * ((L->m + bm - 1) / bm) * L->batch; };
@@ -702,7 +747,13 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
         // the first layer (fp32 observations, K = 80 or 313) converts its obs tile once per column tile: wide tiles and a K step of 32
         // (less zero padding of K) — 54 us against 86 (256 x 256 / BK 32 vs 128 x 128 / BK 64, M = 4096, K = 313)
         if (L->in_f32) cfg = (wgs(256, 256) >= 128 && L->n >= 256) ? 385 : 129;
-        else if (L->n >= 128) cfg = wgs(256, 256) >= 192 ? (L->k >= 1024 ? 516 : 512) : wgs(128, 256) >= 192 ? 513 : 514;    // falls back below when the operands do not qualify
+        else if (L->n <= 32 && L->out_f32 && L->batch == 1 && L->k % 16 == 0 && L->lda % 8 == 0 && L->ldw % 8 == 0 &&
+                 (reinterpret_cast<uintptr_t>(L->in) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->w) & 15) == 0) cfg = 600;   // the heads
+        else if (L->n >= 128) {                                                                        // falls back below when the operands do not qualify
+            const long long w256 = wgs(256, 256), w192 = wgs(256, 192);
+            if (w256 >= 192) cfg = (w256 < 256 && w192 > w256 && w192 <= 256) ? 517 : (L->k >= 1024 ? 516 : 512);   // one partial round: 192-column tiles fill it
+            else cfg = wgs(128, 256) >= 192 ? 513 : 514;
+        }
         else cfg = 128;
     }
 #define PP_LAUNCH(WM_, WN_, TI_, TJ_, BK_)                                                                                                    \
@@ -711,17 +762,22 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
         if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);        \
         else hipLaunchKernelGGL((mlp_layer_kernel<false, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);                  \
     } while (0)
-    if (cfg == 512 || cfg == 513 || cfg == 514 || cfg == 516) {
+    if (cfg == 512 || cfg == 513 || cfg == 514 || cfg == 516 || cfg == 517) {
         const bool ok = !L->in_f32 && L->k % 64 == 0 && L->lda % 8 == 0 && L->ldw % 8 == 0 && L->in_stride % 8 == 0 && L->w_stride % 8 == 0 &&
                         (reinterpret_cast<uintptr_t>(L->in) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->w) & 15) == 0;
         if (!ok) cfg = (wgs(256, 256) >= 192 && L->n >= 256) ? 384 : 128;
     }
-    if (cfg == 512) {
+    if (cfg == 600) {
+        hipLaunchKernelGGL(mlp_heads_kernel, dim3((L->m + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (cfg == 512) {
         const int tn = (L->n + 255) / 256, tm = (L->m + 255) / 256;
-        hipLaunchKernelGGL(mlp_layer_pp_kernel<false>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+        hipLaunchKernelGGL((mlp_layer_pp_kernel<false, 4>), dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
     } else if (cfg == 516) {
         const int tn = (L->n + 255) / 256, tm = (L->m + 255) / 256;
-        hipLaunchKernelGGL(mlp_layer_pp_kernel<true>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+        hipLaunchKernelGGL((mlp_layer_pp_kernel<true, 4>), dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+    } else if (cfg == 517) {
+        const int tn = (L->n + 191) / 192, tm = (L->m + 255) / 256;
+        hipLaunchKernelGGL((mlp_layer_pp_kernel<true, 3>), dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
     } else if (cfg == 513) {
         const int tn = (L->n + 255) / 256, tm = (L->m + 127) / 128;
         hipLaunchKernelGGL(mlp_layer_pp1_kernel<2>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);

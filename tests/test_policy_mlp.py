@@ -73,7 +73,7 @@ def test_layer_kernel_exact_on_integer_data():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", [128, 384, 512, 513, 514, 516])
+@pytest.mark.parametrize("tile", [128, 384, 512, 513, 514, 516, 517])
 @pytest.mark.parametrize("out_f32", [False, True])
 def test_every_tile_exact_on_integer_data(tile, out_f32, monkeypatch):
     """The same bit-for-bit check for each tile configuration the launcher can pick (PPENV_MLP_TILE forces one), as the batched
@@ -144,3 +144,21 @@ def test_sample_actions_distribution_clamp_and_neglogp():
     assert float((other - raw).abs().mean()) > 0.1                      # next counter: new draws
     rows = (raw[1:] - mu[1:]) / sigma - (raw[:-1] - mu[:-1]) / sigma    # and rows are not copies of each other
     assert float(rows.abs().mean()) > 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(100, 28, 1024), (4096, 8, 512), (33, 32, 48)])
+def test_heads_kernel_exact_on_integer_data(m, n, k):
+    """The skinny fp32-output layer (mu | value heads: K split over the four waves of a workgroup, partial tiles summed through LDS)
+    bit for bit on small-integer operands, ragged M, N <= 32, K steps that do not divide evenly among the waves."""
+    import torch
+    from isaacgym_amd.policy import layer_forward
+    gen = torch.Generator().manual_seed(m + n)
+    a = torch.randint(-3, 4, (m, k), generator=gen).to(torch.float16)
+    w = torch.randint(-3, 4, (n, k), generator=gen).to(torch.float16)
+    w[:, 1] = (torch.arange(n) % 7 - 3).to(torch.float16)
+    bias = torch.randint(-2, 3, (n,), generator=gen).to(torch.float16)
+    out = torch.full((m, n), -7.0, dtype=torch.float32, device="cuda")
+    layer_forward(out, a.cuda(), w.cuda(), bias.cuda(), elu=False)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), a.float() @ w.float().t() + bias.float())

@@ -14,3 +14,4 @@ grep -v amdgpu.ids $go/mlp_layers.txt > $out/${tag}_mlp_layers.txt
 for v in T4 TN T3; do cp $go/bench_$v.json $out/${tag}_${v}_bench.json; done
 grep -h "passed\|probe excluded" $go/pytest_gpu.log > $out/${tag}_pytest_gpu.txt
 ls $out | grep $tag
+for v in TA TT; do cp "$(ls -t $go/prof_rollout_$v/*/*kernel_stats.csv | head -1)" $out/${tag}_rollout_${v}_kernel_stats.csv; done
