@@ -162,3 +162,27 @@ def test_heads_kernel_exact_on_integer_data(m, n, k):
     layer_forward(out, a.cuda(), w.cuda(), bias.cuda(), elu=False)
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), a.float() @ w.float().t() + bias.float())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", [512, 513, 514, 516, 517])
+def test_dma_tiles_exact_at_full_size_repeated(tile, monkeypatch):
+    """Race screen for the LDS-DMA kernels' own barrier / vmcnt structure: the reference's widest layer (2048 -> 1536, two problems) at
+    M = 4096 with the chip full, 32 K tiles per workgroup, small-integer operands so that every launch must reproduce the fp32 matmul
+    bit for bit — a fragment read that beats its DMA, or a DMA that overwrites a tile still being read, shows up as a wrong element.
+    Ten launches per configuration (tools/gpu_mlp_race_screen.py runs hundreds at several sizes)."""
+    import torch
+    from isaacgym_amd.policy import layer_forward
+    monkeypatch.setenv("PPENV_MLP_TILE", str(tile))
+    m, n, k = 4096, 1536, 2048
+    gen = torch.Generator(device="cuda").manual_seed(tile)
+    a = torch.randint(-1, 2, (m, 2 * k), generator=gen, device="cuda").to(torch.float16)
+    w = torch.randint(-2, 3, (2, n, k), generator=gen, device="cuda").to(torch.float16)
+    bias = torch.randint(-2, 3, (2, n), generator=gen, device="cuda").to(torch.float16)
+    want = torch.cat([a[:, j * k:(j + 1) * k].float() @ w[j].float().t() + bias[j].float() for j in range(2)], dim=1)
+    assert float(want.abs().max()) < 2 ** 24
+    for rep in range(10):
+        out = torch.full((m, 2 * n), -7.0, dtype=torch.float32, device="cuda")
+        layer_forward(out, a, w, bias, elu=False, batch=2, in_stride=k, w_stride=n * k, bias_stride=n, out_stride=n, m=m, n=n, k=k)
+        bad = int((out != want).sum())
+        assert bad == 0, (tile, rep, bad)

@@ -15,3 +15,5 @@ for v in T4 TN T3; do cp $go/bench_$v.json $out/${tag}_${v}_bench.json; done
 grep -h "passed\|probe excluded" $go/pytest_gpu.log > $out/${tag}_pytest_gpu.txt
 ls $out | grep $tag
 for v in TA TT; do cp "$(ls -t $go/prof_rollout_$v/*/*kernel_stats.csv | head -1)" $out/${tag}_rollout_${v}_kernel_stats.csv; done
+cp $go/mlp_pmc_16384_summary.csv $out/${tag}_mlp_pmc_16384_summary.csv; cp $go/mlp_pmc_4096_summary.csv $out/${tag}_mlp_pmc_4096_summary.csv
+cp $go/mlp_race_screen.txt $out/${tag}_mlp_race_screen.txt

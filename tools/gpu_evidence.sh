@@ -16,3 +16,6 @@ python tools/gpu_mlp_layers.py 4096 313 > gpurun_out/mlp_layers.txt 2>&1; python
 for v in T4:8192 TN:16384 T3:16384; do timeout -k 10 300 python bench.py --variant ${v%%:*} --num-envs ${v##*:} --steps 1024 --warmup 128 --no-cpu-baseline > gpurun_out/bench_${v%%:*}.json 2>/dev/null && python -c "
 import json,sys; d=json.load(open('gpurun_out/bench_${v%%:*}.json')); print('${v%%:*}', d['config']['num_envs_per_gpu'], '%.2f us  %.0f M env-steps/s  frac %.4f' % (d['roofline']['avg_kernel_us'], d['value']/1e6, d['roofline']['frac']))"; done
 bash tools/gpu_rollout_prof.sh || exit 1
+MLP_M=16384 MLP_K=80 bash tools/gpu_mlp_pmc.sh > gpurun_out/mlp_pmc_16384.txt 2>&1 && cp gpurun_out/pmc_mlp/summary.csv gpurun_out/mlp_pmc_16384_summary.csv && tail -8 gpurun_out/mlp_pmc_16384.txt
+MLP_M=4096 MLP_K=313 bash tools/gpu_mlp_pmc.sh > gpurun_out/mlp_pmc_4096.txt 2>&1 && cp gpurun_out/pmc_mlp/summary.csv gpurun_out/mlp_pmc_4096_summary.csv && tail -8 gpurun_out/mlp_pmc_4096.txt
+timeout -k 10 500 python tools/gpu_mlp_race_screen.py 200 2>&1 | grep -v amdgpu.ids > gpurun_out/mlp_race_screen.txt; tail -1 gpurun_out/mlp_race_screen.txt
