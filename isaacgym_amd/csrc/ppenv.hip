@@ -563,6 +563,260 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     PP_STAMP_AT(24);
 }
 
+// ---- the single-humanoid step on FOUR waves per 64 envs (round 2; PPENV_STEP_KERNEL=quad) ---------------------------------------------
+//
+// step_kernel_split<T, 1, 0> is two co-critical serial chains: the arm wave (two substeps, then the final-state sweep, the
+// body block of the observation row and its flush) and the ball wave (per substep a kinematics sweep for the collision geometry, then
+// four micro-steps; then reward / reset / the rest of the row, its flush and the state stores).  Here two more waves — on the two SIMDs
+// the launch leaves idle — take what is not inherently on either chain:
+//   wave 2 (geometry): the ball wave's kinematics sweep, from the substep boundary the arm wave publishes, into an LDS slot; and, after
+//           the final sweep, a third of the observation row's body block and of the flush;
+//   wave 3 (auxiliary): the serve draw of a possible reset (a pure function of seed, env id, episode), then a third of the body block
+//           and of the flush.
+// Hand-offs during the substeps are one-way flags as in the two-wave kernel (the consumers wait anyway).  The tail is two workgroup
+// barriers, at which a waiting wave costs no issue slot: X — final sweep done (paddle position, raw body states, final dof state in
+// LDS; the ball wave's substeps done): the three helpers transform the bodies, the ball wave runs the task arithmetic; Y — the whole
+// observation tile is in LDS: waves 0, 2, 3 flush it, the ball wave stores the state.  Nothing reaches HBM before Y, so a hand-off
+// time-out (bounded wait, as elsewhere) simply marks the workgroup dead and nobody stores.
+template <class T>
+__global__ __launch_bounds__(4 * kBlock) void step_kernel_quad(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on,
+                                                               uint32_t* status, int dbg_drop_handoff) {
+    constexpr int A = 1, kGeo = MovingGeom<T>::count(), kHelpFirst = 4;   // bodies 0 .. kHelpFirst-1: arm wave; then wave 2 and wave 3 split the rest
+    constexpr int kMid = kHelpFirst + (NB - kHelpFirst) / 2;
+    __shared__ float s_geom[2][kGeo][kBlock];          // geometry of boundary s in slot s & 1
+    __shared__ float s_obs[kBlock * kObsStride];
+    __shared__ float s_q[kMaxSplitSubsteps][2 * ND][kBlock];
+    __shared__ float s_tau[ND][kBlock];
+    __shared__ float s_paddle[3][kBlock];
+    __shared__ float s_body[6 * (NB - kHelpFirst)][kBlock];   // final-state position / velocity of the bodies the helpers transform
+    __shared__ float s_serve[3][kBlock];
+    __shared__ int s_flag, s_gflag, s_bflag, s_dead;   // arm: boundaries published; geometry: boundaries swept; ball: substeps done; a wait timed out
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int n = K.num_envs;
+    const int base = blockIdx.x * kBlock;
+    const int i = base + lane;
+    const int nvalid = min(kBlock, n - base);
+    const bool active = i < n;
+    const int substeps = K.substeps;
+    const ArmSite& S = K.site[0];
+    if (threadIdx.x == 0) { s_flag = 0; s_gflag = 0; s_bflag = 0; s_dead = 0; }
+    __syncthreads();
+    bool dead = false;
+#define QD_AWAIT(flag, value)                                                                             \
+    do {                                                                                                  \
+        if (!dead && !await(flag, value)) {                                                               \
+            dead = true;                                                                                  \
+            report_fault(status, PPENV_STATUS_HANDOFF_TIMEOUT);                                           \
+            if (lane == 0) __hip_atomic_store(&s_dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        }                                                                                                 \
+    } while (0)
+    // rows of the tile this wave flushes after Y (waves 0, 2, 3 = parts 0, 1, 2)
+    auto flush_part = [&](int part) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        constexpr int per_row = PPENV_NUM_OBS / 4;
+        const int total = nvalid * per_row;
+        for (int k = part * kBlock + lane; k < total; k += 3 * kBlock) {
+            const int r = k / per_row, c = 4 * (k - r * per_row);
+            const float* src = &s_obs[r * kObsStride + c];
+            const f4v val = {src[0], src[1], src[2], src[3]};
+            __builtin_nontemporal_store(val, reinterpret_cast<f4v*>(b.obs + ((size_t)(base + r) * PPENV_NUM_OBS + c)));
+        }
+    };
+    // a helper's share of the body block: bodies J0 .. J1-1 from s_body, the pelvis (the fixed base) from the site constants
+    auto help_bodies = [&](auto j0c, auto j1c) {
+        constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+        if (!active) return;
+        V3 bpos[NB], bvel[NB];
+        BodyState root;
+        static_body<false>(S, root);
+        bpos[0] = root.pos;
+#pragma unroll
+        for (int j = J0; j < J1; j++) {
+            const int o = 6 * (j - kHelpFirst);
+            bpos[j] = mk(s_body[o][lane], s_body[o + 1][lane], s_body[o + 2][lane]);
+            bvel[j] = mk(s_body[o + 3][lane], s_body[o + 4][lane], s_body[o + 5][lane]);
+        }
+        LdsRowStore store{&s_obs[lane * kObsStride]};
+        write_obs_bodies<J0, J1>(bpos, bvel, S.hinv, store);
+    };
+
+    if (wave == 0) {
+        // ------------------------------------------------------------------ arm wave
+        PP_STAMP_AT(0);
+        float q[ND], qd[ND], target[ND], tau[ND];
+        JointSave js[ND];
+        if (active) {
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                q[d] = b.dof_pos[(size_t)d * n + i];
+                qd[d] = b.dof_vel[(size_t)d * n + i];
+                tau[d] = 0.f;
+                target[d] = pd_target(actions[(size_t)i * ND + d], T::drive(d).lower, T::drive(d).upper, K.clip_actions);   // VecTask.step clamp + TT:1008
+            }
+        }
+        PP_STAMP_AT(1);
+        for (int s = 0; s < substeps; s++) {
+            if (active) {
+                NullVisitor nv;   // velocity recursion only
+                fk_sweep<T>(S, q, qd, js, nv);
+                arm_substep<T>(S, js, q, qd, target, K.h, tau);
+#pragma unroll
+                for (int d = 0; d < ND; d++) { s_q[s][d][lane] = q[d]; s_q[s][ND + d][lane] = qd[d]; }
+                if (s + 1 == substeps) {
+#pragma unroll
+                    for (int d = 0; d < ND; d++) s_tau[d][lane] = tau[d];
+                }
+            }
+            if (!dbg_drop_handoff) publish(&s_flag, s + 1);   // (dbg: tests force the partners' time-out path, PPENV_DEBUG_DROP_HANDOFF)
+            PP_STAMP_AT(2 + 2 * s);
+        }
+        BodyState bodies[NB];
+        PP_STAMP_AT(5);
+        if (active) {
+            ArmGeom<T::kShapes> g;
+            BodyVisitor<T, false> bv(g, bodies);
+            fk_sweep<T>(S, q, qd, js, bv);
+            static_body<false>(S, bodies[0]);
+            s_paddle[0][lane] = bodies[NB - 1].pos.x; s_paddle[1][lane] = bodies[NB - 1].pos.y; s_paddle[2][lane] = bodies[NB - 1].pos.z;
+#pragma unroll
+            for (int j = kHelpFirst; j < NB; j++) {
+                const int o = 6 * (j - kHelpFirst);
+                s_body[o][lane] = bodies[j].pos.x; s_body[o + 1][lane] = bodies[j].pos.y; s_body[o + 2][lane] = bodies[j].pos.z;
+                s_body[o + 3][lane] = bodies[j].lin.x; s_body[o + 4][lane] = bodies[j].lin.y; s_body[o + 5][lane] = bodies[j].lin.z;
+            }
+        }
+        PP_STAMP_AT(6);
+        __syncthreads();   // X
+        if (active) {
+            V3 bpos[NB], bvel[NB];
+#pragma unroll
+            for (int j = 0; j < kHelpFirst; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
+            LdsRowStore store{&s_obs[lane * kObsStride]};
+            write_obs_bodies<0, kHelpFirst>(bpos, bvel, S.hinv, store);
+        }
+        __syncthreads();   // Y
+        PP_STAMP_AT(7);
+        if (!s_dead) flush_part(0);
+        PP_STAMP_AT(8);
+        return;
+    }
+    if (wave == 2) {
+        // ------------------------------------------------------------------ geometry wave
+        float qs[ND], qds[ND];
+        ArmGeom<T::kShapes> gg;
+        if (active) {
+#pragma unroll
+            for (int d = 0; d < ND; d++) { qs[d] = b.dof_pos[(size_t)d * n + i]; qds[d] = b.dof_vel[(size_t)d * n + i]; }
+        }
+        for (int s = 0; s < substeps; s++) {
+            if (s > 0) {
+                QD_AWAIT(&s_flag, s);                          // the arm wave has published boundary s
+                if (active) {
+#pragma unroll
+                    for (int d = 0; d < ND; d++) { qs[d] = s_q[s - 1][d][lane]; qds[d] = s_q[s - 1][ND + d][lane]; }
+                }
+            }
+            if (s >= 2) QD_AWAIT(&s_bflag, s - 1);            // the ball is done with the slot's previous content (substep s - 2)
+            if (active && !dead) {
+                JointSave js[ND];        // dead code: only the geometry (points + velocities) of this sweep is used
+                GeomVisitor<T> gv(gg);
+                fk_sweep<T>(S, qs, qds, js, gv);
+                MovingGeom<T>::each(gg, [&](int k, float& v) { s_geom[s & 1][k][lane] = v; });
+            }
+            if (!dead) publish(&s_gflag, s + 1);
+        }
+        __syncthreads();   // X
+        help_bodies(std::integral_constant<int, kHelpFirst>{}, std::integral_constant<int, kMid>{});
+        __syncthreads();   // Y
+        if (!s_dead) flush_part(1);
+        return;
+    }
+    if (wave == 3) {
+        // ------------------------------------------------------------------ auxiliary wave
+        if (active) {
+            // The serve this env gets if it resets at the end of the step: the counter RNG is a pure function of (seed, env id, episode + 1)
+            V3 sv = serve_on ? mk(b.serve[i], b.serve[(size_t)n + i], b.serve[2 * (size_t)n + i])
+                             : serve_velocity(K, (uint32_t)(K.env_id_offset + i), b.episode[i] + 1u);
+            s_serve[0][lane] = sv.x; s_serve[1][lane] = sv.y; s_serve[2][lane] = sv.z;
+        }
+        __syncthreads();   // X
+        help_bodies(std::integral_constant<int, kMid>{}, std::integral_constant<int, NB>{});
+        __syncthreads();   // Y
+        if (!s_dead) flush_part(2);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- ball wave
+    PP_STAMP_AT(16);
+    EnvStateT<A> st;
+    float rew[A], pre_vx = 0.f;
+    long long reset = 0;
+    V3 next_serve = mk(0, 0, 0);
+    ArmGeom<T::kShapes> g[A];
+    V3 bound[A];
+    rew[0] = 0.f;
+    if (active) {
+        float bl[13];
+#pragma unroll
+        for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
+        st.ball.p = mk(bl[0], bl[1], bl[2]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) st.ball.quat[k] = bl[3 + k];
+        st.ball.v = mk(bl[7], bl[8], bl[9]);
+        st.ball.w = mk(bl[10], bl[11], bl[12]);
+        st.progress = b.progress[(size_t)i];
+        st.flags[0] = b.flags[i];
+        st.episode = b.episode[i];
+        pre_vx = st.ball.v.x;   // TT:1020
+        static_geometry<T>(S, g[0]);
+        bound[0] = ld3(S.bound_center);
+    }
+    PP_STAMP_AT(17);
+    for (int s = 0; s < substeps; s++) {
+        QD_AWAIT(&s_gflag, s + 1);                             // the geometry wave has boundary s in LDS
+        PP_STAMP_AT(18 + 2 * s);
+        if (active && !dead) {
+            MovingGeom<T>::each(g[0], [&](int k, float& v) { v = s_geom[s & 1][k][lane]; });
+            ball_substep<T, A>(K, st.ball, g, bound);
+        }
+        if (!dead) publish(&s_bflag, s + 1);
+        PP_STAMP_AT(19 + 2 * s);
+    }
+    QD_AWAIT(&s_flag, substeps);                               // (only fails when the arm wave withheld a publish: it then never reaches X either way)
+    __syncthreads();   // X: final dof state, drive torques, paddle position, serve
+    if (active && !dead && !s_dead) {
+        BodyState bodies[NB];   // the task part reads the pelvis (row 0) and the paddle (row 9) only
+        LdsRowStore stores[A];
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            st.q[d] = s_q[substeps - 1][d][lane];
+            st.qd[d] = s_q[substeps - 1][ND + d][lane];
+            st.dof_force[d] = s_tau[d][lane];
+        }
+        static_body<false>(S, bodies[0]);
+        bodies[NB - 1].pos = mk(s_paddle[0][lane], s_paddle[1][lane], s_paddle[2][lane]);
+        stores[0].row = &s_obs[lane * kObsStride];
+        next_serve = mk(s_serve[0][lane], s_serve[1][lane], s_serve[2][lane]);
+        post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, &next_serve, rew, reset, stores);
+    }
+    PP_STAMP_AT(22);
+    __syncthreads();   // Y
+    PP_STAMP_AT(23);
+    if (active && !s_dead) {   // st.q / st.qd already show the reset state where the env reset (TN keeps its dof state)
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            st_state(&b.dof_pos[(size_t)d * n + i], st.q[d]);
+            st_state(&b.dof_vel[(size_t)d * n + i], st.qd[d]);
+            st_state(&b.dof_force[(size_t)d * n + i], st.dof_force[d]);
+        }
+        store_ball(b, n, i, st.ball);
+        store_task<A>(b, n, i, st, rew, reset);
+    }
+    PP_STAMP_AT(24);
+#undef QD_AWAIT
+}
+
 // create (mode 0: creation is episode 0) / reset_all (mode 1: next episode): state as after
 // _create_envs (TT:512-643) plus the observations of that state
 template <class T, int A>
@@ -1022,8 +1276,10 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
         // 65536 19.6 / 22.8, 131072 35.3 / 41.5): it needs 187 VGPRs (two waves per SIMD) against 256 + 79 AGPRs.
         const char* k = getenv("PPENV_STEP_KERNEL");
         e->split = k ? (strcmp(k, "fused") != 0) : 1;
+        if (k && strcmp(k, "quad") == 0) e->split = 3;          // four waves per 64 envs (single-humanoid variants)
         if (cfg->substeps > kMaxSplitSubsteps) e->split = 0;   // one LDS hand-off slot per substep boundary
-        if (e->agents == 2) e->split = (k && strcmp(k, "split3") == 0) ? 1 : 2;   // 4-actor: arm waves sweep the geometry (default), or the ball wave
+        if (e->agents == 2) e->split = (k && strcmp(k, "split3") == 0) ? 1 : 2;
+        else if (e->split == 3 && cfg->substeps > kMaxSplitSubsteps) e->split = 0;   // 4-actor: arm waves sweep the geometry (default), or the ball wave
     }
     e->arena = nullptr;
     e->owns_arena = false;
@@ -1119,6 +1375,9 @@ int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->agents == 2)
         hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+    else if (e->split == 3)
+        hipLaunchKernelGGL((step_kernel_quad<ModelG1>), dim3(grid_for(e->cfg.num_envs)), dim3(4 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->split)
         hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,

@@ -341,24 +341,24 @@ __global__ __launch_bounds__(64 * WM * WN) void mlp_layer_kernel(const Args a) {
 // has passed.  Barriers are raw s_barrier: a __syncthreads() would drain the DMAs at every phase.
 //
 // Needs fp16 input, K a multiple of 64 and 16-byte aligned rows; rows beyond M / N are clamped on load and never stored.
-// Diagnostic builds only (-DPP_STAMP, tools/gpu_mlp_stamps.py): shader-clock stamps per workgroup and wave.
-#if defined(PP_STAMP)
-__device__ unsigned long long pp_stamp_buf[256 * 8 * 32];
-#define PP_STAMP_AT(k)                                                                                \
+// Diagnostic builds only (-DPPM_STAMP, tools/gpu_mlp_stamps.py): shader-clock stamps per workgroup and wave.
+#if defined(PPM_STAMP)
+__device__ unsigned long long mlp_stamp_buf[256 * 8 * 32];
+#define PPM_STAMP_AT(k)                                                                                \
     do {                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         unsigned long long t_;                                                                        \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");              \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        if (lane == 0 && blockIdx.x < 256 && blockIdx.y == 0) pp_stamp_buf[(blockIdx.x * 8 + wave) * 32 + (k)] = t_; \
+        if (lane == 0 && blockIdx.x < 256 && blockIdx.y == 0) mlp_stamp_buf[(blockIdx.x * 8 + wave) * 32 + (k)] = t_; \
     } while (0)
 #else
-#define PP_STAMP_AT(k) do { } while (0)
+#define PPM_STAMP_AT(k) do { } while (0)
 #endif
 #ifndef PP_EXP
 #define PP_EXP 0          // timing experiments (diagnostic builds): 1 no fragment reads, 2 no DMA, 4 no barriers in the K loop — results are wrong
 #endif
-#define PP_TILE_STAMP(j) do { if (t == 8) PP_STAMP_AT(j); else if (t == 9) PP_STAMP_AT(9 + (j)); } while (0)
+#define PPM_TILE_STAMP(j) do { if (t == 8) PPM_STAMP_AT(j); else if (t == 9) PPM_STAMP_AT(9 + (j)); } while (0)
 
 // M16: the same tile on v_mfma_f32_16x16x32_f16 (8 x 4 tiles of 16 x 16 per wave, operands swapped so the accumulators hold out^T, see
 // epilogue16) instead of v_mfma_f32_32x32x16_f16 (4 x 2 tiles of 32 x 32): same fragment reads, same flops, half the K depth per
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
 #define PP_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
 
     const int ktiles = a.k / BK;
-    PP_STAMP_AT(30);
+    PPM_STAMP_AT(30);
     stage_a(0, 0, 0); stage_a(0, 0, 2);                            // the order of every tile: what phase A reads first, A rows 64-127 last
     stage_b(0, 0);
     stage_a(0, 0, 1); stage_a(0, 0, 3);
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
         const bool more = t + 1 < ktiles && !(PP_EXP & 2);
         tcur = t;
         const int nbuf = (t + 1) & 1, nk0 = (t + 1) * BK;
-        PP_TILE_STAMP(0);
+        PPM_TILE_STAMP(0);
         // phase A: rows 0-63 of the wave's tile
         read_a(tile, 0);
         read_b(tile);
@@ -481,33 +481,33 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
         // landed before the barrier that ends group 0's MFMAs / group 1's reads of phase A
         if (wm == 1) { if (more) PP_VM(2 + NB); else PP_VM(0); }
         PP_BARRIER();
-        PP_TILE_STAMP(1);
+        PPM_TILE_STAMP(1);
         PP_LGKM0();
         mfmas(0);
         if (wm == 0) { if (more) PP_VM(2 + NB); else PP_VM(0); }
         PP_BARRIER();
-        PP_TILE_STAMP(2);
+        PPM_TILE_STAMP(2);
         // phase B: rows 64-127.  The barrier after group 0's MFMAs is the one after group 1's reads: before it both wait for all of
         // the next tile but its last two pieces.
         read_a(tile, 1);
         if (more) { stage_a(nbuf, nk0, 1); stage_a(nbuf, nk0, 3); }
         if (wm == 1) PP_VM(2);
         PP_BARRIER();
-        PP_TILE_STAMP(3);
+        PPM_TILE_STAMP(3);
         PP_LGKM0();
         mfmas(1);
         if (wm == 0) PP_VM(2);
         PP_BARRIER();
-        PP_TILE_STAMP(4);
+        PPM_TILE_STAMP(4);
     }
     if (wm == 0) PP_BARRIER();                                     // as many barriers as group 1
 #undef PP_BARRIER
 #undef PP_LGKM0
 #undef PP_VM
-    PP_STAMP_AT(31);
+    PPM_STAMP_AT(31);
     if constexpr (M16) epilogue16<8, NT>(a, acc16, smem, m0 + wm * 128, n0 + wn * 16 * NT, b);
     else epilogue<TI, TJ>(a, acc, smem, m0 + wm * 128, n0 + wn * 64, b);
-    PP_STAMP_AT(29);
+    PPM_STAMP_AT(29);
 }
 
 // ---- the same scheme on 128-row tiles, for the layers whose 256 x 256 grid would leave CUs idle (M = 4096: SURVEY.md §8(f)) ----
@@ -682,10 +682,10 @@ __global__ __launch_bounds__(256) void mlp_heads_kernel(const Args a) {
 }
 }  // namespace
 
-#if defined(PP_STAMP)
+#if defined(PPM_STAMP)
 extern "C" int ppenv_mlp_debug_read_stamps(unsigned long long* dst, size_t count) {
     if (hipDeviceSynchronize() != hipSuccess) return PPENV_EHIP;
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pp_stamp_buf), count * sizeof(unsigned long long)) == hipSuccess ? 0 : PPENV_EHIP;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mlp_stamp_buf), count * sizeof(unsigned long long)) == hipSuccess ? 0 : PPENV_EHIP;
 }
 #endif
 

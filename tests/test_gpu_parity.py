@@ -97,9 +97,11 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant)
     env.close()
 
 
-@pytest.mark.parametrize("schedule,n", [("split", 1000), ("fused", 1000), ("fused", 130), ("split", 63), ("split", 1), ("fused", 1)])
+@pytest.mark.parametrize("schedule,n", [("split", 1000), ("fused", 1000), ("fused", 130), ("split", 63), ("split", 1), ("fused", 1),
+                                        ("quad", 1000), ("quad", 63), ("quad", 1)])
 def test_both_schedules_on_ragged_sizes(torch_cuda, oracle_lib, monkeypatch, schedule, n):
-    """The two-wave and the one-wave step kernels run the same arithmetic; sizes that are not a multiple of 64."""
+    """The two-wave (default), the one-wave and the four-wave (round-2 experiment, DESIGN.md §9) step kernels run the same arithmetic;
+    sizes that are not a multiple of 64."""
     torch = torch_cuda
     monkeypatch.setenv("PPENV_STEP_KERNEL", schedule)
     cfg = scene.build_config("TT", num_envs=n, seed=21)
@@ -127,21 +129,23 @@ def test_schedules_agree_step_by_step(torch_cuda, monkeypatch):
     torch = torch_cuda
     n = 4096
     envs = {}
-    for schedule in ("split", "fused"):
+    for schedule in ("split", "fused", "quad"):
         monkeypatch.setenv("PPENV_STEP_KERNEL", schedule)
         envs[schedule] = make_env(scene.build_config("TN", num_envs=n, seed=2))
     gen = torch.Generator(device="cuda").manual_seed(1)
     for t in range(100):
         a = torch.rand(n, 7, device="cuda", generator=gen) * 2 - 1
         envs["fused"].set_state(envs["split"].get_state())
+        envs["quad"].set_state(envs["split"].get_state())
         for e in envs.values():
             e.step(a)
-        for name in ("reset_buf", "progress_buf", "flags", "episode"):
-            assert torch.equal(getattr(envs["split"], name), getattr(envs["fused"], name)), (name, t)
-        # rew: alpha = 1000 (TN) times the ball-velocity agreement of ~1e-4 m/s right after a paddle hit
-        for name, atol in (("obs_buf", 2e-4), ("rew_buf", 1e-1), ("dof_pos", 1e-5), ("dof_vel", 1e-3), ("ball", 5e-3)):
-            x, y = getattr(envs["split"], name), getattr(envs["fused"], name)
-            assert torch.allclose(x, y, rtol=1e-5, atol=atol), (name, t, float((x - y).abs().max()))
+        for other in ("fused", "quad"):
+            for name in ("reset_buf", "progress_buf", "flags", "episode"):
+                assert torch.equal(getattr(envs["split"], name), getattr(envs[other], name)), (other, name, t)
+            # rew: alpha = 1000 (TN) times the ball-velocity agreement of ~1e-4 m/s right after a paddle hit
+            for name, atol in (("obs_buf", 2e-4), ("rew_buf", 1e-1), ("dof_pos", 1e-5), ("dof_vel", 1e-3), ("ball", 5e-3)):
+                x, y = getattr(envs["split"], name), getattr(envs[other], name)
+                assert torch.allclose(x, y, rtol=1e-5, atol=atol), (other, name, t, float((x - y).abs().max()))
     for e in envs.values():
         e.close()
 
@@ -452,12 +456,14 @@ def test_vectask_reset_idx_and_control_frequency(torch_cuda):
     np.testing.assert_allclose(dx, 2 * 0.0083 * ball0[7].cpu().numpy(), rtol=1e-3)
 
 
-def test_handoff_timeout_is_reported_not_stored(torch_cuda, monkeypatch):
+@pytest.mark.parametrize("schedule", ["split", "quad"])
+def test_handoff_timeout_is_reported_not_stored(torch_cuda, monkeypatch, schedule):
     """A wave of the multi-wave step kernel that never receives its partner's LDS hand-off must not store plausible garbage:
     it sets the handle's status word and every later call fails with PPENV_EDEVICE.  PPENV_DEBUG_DROP_HANDOFF withholds the
     arm wave's last hand-off so that the ball wave's bounded wait runs out."""
     torch = torch_cuda
     from isaacgym_amd import _lib
+    monkeypatch.setenv("PPENV_STEP_KERNEL", schedule)
     monkeypatch.setenv("PPENV_DEBUG_DROP_HANDOFF", "1")
     env = make_env(scene.build_config("TT", num_envs=64, seed=2))
     monkeypatch.delenv("PPENV_DEBUG_DROP_HANDOFF")

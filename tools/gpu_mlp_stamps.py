@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: in-kernel timeline of the 256 x 256 policy-layer kernel (PP_STAMP build): cycles per barrier interval of K tiles 8 and 9,
+"""Diagnostic: in-kernel timeline of the 256 x 256 policy-layer kernel (PPM_STAMP build): cycles per barrier interval of K tiles 8 and 9,
 per wave group.  Run on the GPU box."""
 import ctypes as C
 import os
@@ -14,7 +14,7 @@ from isaacgym_amd import _lib  # noqa: E402
 lib = os.path.join(ROOT, "gpurun_out", "libppenv_ppstamp.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 exp = os.environ.get("PP_EXP", "0")      # timing experiments, see ppenv_policy.hip
-subprocess.run(["hipcc"] + _lib.HIPCC_FLAGS + ["-DPP_STAMP=1", "-DPP_EXP=" + exp, "-o", lib] + _lib.SOURCES, check=True)
+subprocess.run(["hipcc"] + _lib.HIPCC_FLAGS + ["-DPPM_STAMP=1", "-DPP_EXP=" + exp, "-o", lib] + _lib.SOURCES, check=True)
 os.environ["PPENV_LIB"] = lib
 _lib.LIB_PATH = lib
 os.environ["PPENV_MLP_TILE"] = "512"

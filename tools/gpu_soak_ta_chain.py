@@ -66,8 +66,13 @@ for seed in seeds:
         keep &= ~sensitive(act, root0, dof0, root1, dof1, rng)
         excluded += int((~keep).sum())
         try:
-            assert np.array_equal(env.reset_buf.cpu().numpy(), reset) and np.array_equal(env.progress_buf.cpu().numpy(), progress)
-            assert np.array_equal(env.state.flags.cpu().numpy().view(np.uint32)[keep], flags[keep])
+            g_reset, g_prog, g_flags = env.reset_buf.cpu().numpy(), env.progress_buf.cpu().numpy(), env.state.flags.cpu().numpy().view(np.uint32)
+            for what, gv, ov in (("reset_buf", g_reset, reset), ("progress_buf", g_prog, progress), ("flags", g_flags, flags)):
+                diff = np.nonzero(gv != ov)[0]
+                # a discrete decision may legitimately differ in an env set aside as sensitive (its continuous state sits on a threshold)
+                assert not keep[diff].any(), f"seed {seed} step {t}: {what} differs in retained envs {diff[keep[diff]][:8]} (and {int((~keep[diff]).sum())} set-aside ones)"
+                if diff.size:
+                    print(f"seed {seed} step {t}: {what} differs in {diff.size} set-aside env(s) {diff[:4]} — not counted", flush=True)
             check_step((env.root_states.cpu().numpy()[keep], env.dof_states.cpu().numpy()[keep], g_rb[keep][:, :40], env.dof_force_tensor.cpu().numpy()[keep]),
                        (root[keep], dof[keep], rb[keep][:, :40], frc[keep]), f"seed {seed} step {t}")
             assert_close(np.delete(env.obs_buf.cpu().numpy(), 120, axis=1)[keep], np.delete(obs, 120, axis=1)[keep], f"seed {seed} step {t}: obs", atol=oa)

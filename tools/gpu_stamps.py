@@ -14,7 +14,7 @@ SRC = os.environ.get("PPENV_STAMP_SRC", os.path.join(ROOT, "isaacgym_amd", "csrc
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-fno-signed-zeros", "-ffinite-math-only",
                 "-fPIC", "-shared", "-DPP_STAMP=1", *os.environ.get("PPENV_STAMP_DEFS", "").split(), "-I", os.path.join(ROOT, "include"), "-o", lib, os.path.join(SRC, "ppenv.hip"), os.path.join(SRC, "ppenv_ta.hip"),
-                os.path.join(SRC, "ppenv_ta_sim.hip")], check=True)
+                os.path.join(SRC, "ppenv_ta_sim.hip"), os.path.join(SRC, "ppenv_ta_chain.hip"), os.path.join(SRC, "ppenv_policy.hip")], check=True)
 os.environ["PPENV_LIB"] = lib
 import torch  # noqa: E402
 from isaacgym_amd import _lib, scene  # noqa: E402
@@ -46,6 +46,9 @@ else:
     t0 = np.minimum(t[:, 0], t[:, 16])
     arm = {1: "arm: loads + targets", 2: "arm: substep 1 (vel sweep + ABA) + publish", 4: "arm: substep 2 + publish",
            5: "arm: FK of final state + publish paddle", 6: "arm: body obs", 7: "arm: final barrier wait"}
+    if os.environ.get("PPENV_STEP_KERNEL") == "quad":
+        arm = {1: "arm: loads + targets", 2: "arm: substep 1 (vel sweep + ABA) + publish", 4: "arm: substep 2 + publish", 5: "arm: (serve draw moved)",
+               6: "arm: FK of final state + bodies to LDS", 7: "arm: X, bodies 0-3, Y", 8: "arm: flush share"}
     ball = {17: "ball: loads + next serve", 18: "ball: (no wait)", 19: "ball: FK + substep 1", 20: "ball: wait for boundary 1",
             21: "ball: FK + substep 2", 22: "ball: wait final + reward/reset/obs tail", 23: "ball: final barrier wait", 24: "ball: flush + stores"}
     tot = np.median(t[:, 24] - t0)
