@@ -476,6 +476,12 @@ int ppenv_ta_sim_device(const ppenv_ta_sim* sim);
  * 0 = one lane per env (any tree).  PPENV_TA_KERNEL=chain|quad|lane forces one. */
 uint32_t ppenv_ta_sim_status(const ppenv_ta_sim* sim);
 int ppenv_ta_sim_kernel(const ppenv_ta_sim* sim);
+/* The policy's first-layer input written by ppenv_ta_step itself (observation normalisation fused into the step
+ * kernel): next to obs_buf the chain-wave kernel stores out[N, ld_out] fp16 = clamp((obs - mean) * inv_std, -clip, clip), columns
+ * 313 .. ld_out-1 zero — bit for bit what ppenv_mlp_prepare_input (ppenv_policy.h) makes of obs_buf, without that launch.  mean /
+ * inv_std: [313] fp32 device arrays read at every step (rl_games' RunningMeanStd in eval mode); ld_out even, >= 313 (320 for the
+ * LDS-DMA layer kernels).  out NULL switches it off.  Only with ppenv_ta_sim_kernel() == 2. */
+int ppenv_ta_sim_set_policy_input(ppenv_ta_sim* sim, const float* mean_dev, const float* inv_std_dev, float clip, void* out_f16_dev, int32_t ld_out);
 /* Host-only (no GPU call): 1 when `model` equals, bit for bit, the tables compiled into the chain-wave kernel
  * (csrc/ppenv_model_g1_ta.h, generated by isaacgym_amd/modelgen_ta.py), 0 when it differs, < 0 on an invalid model. */
 int ppenv_ta_model_is_compiled(const ppenv_config* scene, const ppenv_ta_model* model);

@@ -26,6 +26,12 @@ struct TAChainArgs {
     long long* reset;
     uint32_t* scratch;            // one word, zero between launches: bit 0 = some env reset in this launch, bits 1.. = workgroups done
     uint32_t* status;             // host-visible status word of the handle (bit 0: a hand-off timed out)
+    // optional second copy of the observation rows, as the policy's first layer wants them (ppenv_ta_sim_set_policy_input; NULL: off)
+    const float* pin_mean;        // [313]
+    const float* pin_inv_std;     // [313]
+    float pin_clip;
+    unsigned short* pin_out;      // fp16 [N, pin_ld], columns >= 313 zero
+    int pin_ld;
 };
 
 // does the run-time model equal, bit for bit, the tables the chain-wave kernel was compiled from?

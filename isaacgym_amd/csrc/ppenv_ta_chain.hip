@@ -909,7 +909,37 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                     __builtin_nontemporal_store(v, dr + i);
                 }
             }
+            if (a.pin_out) {
+                // The policy's input straight from the tile: clamp((obs - mean) * inv_std, +-clip) as fp16, rows
+                // padded with zeros to pin_ld — the same arithmetic as ppenv_mlp_prepare_input, which this replaces.  Two columns per
+                // lane: 256 contiguous bytes per wave-store; the statistics are L1 hits after the first row.
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const int ppr = a.pin_ld >> 1, total = kE * ppr;
+                _Float16* dst = reinterpret_cast<_Float16*>(a.pin_out) + (size_t)e0 * a.pin_ld;
+                for (int i = tid; i < total; i += kThreads) {
+                    const int ee = i / ppr, c = 2 * (i - ee * ppr);
+                    const int c0 = c < PPENV_TA_NUM_OBS ? c : PPENV_TA_NUM_OBS - 1, c1 = c + 1 < PPENV_TA_NUM_OBS ? c + 1 : PPENV_TA_NUM_OBS - 1;
+                    float g0 = (S.u.obs[ee * PPENV_TA_NUM_OBS + c0] - a.pin_mean[c0]) * a.pin_inv_std[c0];
+                    float g1 = (S.u.obs[ee * PPENV_TA_NUM_OBS + c1] - a.pin_mean[c1]) * a.pin_inv_std[c1];
+                    g0 = fminf(fmaxf(g0, -a.pin_clip), a.pin_clip); g1 = fminf(fmaxf(g1, -a.pin_clip), a.pin_clip);
+                    const h2 v = {(_Float16)(c < PPENV_TA_NUM_OBS ? g0 : 0.f), (_Float16)(c + 1 < PPENV_TA_NUM_OBS ? g1 : 0.f)};
+                    *reinterpret_cast<h2*>(dst + (size_t)ee * a.pin_ld + c) = v;
+                }
+            }
         } else {
+            if (a.pin_out) {   // ragged last block: the same, row by row
+                const int ppr = a.pin_ld >> 1;
+                _Float16* dst = reinterpret_cast<_Float16*>(a.pin_out) + (size_t)e0 * a.pin_ld;
+                for (int i = tid; i < nvalid * ppr; i += kThreads) {
+                    const int ee = i / ppr, c = 2 * (i - ee * ppr);
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        float g = 0.f;
+                        if (c + k < PPENV_TA_NUM_OBS) g = fminf(fmaxf((S.u.obs[ee * PPENV_TA_NUM_OBS + c + k] - a.pin_mean[c + k]) * a.pin_inv_std[c + k], -a.pin_clip), a.pin_clip);
+                        dst[(size_t)ee * a.pin_ld + c + k] = (_Float16)g;
+                    }
+                }
+            }
             const int nvec = nvalid * PPENV_TA_NUM_OBS / 4, rem = nvalid * PPENV_TA_NUM_OBS - 4 * nvec;   // a ragged block need not be a multiple of 4
             for (int t = tid; t < nvec; t += kThreads)
                 __builtin_nontemporal_store(reinterpret_cast<const f4v*>(S.u.obs)[t], reinterpret_cast<f4v*>(dobs) + t);

@@ -536,6 +536,11 @@ struct ppenv_ta_sim {
     int chain;    // 1: ppenv_ta_step runs the chain-wave kernel (ppenv_ta_chain.hip: one lane per env, one wave per limb; the compiled G1 model only)
     uint32_t* status_host;   // PPENV_STATUS_* bits, pinned host memory the kernels write through (cf. ppenv::status_host)
     uint32_t* status_dev;
+    const float* pin_mean;   // ppenv_ta_sim_set_policy_input (chain-wave kernel only); pin_out NULL: off
+    const float* pin_inv_std;
+    float pin_clip;
+    unsigned short* pin_out;
+    int pin_ld;
 };
 
 namespace {
@@ -554,6 +559,18 @@ extern "C" {
 
 int ppenv_ta_sim_device(const ppenv_ta_sim* s) { return s ? s->device : -1; }
 uint32_t ppenv_ta_sim_status(const ppenv_ta_sim* s) { return s ? *(volatile uint32_t*)s->status_host : 0u; }
+/* the policy's first-layer input written by ppenv_ta_step itself (chain-wave kernel): out NULL switches it off */
+int ppenv_ta_sim_set_policy_input(ppenv_ta_sim* s, const float* mean_dev, const float* inv_std_dev, float clip, void* out_f16_dev, int32_t ld_out) {
+    if (!s) { ppenv_set_error("ppenv_ta_sim_set_policy_input: NULL handle"); return PPENV_EINVAL; }
+    if (!out_f16_dev) { s->pin_out = nullptr; return PPENV_OK; }
+    if (!s->chain) { ppenv_set_error("ppenv_ta_sim_set_policy_input: only the chain-wave kernel writes the policy input (ppenv_ta_sim_kernel() == 2)"); return PPENV_EINVAL; }
+    if (!mean_dev || !inv_std_dev || ld_out < PPENV_TA_NUM_OBS || (ld_out & 1) || (reinterpret_cast<uintptr_t>(out_f16_dev) & 3)) {
+        ppenv_set_error("ppenv_ta_sim_set_policy_input: need mean, inv_std, an even ld_out >= 313 and a 4-byte aligned output");
+        return PPENV_EINVAL;
+    }
+    s->pin_mean = mean_dev; s->pin_inv_std = inv_std_dev; s->pin_clip = clip; s->pin_out = reinterpret_cast<unsigned short*>(out_f16_dev); s->pin_ld = ld_out;
+    return PPENV_OK;
+}
 /* which kernel ppenv_ta_step launches: 2 chain-wave, 1 quad, 0 one lane per env */
 int ppenv_ta_sim_kernel(const ppenv_ta_sim* s) { return s ? (s->chain ? 2 : (s->quad ? 1 : 0)) : -1; }
 /* host-only (no GPU call): 1 when the model equals, bit for bit, the tables compiled into the chain-wave kernel; 0 when it differs; < 0 on a bad model */
@@ -602,6 +619,7 @@ int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, 
         }
     }
     s->status_host = s->status_dev = nullptr;
+    s->pin_mean = s->pin_inv_std = nullptr; s->pin_out = nullptr; s->pin_clip = 0.f; s->pin_ld = 0;
     // the handle lives on scene->device_id when that names a visible GPU (the caller's current device otherwise)
     int ndev = 0;
     s->device = -1;
@@ -679,7 +697,8 @@ int ppenv_ta_step(ppenv_ta_sim* s, const ppenv_ta_params* params, const float* a
     if (int rc = ta_use_device(s)) return rc;
     if (s->chain) {   // one lane per env, one wave per limb; rigid_body_states only on request
         TAChainArgs a{*params, s->devK, actions_dev, initial_rb_states_dev, root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev,
-                      reset_override_dev, flags_dev, episode_dev, (long long*)progress_dev, obs_dev, rew_dev, (long long*)reset_dev, scratch_any_reset_dev, s->status_dev};
+                      reset_override_dev, flags_dev, episode_dev, (long long*)progress_dev, obs_dev, rew_dev, (long long*)reset_dev, scratch_any_reset_dev, s->status_dev,
+                      s->pin_mean, s->pin_inv_std, s->pin_clip, s->pin_out, s->pin_ld};
         return ta_chain_launch(s->host.sc, a, stream);
     }
     if (!rb_states_dev) { ppenv_set_error("ppenv_ta_step: rb_states may only be NULL with the chain-wave kernel (the compiled G1 model)"); return PPENV_EINVAL; }

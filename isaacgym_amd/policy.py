@@ -138,10 +138,21 @@ class NativeMLP:
         self.x16 = None if self.fuse_input else z(self.w[0].shape[-1], torch.float16)   # normalised observations, K padded like the weights
         self._rows = m
 
-    def forward(self, obs):
-        """obs: fp32 [M, num_obs] on this device (the env's obs_buf, read in place) -> (mu [M, A], value [M, 1]) fp32 (buffers reused)."""
+    def attach_env(self, env):
+        """Let the env's step kernel write this network's first-layer input (normalised, clamped, padded fp16 rows) next to obs_buf:
+        `forward(obs, prepared=True)` then skips the normalise-and-pad launch.  Needs an env with `set_policy_input` (TAEnv on the
+        chain-wave kernel) and statistics (`set_normalization`); the statistics tensors are read by every later step."""
+        assert not self.fuse_input and self.mean is not None
+        if env.num_envs != self._rows:
+            self._alloc(env.num_envs)
+        env.set_policy_input(self.x16, self.mean, self.inv_std, self.clip)
+
+    def forward(self, obs, prepared=False):
+        """obs: fp32 [M, num_obs] on this device (the env's obs_buf, read in place) -> (mu [M, A], value [M, 1]) fp32 (buffers reused).
+        prepared: the first-layer input is already in self.x16 (attach_env: written by the env's step kernel)."""
         m = obs.shape[0]
         if m != self._rows:
+            assert not prepared
             self._alloc(m)
         assert obs.dtype == torch.float32 and obs.device == self.device and obs.stride(1) == 1 and obs.shape[1] == self.num_obs
         u = self.units
@@ -150,7 +161,8 @@ class NativeMLP:
         if self.fuse_input:
             layer_forward(self.h[0], obs, w0, self.b[0].view(-1), elu=True, mean=self.mean, inv_std=self.inv_std, clip=self.clip, k=self.num_obs)
         else:
-            prepare_input(self.x16, obs, self.mean, self.inv_std, self.clip)
+            if not prepared:
+                prepare_input(self.x16, obs, self.mean, self.inv_std, self.clip)
             layer_forward(self.h[0], self.x16, w0, self.b[0].view(-1), elu=True)
         for i in range(1, len(u)):
             layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],

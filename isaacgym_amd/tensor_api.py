@@ -117,6 +117,18 @@ class TASim:
         if ov is not None:
             torch.cuda.current_stream(self.device).synchronize()
 
+    def set_policy_input(self, out=None, mean=None, inv_std=None, clip=5.0):
+        """ppenv_ta_sim_set_policy_input: from the next `step` on the chain-wave kernel also writes out [N, ld] fp16 =
+        clamp((obs - mean) * inv_std, +-clip), zero beyond column 312 (what policy.prepare_input makes of obs_buf).  out None: off.
+        The tensors are read / written by every later step: the caller keeps them alive."""
+        if out is None:
+            _lib.check(self.L.ppenv_ta_sim_set_policy_input(self.h, None, None, 0.0, None, 0))
+            self._pin = None
+            return
+        assert out.dtype == torch.float16 and out.shape[0] == self.num_envs and out.stride(1) == 1 and mean.dtype == inv_std.dtype == torch.float32
+        self._pin = (out, mean, inv_std)
+        _lib.check(self.L.ppenv_ta_sim_set_policy_input(self.h, mean.data_ptr(), inv_std.data_ptr(), float(clip), out.data_ptr(), out.stride(0)))
+
     def pd_targets(self, actions):
         """pre_physics_step's PD targets (TA:1131) for actions [N,27]."""
         a = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, 27).contiguous()
@@ -196,6 +208,10 @@ class TAEnv:
         if not self.materialize_rb:
             self.sim.forward_kinematics(self.root_states, self.dof_states, self._rb_states)
         return self._rb_states
+
+    def set_policy_input(self, out=None, mean=None, inv_std=None, clip=5.0):
+        """The step kernel writes the policy's first-layer input itself (TASim.set_policy_input; NativeMLP.attach_env wires it)."""
+        self.sim.set_policy_input(out, mean, inv_std, clip)
 
     def reset_idx(self, env_ids=None):
         """_reset_idx (TA:965-1028) outside a step, for the listed env ids (None: all).  A rare host-driven path: plain torch

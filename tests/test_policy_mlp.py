@@ -186,3 +186,36 @@ def test_dma_tiles_exact_at_full_size_repeated(tile, monkeypatch):
         layer_forward(out, a, w, bias, elu=False, batch=2, in_stride=k, w_stride=n * k, bias_stride=n, out_stride=n, m=m, n=n, k=k)
         bad = int((out != want).sum())
         assert bad == 0, (tile, rep, bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 1000])
+def test_step_kernel_writes_the_policy_input(n):
+    """SURVEY.md §8(f) N2, "fuse obs normalisation into the step kernel": with ppenv_ta_sim_set_policy_input the chain-wave step writes
+    the policy's first-layer input next to obs_buf — bit for bit what ppenv_mlp_prepare_input makes of the obs_buf of the same step
+    (ragged last workgroup included), obs_buf itself unchanged; and switched off again it is no longer written."""
+    import torch
+    from isaacgym_amd.policy import prepare_input
+    from isaacgym_amd.tensor_api import TAEnv
+    env = TAEnv(n, device="cuda:0", seed=3)
+    if env.sim.kernel != "chain":
+        pytest.skip("the chain-wave kernel is not the one in use")
+    ref = TAEnv(n, device="cuda:0", seed=3)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    mean = torch.randn(313, device="cuda", generator=gen) * 0.3
+    inv_std = torch.rand(313, device="cuda", generator=gen) * 3 + 0.2
+    x16 = torch.full((n, 320), 9.0, dtype=torch.float16, device="cuda")
+    env.set_policy_input(x16, mean, inv_std, 5.0)
+    want = torch.empty_like(x16)
+    for t in range(70):                                  # past episode ends: reset envs carry the observation of the restored state
+        a = torch.rand(n, 27, device="cuda", generator=gen) * 2 - 1
+        env.step(a)
+        ref.step(a)
+        assert torch.equal(env.obs_buf, ref.obs_buf), t
+        prepare_input(want, env.obs_buf, mean, inv_std, 5.0)
+        assert torch.equal(x16, want), t
+    env.set_policy_input(None)
+    x16.fill_(7.0)
+    env.step(a)
+    assert bool((x16 == 7.0).all())
+    env.close(); ref.close()
