@@ -240,10 +240,21 @@ struct Limb {
             outward_step(P, L, E, sv[k].w, sv[k].v, jo[k], aw, av, target[k], q[k], qd[k], force[k]);
         });
     }
-    __device__ __forceinline__ void load(const Shared& S, int e) {
+    // (the staging leaves the raw actions in S.act_frc: the clamp and the map onto the joint range happen here, where the joint is a
+    // compile-time constant — in the staging loop the lanes of a wave look at different dofs and the limits were a table lookup)
+    __device__ __forceinline__ void load(const Shared& S, int e, float clip_actions) {
         static_for<N>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            q[k] = S.q[FIRST - 1 + k][e]; qd[k] = S.qd[FIRST - 1 + k][e]; target[k] = S.act_frc[FIRST - 1 + k][e]; force[k] = 0.f;
+            constexpr LinkC L = T::link(FIRST + k);
+            q[k] = S.q[FIRST - 1 + k][e]; qd[k] = S.qd[FIRST - 1 + k][e]; force[k] = 0.f;
+            target[k] = pd_target(S.act_frc[FIRST - 1 + k][e], L.lo, L.hi, clip_actions);   // VecTask.step clamp + TA:1131, 729-733
+        });
+    }
+    // the final phase only needs the new (q, qd): S.act_frc holds the drive torques by then
+    __device__ __forceinline__ void load_state(const Shared& S, int e) {
+        static_for<N>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            q[k] = S.q[FIRST - 1 + k][e]; qd[k] = S.qd[FIRST - 1 + k][e]; target[k] = 0.f; force[k] = 0.f;
         });
     }
     __device__ __forceinline__ void store(Shared& S, int e) const {
@@ -483,8 +494,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int t = 4 * i + k, ee = t / NDOF, d = t - ee * NDOF;
-                    const LinkC L = T::link(d + 1);   // (a run-time index: the one place where the lanes of a wave look at different dofs)
-                    S.act_frc[d][ee] = pd_target(va[it][k], L.lo, L.hi, P.clip_actions);   // VecTask.step clamp + TA:1131, 729-733
+                    S.act_frc[d][ee] = va[it][k];   // raw: Limb::load maps it to the PD target
                 }
             }
         }
@@ -504,8 +514,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         }
         for (int t = tid; t < nvalid * NDOF; t += kWaves * 64) {
             const int ee = t / NDOF, d = t - ee * NDOF;
-            const LinkC L = T::link(d + 1);
-            S.act_frc[d][ee] = pd_target(a.actions[(size_t)e0 * NDOF + t], L.lo, L.hi, P.clip_actions);
+            S.act_frc[d][ee] = a.actions[(size_t)e0 * NDOF + t];
         }
         tile_in<39>(S.root, a.root_states + (size_t)e0 * 39, nvalid, tid);
     }
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     auto no_geo = [](auto, const Frame&) {};
     auto leg_role = [&](auto limb_tag, const int leg) {
         typename decltype(limb_tag)::type L;
-        L.load(S, e);
+        L.load(S, e, P.clip_actions);
         for (int sub = 0; sub < substeps; sub++) {
             if (sub > 0) TA_AWAIT(&S.f_base, sub);                  // the base state of this substep
             CH_STAMP(2 + 8 * (sub & 1));
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     };
     auto arm_role = [&](auto limb_tag, const int arm, auto with_geo) {
         typename decltype(limb_tag)::type L;
-        L.load(S, e);
+        L.load(S, e, P.clip_actions);
         for (int sub = 0; sub < substeps; sub++) {
             TA_AWAIT(&S.f_torso, sub + 1);
             CH_STAMP(2 + 8 * (sub & 1));
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     };
     auto waist_role = [&]() {   // pelvis + waist: the two hubs, the base solve, the base integration
         Limb<13, 3> WA;
-        WA.load(S, e);
+        WA.load(S, e, P.clip_actions);
         BaseState base;
         base.p = row3(S.root, 0, e);
         for (int k = 0; k < 4; k++) base.quat[k] = S.root[3 + k][e];
@@ -703,11 +712,11 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             heading_quat_inv(rq, c.hinv);                        // calc_heading_quat_inv of the (pre-reset) pelvis, TA:1862
             c.rootp = row3(S.root, 0, e);
         }
-        if (wave == W_LL) { Limb<1, 6> L; L.load(S, e); limb_out(c, L, base_frame(S.root, e)); }
-        else if (wave == W_RL) { Limb<7, 6> L; L.load(S, e); limb_out(c, L, base_frame(S.root, e)); }
+        if (wave == W_LL) { Limb<1, 6> L; L.load_state(S, e); limb_out(c, L, base_frame(S.root, e)); }
+        else if (wave == W_RL) { Limb<7, 6> L; L.load_state(S, e); limb_out(c, L, base_frame(S.root, e)); }
         else if (wave == W_WAIST) {
             Limb<13, 3> WA;
-            WA.load(S, e);
+            WA.load_state(S, e);
             const Frame f0 = base_frame(S.root, e);
             Frame fr[3];
             const Frame ft = limb_frames(WA, f0, fr);
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         } else {
             TA_AWAIT(&S.f_torso, substeps + 1);
             const Frame ft = torso_frame(S, e);
-            if (wave == W_LA) { Limb<16, 7> L; L.load(S, e); limb_out(c, L, ft); } else { Limb<23, 5> L; L.load(S, e); limb_out(c, L, ft); }
+            if (wave == W_LA) { Limb<16, 7> L; L.load_state(S, e); limb_out(c, L, ft); } else { Limb<23, 5> L; L.load_state(S, e); limb_out(c, L, ft); }
         }
         S.sums[wave][0][e] = c.pos_acc; S.sums[wave][1][e] = c.vel_acc; S.sums[wave][2][e] = c.norm_acc;
     } else {
