@@ -112,10 +112,13 @@ static_assert(sizeof(Shared) <= 160 * 1024, "LDS budget");
 __device__ __forceinline__ void publish(int* flag, int value) {
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+#ifndef TA_POLL_SLEEP
+#define TA_POLL_SLEEP 1      // s_sleep argument between two polls of a hand-off flag (x 64 cycles)
+#endif
 __device__ __forceinline__ bool await(int* flag, int value) {
     for (int spin = 0; spin < (1 << 22); spin++) {
         if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= value) return true;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(TA_POLL_SLEEP);
     }
     return false;
 }
@@ -144,6 +147,15 @@ __device__ __forceinline__ ArtI get_art(const float (*r)[kE], int e) {
     ArtI I = {{v[0], v[1], v[2], v[3], v[4], v[5]}, {{v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13], v[14]}},
               {v[15], v[16], v[17], v[18], v[19], v[20]}, mk(v[21], v[22], v[23]), mk(v[24], v[25], v[26])};
     return I;
+}
+// Keeps the compiler from sinking the computation of I below this point: a bounded wait on a hand-off flag is no obstacle to moving
+// register arithmetic across it, and whatever is only consumed after the wait would otherwise be scheduled there — on the critical
+// path, instead of inside the time the wave spends waiting anyway.
+__device__ __forceinline__ void pin_art(ArtI& I) {
+    asm volatile("" : "+v"(I.A.xx), "+v"(I.A.yy), "+v"(I.A.zz), "+v"(I.A.xy), "+v"(I.A.xz), "+v"(I.A.yz));
+    asm volatile("" : "+v"(I.B.m[0]), "+v"(I.B.m[1]), "+v"(I.B.m[2]), "+v"(I.B.m[3]), "+v"(I.B.m[4]), "+v"(I.B.m[5]), "+v"(I.B.m[6]), "+v"(I.B.m[7]), "+v"(I.B.m[8]));
+    asm volatile("" : "+v"(I.D.xx), "+v"(I.D.yy), "+v"(I.D.zz), "+v"(I.D.xy), "+v"(I.D.xz), "+v"(I.D.yz));
+    asm volatile("" : "+v"(I.pn.x), "+v"(I.pn.y), "+v"(I.pn.z), "+v"(I.pf.x), "+v"(I.pf.y), "+v"(I.pf.z));
 }
 __device__ __forceinline__ ArtI art_zero() {
     ArtI I = {{0, 0, 0, 0, 0, 0}, {{0, 0, 0, 0, 0, 0, 0, 0, 0}}, {0, 0, 0, 0, 0, 0}, mk(0, 0, 0), mk(0, 0, 0)};
@@ -218,12 +230,24 @@ struct Limb {
     }
     // pass 2: articulated inertias inwards; `acc` = what the chain's tip receives from outside (zero, or the arms at the torso);
     // returns the chain's contribution to its parent, in the parent's coordinates
-    __device__ __forceinline__ ArtI pass2(const TAScal& P, ArtI acc) {
+    // The links' own dynamics do not depend on what arrives at the tip: a chain that WAITS for its tip's input (the waist, for the arms)
+    // computes them first (pass2_own into `own`, then pass2 with OWN = true) instead of after the wait, on the critical path.
+    __device__ __forceinline__ void pass2_own(const TAScal& P, ArtI (&own)[N]) {
+        constexpr CPTable cp = cp_table();
+        static_for<N>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr LinkC L = T::link(FIRST + k);
+            own[k] = link_dynamics(P, L, cp.p, sv[k].Rw, sv[k].pw, sv[k].w, sv[k].v);
+            pin_art(own[k]);
+        });
+    }
+    template <bool OWN = false>
+    __device__ __forceinline__ ArtI pass2(const TAScal& P, ArtI acc, const ArtI* own = nullptr) {
         constexpr CPTable cp = cp_table();
         static_for<N>([&](auto kc) {
             constexpr int k = N - 1 - decltype(kc)::value;
             constexpr LinkC L = T::link(FIRST + k);
-            ArtI I = link_dynamics(P, L, cp.p, sv[k].Rw, sv[k].pw, sv[k].w, sv[k].v);
+            ArtI I = OWN ? own[k] : link_dynamics(P, L, cp.p, sv[k].Rw, sv[k].pw, sv[k].w, sv[k].v);
             add_art(I, acc);
             const M3 E = joint_E<FIRST + k>(sv[k].c, sv[k].s);
             inward_step(P, L, I, sv[k].w, sv[k].v, E, q[k], qd[k], target[k], jo[k]);
@@ -616,14 +640,18 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             constexpr LinkC L0 = T::link(0);
             CH_STAMP(3 + 8 * (sub & 1));
             ArtI I0 = link_dynamics(P, L0, cp.p, f0.Rw, f0.pw, f0.w, f0.v);
+            pin_art(I0);                                            // the pelvis' own dynamics: before the wait for the arms
+            ArtI own[3];
+            WA.pass2_own(P, own);                                   // and the waist links' own
             CH_STAMP(7 + 8 * (sub & 1));
             TA_AWAIT(&S.f_arm[0], sub + 1);
             TA_AWAIT(&S.f_arm[1], sub + 1);
             CH_STAMP(4 + 8 * (sub & 1));
             ArtI arms = get_art(S.u.hub.art_arm[0], e);
             add_art(arms, get_art(S.u.hub.art_arm[1], e));
-            const ArtI up = WA.pass2(P, arms);
+            const ArtI up = WA.template pass2<true>(P, arms, own);
             add_art(I0, up);
+            pin_art(I0);                                            // done before the wait for the legs, not after it
             CH_STAMP(8 + 8 * (sub & 1));
             TA_AWAIT(&S.f_leg[0], sub + 1);
             TA_AWAIT(&S.f_leg[1], sub + 1);

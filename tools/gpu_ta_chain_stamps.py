@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from isaacgym_amd import _lib  # noqa: E402
 lib = os.path.join(ROOT, "gpurun_out", "libppenv_chainstamp.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-subprocess.run(["hipcc"] + _lib.HIPCC_FLAGS + ["-DTA_STAMP=1", "-o", lib] + _lib.SOURCES, check=True)
+subprocess.run(["hipcc"] + _lib.HIPCC_FLAGS + ["-DTA_STAMP=1"] + os.environ.get("PPENV_STAMP_DEFS", "").split() + ["-o", lib] + _lib.SOURCES, check=True)
 os.environ["PPENV_LIB"] = lib
 _lib.LIB_PATH = lib
 import torch  # noqa: E402
