@@ -175,3 +175,67 @@ class NativeMLP:
         dims = [num_obs] + list(units)
         per_net = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
         return 2 * m * (2 * per_net + units[-1] * (num_actions + 1))
+
+
+# ---- a trained rl_games checkpoint on the native forward (the reference's `train.py test=True checkpoint=...` play mode) ---------------
+_MLP_KEY = r"a2c_network\.%s_mlp\.(\d+)\.weight"
+
+
+def layers_from_rlgames_state_dict(sd):
+    """rl_games' a2c_continuous(_logstd) model state_dict (what `torch.load(ckpt)["model"]` holds for the reference's network:
+    `separate: True`, cfg/train/HumanoidPingpongTiltG1PPO.yaml:10-31) -> (actor, critic) lists of (weight, bias), head last.
+    Keys: a2c_network.{actor,critic}_mlp.<even index>.{weight,bias} (nn.Sequential of Linear / activation), a2c_network.mu.*,
+    a2c_network.value.*."""
+    import re
+
+    def mlp(which):
+        idx = sorted(int(m.group(1)) for k in sd for m in [re.fullmatch(_MLP_KEY % which, k)] if m)
+        if not idx:
+            raise KeyError(f"no a2c_network.{which}_mlp.*.weight in the state dict (a `separate: True` a2c network is expected)")
+        return [(sd[f"a2c_network.{which}_mlp.{i}.weight"], sd[f"a2c_network.{which}_mlp.{i}.bias"]) for i in idx]
+    actor = mlp("actor") + [(sd["a2c_network.mu.weight"], sd["a2c_network.mu.bias"])]
+    critic = mlp("critic") + [(sd["a2c_network.value.weight"], sd["a2c_network.value.bias"])]
+    return actor, critic
+
+
+class RLGamesPolicy:
+    """A trained rl_games continuous-action policy served by NativeMLP: input normalisation (running_mean_std, eval mode), actor and
+    critic, fixed log-std sigma (`continuous_a2c_logstd`: sigma = exp(a2c_network.sigma)), value de-normalisation (value_mean_std,
+    `normalize_value: True`).  `act(obs)` is what rl_games' player does per step: mu (deterministic) or a Normal(mu, sigma) draw,
+    clamped to [-1, 1]."""
+
+    def __init__(self, state_dict, device, max_rows=None, eps=1e-5):
+        sd = state_dict
+        actor, critic = layers_from_rlgames_state_dict(sd)
+        num_obs = actor[0][0].shape[1]
+        mean, var = sd.get("running_mean_std.running_mean"), sd.get("running_mean_std.running_var")
+        if mean is None:                                       # normalize_input: False
+            mean, var = torch.zeros(num_obs), torch.ones(num_obs) - eps
+        self.net = NativeMLP(actor, critic, num_obs, device, mean=mean.float(), var=var.float(), eps=eps, max_rows=max_rows)
+        self.device = self.net.device
+        self.sigma = torch.exp(sd["a2c_network.sigma"].detach().float()).to(self.device).contiguous()
+        vm, vv = sd.get("value_mean_std.running_mean"), sd.get("value_mean_std.running_var")
+        self.value_mean = float(vm.reshape(-1)[0]) if vm is not None else 0.0
+        self.value_std = float(torch.sqrt(vv.reshape(-1)[0].float() + eps)) if vv is not None else 1.0
+        self._actions = self._neglogp = None
+        self._counter = 0
+
+    @classmethod
+    def load(cls, path, device, max_rows=None):
+        """A checkpoint file written by rl_games (`nn/<name>.pth`): tensors only are read (weights_only)."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        return cls(ckpt["model"] if "model" in ckpt else ckpt, device, max_rows=max_rows)
+
+    def act(self, obs, deterministic=True, seed=0):
+        """obs [M, num_obs] fp32 on the device -> (actions [M, A] in [-1, 1], value [M, 1] de-normalised)."""
+        mu, v = self.net.forward(obs)
+        m = obs.shape[0]
+        if self._actions is None or self._actions.shape[0] != m:
+            self._actions = torch.empty(m, self.net.num_actions, device=self.device)
+            self._neglogp = torch.empty(m, device=self.device)
+        if deterministic:
+            torch.clamp(mu, -1.0, 1.0, out=self._actions)
+        else:
+            self._counter += 1
+            sample_actions(self._actions, mu, self.sigma, seed, self._counter, -1.0, 1.0, self._neglogp)
+        return self._actions, v * self.value_std + self.value_mean

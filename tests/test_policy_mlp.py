@@ -219,3 +219,65 @@ def test_step_kernel_writes_the_policy_input(n):
     env.step(a)
     assert bool((x16 == 7.0).all())
     env.close(); ref.close()
+
+
+def _rlgames_state_dict(torch, num_obs, units, num_act, gen):
+    """A state dict with the key layout of rl_games' a2c_continuous_logstd model for a `separate: True` network."""
+    sd, d = {}, num_obs
+    for which in ("actor", "critic"):
+        d = num_obs
+        for li, u in enumerate(units):
+            sd[f"a2c_network.{which}_mlp.{2 * li}.weight"] = (torch.rand(u, d, generator=gen) * 2 - 1) / np.sqrt(d)
+            sd[f"a2c_network.{which}_mlp.{2 * li}.bias"] = (torch.rand(u, generator=gen) * 2 - 1) / np.sqrt(d)
+            d = u
+    sd["a2c_network.mu.weight"], sd["a2c_network.mu.bias"] = (torch.rand(num_act, d, generator=gen) * 2 - 1) / np.sqrt(d), torch.zeros(num_act)
+    sd["a2c_network.value.weight"], sd["a2c_network.value.bias"] = (torch.rand(1, d, generator=gen) * 2 - 1) / np.sqrt(d), torch.zeros(1)
+    sd["a2c_network.sigma"] = torch.full((num_act,), -2.0)
+    sd["running_mean_std.running_mean"], sd["running_mean_std.running_var"] = torch.randn(num_obs, generator=gen) * 0.2, torch.rand(num_obs, generator=gen) + 0.5
+    sd["running_mean_std.count"] = torch.tensor(1000.0)
+    sd["value_mean_std.running_mean"], sd["value_mean_std.running_var"], sd["value_mean_std.count"] = torch.tensor([3.0]), torch.tensor([4.0]), torch.tensor(1000.0)
+    return sd
+
+
+def test_rlgames_state_dict_layout_is_parsed():
+    """CPU: the key layout of an rl_games checkpoint's model -> ordered (weight, bias) lists, heads last; a shared-trunk network is refused."""
+    import torch
+    from isaacgym_amd.policy import layers_from_rlgames_state_dict
+    sd = _rlgames_state_dict(torch, 80, (64, 32, 16), 7, torch.Generator().manual_seed(0))
+    actor, critic = layers_from_rlgames_state_dict(sd)
+    assert [tuple(w.shape) for w, _ in actor] == [(64, 80), (32, 64), (16, 32), (7, 16)]
+    assert [tuple(w.shape) for w, _ in critic] == [(64, 80), (32, 64), (16, 32), (1, 16)]
+    assert actor[1][0] is sd["a2c_network.actor_mlp.2.weight"] and critic[2][1] is sd["a2c_network.critic_mlp.4.bias"]
+    with pytest.raises(KeyError):
+        layers_from_rlgames_state_dict({k: v for k, v in sd.items() if "critic_mlp" not in k})
+
+
+@pytest.mark.gpu
+def test_rlgames_checkpoint_is_served_by_the_native_forward(tmp_path):
+    """A checkpoint file with rl_games' layout, loaded with weights_only, played deterministically: actions and de-normalised values
+    against the same network evaluated in fp32 torch."""
+    import torch
+    from isaacgym_amd.policy import RLGamesPolicy
+    gen = torch.Generator().manual_seed(4)
+    units, num_obs, num_act, m = (2048, 1536, 1024, 1024, 512, 512), 313, 27, 1024
+    sd = _rlgames_state_dict(torch, num_obs, units, num_act, gen)
+    path = tmp_path / "last_ep_100.pth"
+    torch.save({"model": sd, "epoch": 100, "frame": 1}, path)
+    pol = RLGamesPolicy.load(str(path), "cuda:0")
+    obs = torch.randn(m, num_obs, generator=gen) * 1.5
+    act, val = pol.act(obs.cuda(), deterministic=True)
+    x = torch.clamp((obs - sd["running_mean_std.running_mean"]) / torch.sqrt(sd["running_mean_std.running_var"] + 1e-5), -5, 5)
+
+    def net(which, head):
+        h = x
+        for li in range(len(units)):
+            h = torch.nn.functional.elu(h @ sd[f"a2c_network.{which}_mlp.{2 * li}.weight"].t() + sd[f"a2c_network.{which}_mlp.{2 * li}.bias"])
+        return h @ sd[f"a2c_network.{head}.weight"].t() + sd[f"a2c_network.{head}.bias"]
+    want_a, want_v = torch.clamp(net("actor", "mu"), -1, 1), net("critic", "value") * 2.0 + 3.0
+    assert float((act.cpu() - want_a).abs().max()) < 2e-2 * max(1.0, float(want_a.abs().max()))
+    assert float((val.cpu() - want_v).abs().max()) < 2e-2 * float(want_v.abs().max())
+    assert torch.allclose(pol.sigma.cpu(), torch.full((num_act,), float(np.exp(-2.0))))
+    drawn, _ = pol.act(obs.cuda(), deterministic=False)
+    z = (drawn.cpu() - net("actor", "mu")) / float(np.exp(-2.0))
+    inside = (drawn.cpu().abs() < 1.0)
+    assert abs(float(z[inside].std()) - 1.0) < 0.05                   # Normal(mu, sigma) draws where the clamp did not bite
