@@ -266,6 +266,9 @@ def main():
                          "created and nothing is measured; used by tests/test_bench_launch.py")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm launches before the W warm-up steps")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL (default); gloo only to rehearse the rank logic on one GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group and issue the per-horizon all-reduces even with ONE rank: the RCCL code path (communicator "
+                         "init with device_id, asynchronous float64 all-reduce beside the graph replays, barrier, max-reduce) on a one-GPU box")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -297,9 +300,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world                          # under a launcher the world size is authoritative
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
     ndev = torch.cuda.device_count()
     if local_rank >= ndev and args.dist_backend == "nccl":
         sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible; one process per GPU is required")
@@ -336,13 +340,13 @@ def main():
         torch.cuda.synchronize(device)
     graph = graphs.get(HORIZON)
 
-    if world > 1:
+    if dist is not None:
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
     # what the reference prints every 40 steps (TT:763-766) + finished episodes; all-reduced over the ranks
-    stats = D.AsyncHorizonStats(env) if args.variant != "TA" else None
+    stats = D.AsyncHorizonStats(env, force=args.force_dist) if args.variant != "TA" else None
 
     def horizon_stats():
         if stats is not None:

@@ -49,12 +49,13 @@ class AsyncHorizonStats:
     comes round again (or in `latest()`).  A synchronous all-reduce would serialise ~30 us of RCCL latency into
     every 32-step horizon of a ~16 us step."""
 
-    def __init__(self, env, depth=4, group=None):
+    def __init__(self, env, depth=4, group=None, force=False):
+        """force: issue the all-reduce even in a one-rank group (bench.py --force-dist: the RCCL path on a one-GPU box)."""
         self.env, self.group, self.depth = env, group, depth
         self.bufs = [torch.zeros(4, dtype=torch.float64, device=env.device) for _ in range(depth)]
         self.works = [None] * depth
         self.k = -1
-        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
 
     def push(self):
         self.k += 1

@@ -46,3 +46,14 @@ def test_bench_gpus_2_real_entry_on_one_gpu_gloo():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["global_envs"] == 4096 and out["value"] > 0
     assert out["roofline"]["avg_kernel_us"] > 0 and "cpu_baseline" not in out
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_with_one_rank():
+    """RCCL on the hardware at hand: one rank, `--force-dist` — the process group is created with backend nccl (= RCCL) and device_id,
+    every horizon's statistics go through an asynchronous float64 all-reduce beside the graph replays, the timing goes through the
+    barrier and the max-reduce.  (More than one rank per GPU is refused by RCCL, and multi-GPU runs are the driver's.)"""
+    r = _run(["--gpus", "1", "--force-dist", "--num-envs", "4096", "--steps", "128", "--warmup", "32", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["episode_stats"]["mean_progress"] > 0
