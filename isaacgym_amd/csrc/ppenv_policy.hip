@@ -568,9 +568,11 @@ __global__ __launch_bounds__(512) void mlp_layer_pp1_kernel(const Args a, const 
     PP_BARRIER();
     if (wm == 1) PP_BARRIER();                                     // group 1 runs one barrier behind
     int buf = 0;
+    PPM_STAMP_AT(30);
     for (int t = 0; t < ktiles; t++) {
         const _Float16* tile = smem + buf * TILE;
         const bool more = t + 2 < ktiles;
+        PPM_TILE_STAMP(0);
 #pragma unroll
         for (int i = 0; i < TI; i++)
 #pragma unroll
@@ -580,10 +582,15 @@ __global__ __launch_bounds__(512) void mlp_layer_pp1_kernel(const Args a, const 
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) fb[j][kk] = *reinterpret_cast<const h8*>(&tile[brow + j * 32 * BK + swz[kk]]);
         const int wbuf = buf == 0 ? 2 : buf - 1;                   // (t + 2) % 3: the buffer read in phase t - 1
+        PPM_TILE_STAMP(1);
         if (more) stage(wbuf, (t + 2) * BK);
+        PPM_TILE_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PPM_TILE_STAMP(3);
         if (wm == 1) PP_WAIT_TILE(more);
+        PPM_TILE_STAMP(4);
         PP_BARRIER();
+        PPM_TILE_STAMP(5);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
@@ -592,14 +599,19 @@ __global__ __launch_bounds__(512) void mlp_layer_pp1_kernel(const Args a, const 
 #pragma unroll
                 for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        PPM_TILE_STAMP(6);
         if (wm == 0) PP_WAIT_TILE(more);
+        PPM_TILE_STAMP(7);
         PP_BARRIER();
+        PPM_TILE_STAMP(8);
         buf = buf == 2 ? 0 : buf + 1;
     }
     if (wm == 0) PP_BARRIER();
 #undef PP_BARRIER
 #undef PP_WAIT_TILE
+    PPM_STAMP_AT(31);
     epilogue<TI, TJ>(a, acc, smem, m0 + wm * 64, n0 + wn * 32 * TJ, b);
+    PPM_STAMP_AT(29);
 }
 
 // obs [m, k] fp32 -> out [m, ld_out] fp16, normalised and clamped, zero beyond k.  One thread per two output columns: every load is
