@@ -20,7 +20,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 seeds = [int(a) for a in sys.argv[2:]] or [21, 22, 23]
 ob.build()
 tot = bad = 0
-for variant in ("TT", "T3", "TN", "T4"):
+DR = os.environ.get("PPENV_SOAK_DR") == "1"
+for variant in (("TT", "T3", "TN") if DR else ("TT", "T3", "TN", "T4")):
     for seed in seeds:
         n = 2048
         A = 2 if variant == "T4" else 1
@@ -29,6 +30,14 @@ for variant in ("TT", "T3", "TN", "T4"):
         env = PPEnv(scene.build_config(variant, num_envs=n, seed=seed), device="cuda:0")
         probe = SensitivityProbe(ob, cfg)
         rng = np.random.default_rng(seed)
+        if DR:   # domain randomisation on (N4): per-env tables, action / observation noise, another gravity — same tables on both sides
+            tabs = dict(dof_stiffness_scale=rng.uniform(0.5, 1.5, (7, n)).astype(np.float32), dof_damping_scale=rng.uniform(0.5, 1.5, (7, n)).astype(np.float32),
+                        link_mass_scale=rng.uniform(0.5, 1.5, (7, n)).astype(np.float32), restitution_scale=rng.uniform(0.0, 0.7, n).astype(np.float32),
+                        friction_scale=rng.uniform(0.7, 1.3, n).astype(np.float32))
+            kw = dict(action_noise_sigma=0.02, observation_noise_sigma=0.002)
+            for x in (o, probe.o2, env):
+                x.set_randomization(**tabs, **kw)
+                x.set_gravity(-9.8 - 0.3)
         for t in range(steps):
             a = rng.uniform(-1.2, 1.2, (n * A, 7)).astype(np.float32)
             st = o.get_state()
@@ -54,4 +63,4 @@ for variant in ("TT", "T3", "TN", "T4"):
             tot += int(keep.sum())
         env.close()
         print(variant, seed, "done", flush=True)
-print("env-steps compared", tot, "violations", bad)
+print("domain randomisation on:" if DR else "", "env-steps compared", tot, "violations", bad)
