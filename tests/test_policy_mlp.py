@@ -24,7 +24,7 @@ def _ref_forward(torch, layers, x):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,num_obs,num_act,units", [(4096, 313, 27, (2048, 1536, 1024, 1024, 512, 512)), (1000, 80, 7, (2048, 1536, 1024, 1024, 512, 512)),
-                                                      (130, 80, 7, (256, 128))])
+                                                      (130, 80, 7, (256, 128)), (77, 33, 5, (100, 50, 36))])   # last: nothing aligned, nothing a tile multiple
 @pytest.mark.parametrize("fuse_input", [False, True])
 def test_native_mlp_matches_fp32_pytorch(m, num_obs, num_act, units, fuse_input):
     import torch
