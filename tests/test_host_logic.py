@@ -246,3 +246,28 @@ def test_paddle_contact_known_answer(oracle_lib):
     assert min(vn) < -3.5                                    # approached ...
     assert max(vn) == pytest.approx(cfg.paddle_restitution * speed, rel=0.12)   # ... and left with e = 0.8 (gravity perturbs slightly)
     assert cfg.paddle_restitution == pytest.approx(0.8)
+
+
+def test_policy_entry_points_reject_bad_arguments_without_a_gpu():
+    """include/ppenv_policy.h: every entry validates its arguments before any device call — NULL pointers, strides shorter than the
+    rows, unaligned or odd output strides — and reports PPENV_EINVAL with a message (no compute happens here: there is no GPU)."""
+    import ctypes as C
+    from isaacgym_amd import _lib
+    from isaacgym_amd.policy import MLPLayer, _lib_policy
+    L = _lib_policy()
+    EINVAL = -1
+    d = MLPLayer()
+    assert L.ppenv_mlp_layer_forward(C.byref(d), None) == EINVAL                       # all NULL
+    d.m, d.n, d.k, d.batch = 8, 8, 16, 1
+    d.in_, d.w, d.out = 0x1000, 0x2000, 0x3000                                          # never dereferenced: the sizes fail first
+    d.lda, d.ldw, d.ldo = 8, 16, 8                                                      # lda < k
+    assert L.ppenv_mlp_layer_forward(C.byref(d), None) == EINVAL
+    assert b"lda >= k" in L.ppenv_last_error()
+    f = C.c_void_p(0x1000)
+    assert L.ppenv_mlp_prepare_input(None, 4, 8, 8, None, None, 5.0, f, 8, None) == EINVAL
+    assert L.ppenv_mlp_prepare_input(f, 4, 8, 8, None, None, 5.0, f, 12, None) == EINVAL      # ld_out not a multiple of 8
+    assert L.ppenv_mlp_prepare_input(f, 4, 8, 8, f, None, 5.0, f, 8, None) == EINVAL          # mean without inv_std
+    assert L.ppenv_mlp_sample_actions(f, 4, 300, 300, f, 0, 0, -1.0, 1.0, f, None, None) == EINVAL   # more than 256 actions
+    assert L.ppenv_mlp_sample_actions(f, 4, 8, 4, f, 0, 0, -1.0, 1.0, f, None, None) == EINVAL       # ld_mu < a
+    L.ppenv_ta_sim_set_policy_input.restype = C.c_int
+    assert L.ppenv_ta_sim_set_policy_input(None, None, None, 5.0, None, 0) == EINVAL                 # NULL handle
