@@ -104,7 +104,8 @@ def test_bad_cfg_raises_like_the_reference():
 
 def test_product_never_imports_the_oracle():
     """The product path must not route through oracle/ or the tests' host shim."""
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "isaacgym_amd")):
+    roots = [os.path.join(ROOT, d) for d in ("isaacgym_amd", "isaacgymenvs", "isaacgym", "include")]
+    for dirpath, _, files in (x for r in roots for x in os.walk(r)):
         for f in files:
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
