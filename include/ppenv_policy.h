@@ -58,6 +58,12 @@ int ppenv_mlp_prepare_input(const float* obs, int32_t m, int32_t k, int32_t ld_o
 int ppenv_mlp_sample_actions(const float* mu, int32_t m, int32_t a, int32_t ld_mu, const float* sigma, uint64_t seed, uint64_t counter,
                              float lo, float hi, float* actions, float* neglogp, void* stream);
 
+/* The heads layer and the draw in ONE launch: `heads` must be a layer the skinny heads kernel takes (fp16 input, fp32 output [m, n <= 32],
+ * batch 1, k % 16 == 0, 16-byte aligned rows); its first num_actions output columns are mu.  Writes `out` as ppenv_mlp_layer_forward
+ * does, and actions / neglogp exactly as ppenv_mlp_sample_actions(out, ...) with the same (seed, counter) would. */
+int ppenv_mlp_heads_sample(const ppenv_mlp_layer* heads, int32_t num_actions, const float* sigma, uint64_t seed, uint64_t counter,
+                           float lo, float hi, float* actions, float* neglogp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -645,21 +645,30 @@ __global__ __launch_bounds__(256) void sample_actions_kernel(const float* __rest
         for (int j = j0; j < a; j += 32) {
             const float sg = sigma[j];
             const float g = pp::dr_gauss(seed, (uint32_t)row, (uint32_t)(counter >> 24), (uint32_t)(counter & 0xFFFFFFu), (uint32_t)j);
-            float x = mu[(size_t)row * ld_mu + j] + sg * g;
-            nl += 0.5f * g * g + logf(sg);
+            float x = __fmaf_rn(sg, g, mu[(size_t)row * ld_mu + j]);
+            nl += __fmaf_rn(0.5f * g, g, logf(sg));   // spelled out: both samplers must round alike
             if (lo < hi) x = fminf(fmaxf(x, lo), hi);
             actions[(size_t)row * a + j] = x;
         }
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) nl += __shfl_xor(nl, d, 32);
-    if (live && j0 == 0 && neglogp) neglogp[row] = nl + 0.9189385332f * (float)a;     // + 0.5 log(2 pi) per action
+    if (live && j0 == 0 && neglogp) neglogp[row] = __fmaf_rn(0.9189385332f, (float)a, nl);     // + 0.5 log(2 pi) per action
 }
 
 // The heads: out[m, n <= 32] (fp32) = in[m, k] * W[n, k]^T + bias — a skinny layer that is all input traffic (8 MB of features for
 // 0.2 GFLOP).  A workgroup of four waves owns 32 rows; wave w takes the K steps w, w + 4, ... with both MFMA operands loaded straight
 // from global memory as fragments (16 bytes per lane; W is 56 KB and stays in L2), and the four partial 32 x 32 tiles are summed
 // through LDS.  Rows of W beyond n are clamped on load and never stored.
-__global__ __launch_bounds__(256) void mlp_heads_kernel(const Args a) {
+// sampling fused into the heads (ppenv_mlp_heads_sample): what sample_actions_kernel does, on the row the 32-lane group has just finished
+struct SampleArgs {
+    int num_actions;                 // the first num_actions columns of `out` are mu
+    const float* sigma;
+    unsigned long long seed, counter;
+    float lo, hi;
+    float* actions;                  // [m, num_actions]; NULL: no sampling (plain ppenv_mlp_layer_forward)
+    float* neglogp;                  // [m] or NULL
+};
+__global__ __launch_bounds__(256) void mlp_heads_kernel(const Args a, const SampleArgs sa) {
     __shared__ float part[4][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 32;
@@ -684,12 +693,29 @@ __global__ __launch_bounds__(256) void mlp_heads_kernel(const Args a) {
     __syncthreads();
     float* out = reinterpret_cast<float*>(a.out);
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int idx = tid + 256 * e, orow = idx >> 5, col = idx & 31;
-        if (m0 + orow >= a.m || col >= a.n) continue;
-        float x = part[0][orow][col] + part[1][orow][col] + part[2][orow][col] + part[3][orow][col] + (a.bias ? (float)a.bias[col] : 0.f);
-        if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
-        out[(size_t)(m0 + orow) * a.ldo + col] = x;
+    for (int e = 0; e < 4; e++) {                                 // a 32-lane group holds one row of the tile
+        const int idx = tid + 256 * e, orow = idx >> 5, col = idx & 31, row = m0 + orow;
+        const bool live = row < a.m && col < a.n;
+        float x = 0.f;
+        if (live) {
+            x = part[0][orow][col] + part[1][orow][col] + part[2][orow][col] + part[3][orow][col] + (a.bias ? (float)a.bias[col] : 0.f);
+            if (a.elu) x = x > 0.f ? x : __expf(x) - 1.0f;
+            out[(size_t)row * a.ldo + col] = x;
+        }
+        if (sa.actions) {                                         // same draws, clamp and log-probability as sample_actions_kernel
+            float nl = 0.f;
+            if (live && col < sa.num_actions) {
+                const float sg = sa.sigma[col];
+                const float g = pp::dr_gauss(sa.seed, (uint32_t)row, (uint32_t)(sa.counter >> 24), (uint32_t)(sa.counter & 0xFFFFFFu), (uint32_t)col);
+                float v = __fmaf_rn(sg, g, x);
+                nl = __fmaf_rn(0.5f * g, g, logf(sg));    // as sample_actions_kernel
+                if (sa.lo < sa.hi) v = fminf(fmaxf(v, sa.lo), sa.hi);
+                sa.actions[(size_t)row * sa.num_actions + col] = v;
+            }
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) nl += __shfl_xor(nl, d, 32);
+            if (row < a.m && col == 0 && sa.neglogp) sa.neglogp[row] = __fmaf_rn(0.9189385332f, (float)sa.num_actions, nl);
+        }
     }
 }
 }  // namespace
@@ -723,6 +749,26 @@ extern "C" int ppenv_mlp_sample_actions(const float* mu, int32_t m, int32_t a, i
     hipLaunchKernelGGL(sample_actions_kernel, dim3((m + 7) / 8), dim3(256), 0, (hipStream_t)stream, mu, m, a, ld_mu, sigma,
                        (unsigned long long)seed, (unsigned long long)counter, lo, hi, actions, neglogp);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching sample_actions_kernel failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
+
+// the heads layer and the action draw in one launch
+extern "C" int ppenv_mlp_heads_sample(const ppenv_mlp_layer* L, int32_t num_actions, const float* sigma, uint64_t seed, uint64_t counter, float lo, float hi,
+                                      float* actions, float* neglogp, void* stream) {
+    const bool ok = L && L->in && L->w && L->out && actions && sigma && L->m > 0 && L->k > 0 && L->n > 0 && L->n <= 32 && num_actions > 0 && num_actions <= L->n &&
+                    L->batch == 1 && L->out_f32 && !L->in_f32 && L->k % 16 == 0 && L->lda >= L->k && L->ldw >= L->k && L->ldo >= L->n && L->lda % 8 == 0 && L->ldw % 8 == 0 &&
+                    (reinterpret_cast<uintptr_t>(L->in) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->w) & 15) == 0;
+    if (!ok) {
+        ppenv_set_error("ppenv_mlp_heads_sample: needs a heads layer the skinny kernel takes (fp16 input, fp32 output, batch 1, n <= 32, k % 16 == 0, "
+                        "16-byte aligned rows) and 0 < num_actions <= n");
+        return PPENV_EINVAL;
+    }
+    Args a{L->m, L->n, L->k, L->lda, L->ldw, L->ldo, L->elu, L->out_f32, L->in, (long long)L->in_stride, L->mean, L->inv_std, L->clip,
+           reinterpret_cast<const _Float16*>(L->w), (long long)L->w_stride, reinterpret_cast<const _Float16*>(L->bias), (long long)L->bias_stride,
+           L->out, (long long)L->out_stride};
+    hipLaunchKernelGGL(mlp_heads_kernel, dim3((L->m + 31) / 32), dim3(256), 0, (hipStream_t)stream, a,
+                       SampleArgs{num_actions, sigma, (unsigned long long)seed, (unsigned long long)counter, lo, hi, actions, neglogp});
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching mlp_heads_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }
 
@@ -780,7 +826,7 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
         if (!ok) cfg = (wgs(256, 256) >= 192 && L->n >= 256) ? 384 : 128;
     }
     if (cfg == 600) {
-        hipLaunchKernelGGL(mlp_heads_kernel, dim3((L->m + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(mlp_heads_kernel, dim3((L->m + 31) / 32), dim3(256), 0, (hipStream_t)stream, a, SampleArgs{});
     } else if (cfg == 512) {
         const int tn = (L->n + 255) / 256, tm = (L->m + 255) / 256;
         hipLaunchKernelGGL((mlp_layer_pp_kernel<false, 4>), dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);

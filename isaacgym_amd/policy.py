@@ -35,6 +35,7 @@ def _lib_policy():
     L = _lib.lib()
     L.ppenv_mlp_layer_forward.argtypes = [C.POINTER(MLPLayer), C.c_void_p]
     L.ppenv_mlp_prepare_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
+    L.ppenv_mlp_heads_sample.argtypes = [C.POINTER(MLPLayer), C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ppenv_mlp_sample_actions.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_float, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
     return L
@@ -58,10 +59,8 @@ def prepare_input(out, obs, mean=None, inv_std=None, clip=5.0):
                                          torch.cuda.current_stream(obs.device).cuda_stream))
 
 
-def layer_forward(out, x, w, bias, elu, batch=1, in_stride=0, w_stride=0, bias_stride=0, out_stride=0, mean=None, inv_std=None, clip=5.0,
-                  m=None, n=None, k=None):
-    """One launch of ppenv_mlp_layer_forward on torch tensors (x: fp16 activations or fp32 observations; w: fp16 [n, k])."""
-    L = _lib_policy()
+def _descriptor(out, x, w, bias, elu, batch=1, in_stride=0, w_stride=0, bias_stride=0, out_stride=0, mean=None, inv_std=None, clip=5.0,
+                m=None, n=None, k=None):
     d = MLPLayer()
     d.m = x.shape[0] if m is None else m
     d.n = (w.shape[-2] if n is None else n)
@@ -75,7 +74,23 @@ def layer_forward(out, x, w, bias, elu, batch=1, in_stride=0, w_stride=0, bias_s
     d.bias, d.bias_stride = (bias.data_ptr() if bias is not None else None), bias_stride
     d.elu = int(elu)
     d.out, d.out_stride, d.ldo, d.out_f32 = out.data_ptr(), out_stride, out.stride(0), int(out.dtype == torch.float32)
-    _lib.check(L.ppenv_mlp_layer_forward(C.byref(d), torch.cuda.current_stream(x.device).cuda_stream))
+    return d
+
+
+def layer_forward(out, x, w, bias, elu, **kw):
+    """One launch of ppenv_mlp_layer_forward on torch tensors (x: fp16 activations or fp32 observations; w: fp16 [n, k])."""
+    d = _descriptor(out, x, w, bias, elu, **kw)
+    _lib.check(_lib_policy().ppenv_mlp_layer_forward(C.byref(d), torch.cuda.current_stream(x.device).cuda_stream))
+
+
+def heads_sample(out, x, w, bias, num_actions, actions, sigma, seed, counter, lo=-1.0, hi=1.0, neglogp=None):
+    """ppenv_mlp_heads_sample: the heads layer out [M, n <= 32] (fp32) = x . w^T + bias and, in the same launch, what
+    sample_actions(actions, out[:, :num_actions], sigma, seed, counter, lo, hi, neglogp) would produce."""
+    d = _descriptor(out, x, w, bias, False)
+    assert actions.is_contiguous() and actions.shape[1] == num_actions and sigma.is_contiguous()
+    _lib.check(_lib_policy().ppenv_mlp_heads_sample(C.byref(d), num_actions, sigma.data_ptr(), seed, counter, lo, hi, actions.data_ptr(),
+                                                    neglogp.data_ptr() if neglogp is not None else None,
+                                                    torch.cuda.current_stream(x.device).cuda_stream))
 
 
 class NativeMLP:
@@ -147,9 +162,11 @@ class NativeMLP:
             self._alloc(env.num_envs)
         env.set_policy_input(self.x16, self.mean, self.inv_std, self.clip)
 
-    def forward(self, obs, prepared=False):
+    def forward(self, obs, prepared=False, sample=None):
         """obs: fp32 [M, num_obs] on this device (the env's obs_buf, read in place) -> (mu [M, A], value [M, 1]) fp32 (buffers reused).
-        prepared: the first-layer input is already in self.x16 (attach_env: written by the env's step kernel)."""
+        prepared: the first-layer input is already in self.x16 (attach_env: written by the env's step kernel).
+        sample: dict(actions=[M, A] fp32, sigma=[A], seed=, counter=, lo=-1, hi=1, neglogp=[M] or None) — the heads launch also draws the
+        actions (ppenv_mlp_heads_sample): one launch fewer than forward + sample_actions, the same numbers."""
         m = obs.shape[0]
         if m != self._rows:
             assert not prepared
@@ -167,7 +184,11 @@ class NativeMLP:
         for i in range(1, len(u)):
             layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],
                           bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])
-        layer_forward(self.head_out, self.h[-1], self.head_w, self.head_b, elu=False)
+        if sample is None:
+            layer_forward(self.head_out, self.h[-1], self.head_w, self.head_b, elu=False)
+        else:
+            heads_sample(self.head_out, self.h[-1], self.head_w, self.head_b, self.num_actions, sample["actions"], sample["sigma"], sample["seed"],
+                         sample["counter"], sample.get("lo", -1.0), sample.get("hi", 1.0), sample.get("neglogp"))
         return self.mu, self.value
 
     @staticmethod

@@ -281,3 +281,27 @@ def test_rlgames_checkpoint_is_served_by_the_native_forward(tmp_path):
     z = (drawn.cpu() - net("actor", "mu")) / float(np.exp(-2.0))
     inside = (drawn.cpu().abs() < 1.0)
     assert abs(float(z[inside].std()) - 1.0) < 0.05                   # Normal(mu, sigma) draws where the clamp did not bite
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [4096, 77])
+def test_heads_sample_equals_heads_then_sample(m):
+    """ppenv_mlp_heads_sample: the heads launch that also draws the actions writes the same mu / value, and bit for bit the same actions
+    and log-probabilities, as the heads layer followed by ppenv_mlp_sample_actions with the same (seed, counter)."""
+    import torch
+    from isaacgym_amd.policy import heads_sample, layer_forward, sample_actions
+    gen = torch.Generator().manual_seed(m)
+    a, k = 27, 1024
+    x = (torch.randn(m, k, generator=gen) * 0.5).half().cuda()
+    w = (torch.randn(a + 1, k, generator=gen) / 32).half().cuda()
+    b = (torch.randn(a + 1, generator=gen) * 0.1).half().cuda()
+    sigma = (torch.rand(a, generator=gen) * 0.5 + 0.1).cuda()
+    out1, out2 = torch.zeros(m, a + 1, device="cuda"), torch.zeros(m, a + 1, device="cuda")
+    act1, act2 = torch.zeros(m, a, device="cuda"), torch.zeros(m, a, device="cuda")
+    nl1, nl2 = torch.zeros(m, device="cuda"), torch.zeros(m, device="cuda")
+    layer_forward(out1, x, w, b, elu=False)
+    sample_actions(act1, out1[:, :a], sigma, 11, 5, -1.0, 1.0, nl1)
+    heads_sample(out2, x, w, b, a, act2, sigma, 11, 5, -1.0, 1.0, nl2)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2) and torch.equal(act1, act2) and torch.equal(nl1, nl2)
+    assert float(act1.abs().max()) <= 1.0 and float((act1 - out1[:, :a]).abs().mean()) > 0.05

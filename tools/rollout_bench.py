@@ -89,12 +89,12 @@ def main():
 
     @torch.no_grad()
     def rollout_step():
-        mu, v = forward()
-        if native is not None:   # the value is already where the learner reads it (a view of the heads' output); one launch samples, clamps and scores
+        if native is not None:   # the value is already where the learner reads it (a view of the heads' output); the heads launch also samples, clamps and scores
             counter[0] += 1
-            sample_actions(action_buf, mu, sigma, 0, counter[0], -1.0, 1.0, neglogp)
+            native.forward(obs_buf, prepared=attached, sample=dict(actions=action_buf, sigma=sigma, seed=0, counter=counter[0], neglogp=neglogp))
             step(action_buf)
             return
+        mu, v = forward()
         values.copy_(v)
         action = torch.clamp(mu + sigma * torch.randn_like(mu), -1.0, 1.0).contiguous()
         step(action)
