@@ -249,14 +249,14 @@ class RLGamesPolicy:
 
     def act(self, obs, deterministic=True, seed=0):
         """obs [M, num_obs] fp32 on the device -> (actions [M, A] in [-1, 1], value [M, 1] de-normalised)."""
-        mu, v = self.net.forward(obs)
         m = obs.shape[0]
         if self._actions is None or self._actions.shape[0] != m:
             self._actions = torch.empty(m, self.net.num_actions, device=self.device)
             self._neglogp = torch.empty(m, device=self.device)
         if deterministic:
+            mu, v = self.net.forward(obs)
             torch.clamp(mu, -1.0, 1.0, out=self._actions)
-        else:
+        else:                                                  # the heads launch draws the actions as well
             self._counter += 1
-            sample_actions(self._actions, mu, self.sigma, seed, self._counter, -1.0, 1.0, self._neglogp)
+            mu, v = self.net.forward(obs, sample=dict(actions=self._actions, sigma=self.sigma, seed=seed, counter=self._counter, neglogp=self._neglogp))
         return self._actions, v * self.value_std + self.value_mean
