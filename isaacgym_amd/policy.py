@@ -184,8 +184,11 @@ class NativeMLP:
         for i in range(1, len(u)):
             layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],
                           bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])
-        if sample is None:
+        if sample is None or self.num_actions + 1 > 32:        # the skinny heads kernel (and with it the fused draw) takes up to 32 columns
             layer_forward(self.head_out, self.h[-1], self.head_w, self.head_b, elu=False)
+            if sample is not None:
+                sample_actions(sample["actions"], self.mu, sample["sigma"], sample["seed"], sample["counter"], sample.get("lo", -1.0), sample.get("hi", 1.0),
+                               sample.get("neglogp"))
         else:
             heads_sample(self.head_out, self.h[-1], self.head_w, self.head_b, self.num_actions, sample["actions"], sample["sigma"], sample["seed"],
                          sample["counter"], sample.get("lo", -1.0), sample.get("hi", 1.0), sample.get("neglogp"))
