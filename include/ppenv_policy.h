@@ -64,6 +64,14 @@ int ppenv_mlp_sample_actions(const float* mu, int32_t m, int32_t a, int32_t ld_m
 int ppenv_mlp_heads_sample(const ppenv_mlp_layer* heads, int32_t num_actions, const float* sigma, uint64_t seed, uint64_t counter,
                            float lo, float hi, float* actions, float* neglogp, void* stream);
 
+/* Generalised advantage estimation over a horizon-major rollout (rl_games' discount_values, a2c_common.py; `gamma`, `tau` of
+ * cfg/train/HumanoidPingpongTiltG1PPO.yaml:58-59): for t = H-1 .. 0
+ *   delta = scale * rewards[t] + gamma * values[t+1] * (1 - done[t]) - values[t];   adv[t] = delta + gamma * tau * (1 - done[t]) * adv[t+1]
+ * returns[t] = adv[t] + values[t].  rewards [H, N] fp32, values [H+1, N] fp32 with row stride ld_values (values[H] = the bootstrap
+ * value of the last observation), dones [H, N] int64 (VecTask's reset_buf), advantages / returns [H, N].  One thread per env. */
+int ppenv_gae(const float* rewards, const float* values, int32_t ld_values, int64_t values_step, const int64_t* dones, int32_t horizon, int32_t n,
+              float gamma, float tau, float reward_scale, float* advantages, float* returns, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -655,6 +655,24 @@ __global__ __launch_bounds__(256) void sample_actions_kernel(const float* __rest
     if (live && j0 == 0 && neglogp) neglogp[row] = __fmaf_rn(0.9189385332f, (float)a, nl);     // + 0.5 log(2 pi) per action
 }
 
+// GAE backwards over the horizon, one thread per env (values: element (t, i) at values[t * values_step + i * ld_values])
+__global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values, int ld_values, long long values_step,
+                                                  const long long* __restrict__ dones, int horizon, int n, float gamma, float tau, float scale,
+                                                  float* __restrict__ adv, float* __restrict__ ret) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float next_v = values[(size_t)horizon * values_step + (size_t)i * ld_values], run = 0.f;
+    for (int t = horizon - 1; t >= 0; t--) {
+        const float nd = dones[(size_t)t * n + i] ? 0.f : 1.f;
+        const float v = values[(size_t)t * values_step + (size_t)i * ld_values];
+        const float delta = scale * rewards[(size_t)t * n + i] + gamma * next_v * nd - v;
+        run = delta + gamma * tau * nd * run;
+        adv[(size_t)t * n + i] = run;
+        ret[(size_t)t * n + i] = run + v;
+        next_v = v;
+    }
+}
+
 // The heads: out[m, n <= 32] (fp32) = in[m, k] * W[n, k]^T + bias — a skinny layer that is all input traffic (8 MB of features for
 // 0.2 GFLOP).  A workgroup of four waves owns 32 rows; wave w takes the K steps w, w + 4, ... with both MFMA operands loaded straight
 // from global memory as fragments (16 bytes per lane; W is 56 KB and stays in L2), and the four partial 32 x 32 tiles are summed
@@ -749,6 +767,18 @@ extern "C" int ppenv_mlp_sample_actions(const float* mu, int32_t m, int32_t a, i
     hipLaunchKernelGGL(sample_actions_kernel, dim3((m + 7) / 8), dim3(256), 0, (hipStream_t)stream, mu, m, a, ld_mu, sigma,
                        (unsigned long long)seed, (unsigned long long)counter, lo, hi, actions, neglogp);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching sample_actions_kernel failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
+
+extern "C" int ppenv_gae(const float* rewards, const float* values, int32_t ld_values, int64_t values_step, const int64_t* dones, int32_t horizon, int32_t n,
+                         float gamma, float tau, float reward_scale, float* advantages, float* returns, void* stream) {
+    if (!rewards || !values || !dones || !advantages || !returns || horizon <= 0 || n <= 0 || ld_values <= 0 || values_step <= 0) {
+        ppenv_set_error("ppenv_gae: NULL pointer or non-positive size");
+        return PPENV_EINVAL;
+    }
+    hipLaunchKernelGGL(gae_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rewards, values, ld_values, (long long)values_step,
+                       reinterpret_cast<const long long*>(dones), horizon, n, gamma, tau, reward_scale, advantages, returns);
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching gae_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }
 

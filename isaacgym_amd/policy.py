@@ -35,6 +35,7 @@ def _lib_policy():
     L = _lib.lib()
     L.ppenv_mlp_layer_forward.argtypes = [C.POINTER(MLPLayer), C.c_void_p]
     L.ppenv_mlp_prepare_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
+    L.ppenv_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ppenv_mlp_heads_sample.argtypes = [C.POINTER(MLPLayer), C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ppenv_mlp_sample_actions.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_float, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
@@ -162,11 +163,13 @@ class NativeMLP:
             self._alloc(env.num_envs)
         env.set_policy_input(self.x16, self.mean, self.inv_std, self.clip)
 
-    def forward(self, obs, prepared=False, sample=None):
+    def forward(self, obs, prepared=False, sample=None, head_out=None):
         """obs: fp32 [M, num_obs] on this device (the env's obs_buf, read in place) -> (mu [M, A], value [M, 1]) fp32 (buffers reused).
         prepared: the first-layer input is already in self.x16 (attach_env: written by the env's step kernel).
         sample: dict(actions=[M, A] fp32, sigma=[A], seed=, counter=, lo=-1, hi=1, neglogp=[M] or None) — the heads launch also draws the
-        actions (ppenv_mlp_heads_sample): one launch fewer than forward + sample_actions, the same numbers."""
+        actions (ppenv_mlp_heads_sample): one launch fewer than forward + sample_actions, the same numbers.
+        head_out: [M, A + 1] fp32, row stride A + 1 — where mu | value go instead of the network's own buffer (a rollout collector's
+        horizon-major slice); the returned views then point into it."""
         m = obs.shape[0]
         if m != self._rows:
             assert not prepared
@@ -184,15 +187,17 @@ class NativeMLP:
         for i in range(1, len(u)):
             layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],
                           bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])
+        ho = self.head_out if head_out is None else head_out
+        mu, value = ho[:, :self.num_actions], ho[:, self.num_actions:]
         if sample is None or self.num_actions + 1 > 32:        # the skinny heads kernel (and with it the fused draw) takes up to 32 columns
-            layer_forward(self.head_out, self.h[-1], self.head_w, self.head_b, elu=False)
+            layer_forward(ho, self.h[-1], self.head_w, self.head_b, elu=False)
             if sample is not None:
-                sample_actions(sample["actions"], self.mu, sample["sigma"], sample["seed"], sample["counter"], sample.get("lo", -1.0), sample.get("hi", 1.0),
+                sample_actions(sample["actions"], mu, sample["sigma"], sample["seed"], sample["counter"], sample.get("lo", -1.0), sample.get("hi", 1.0),
                                sample.get("neglogp"))
         else:
-            heads_sample(self.head_out, self.h[-1], self.head_w, self.head_b, self.num_actions, sample["actions"], sample["sigma"], sample["seed"],
+            heads_sample(ho, self.h[-1], self.head_w, self.head_b, self.num_actions, sample["actions"], sample["sigma"], sample["seed"],
                          sample["counter"], sample.get("lo", -1.0), sample.get("hi", 1.0), sample.get("neglogp"))
-        return self.mu, self.value
+        return mu, value
 
     @staticmethod
     def flops(m, num_obs, units=UNITS, num_actions=0):

@@ -98,10 +98,18 @@ class TASim:
     def status(self):
         return int(self.L.ppenv_ta_sim_status(self.h))
 
-    def step(self, state, actions, initial_rb_states, root_states, dof_states, rb_states, dof_force, pre_ball_vx, reset_override=None):
+    def step(self, state, actions, initial_rb_states, root_states, dof_states, rb_states, dof_force, pre_ball_vx, reset_override=None,
+             obs=None, rew=None, reset=None):
         """ppenv_ta_step: simulate + post_physics_step (on `state`: a TAState) in one launch.  rb_states may be None with the
-        chain-wave kernel: rigid_body_states [N,42,13] is then not materialised."""
+        chain-wave kernel: rigid_body_states [N,42,13] is then not materialised.  obs / rew / reset: where this step's observation
+        rows [N,313], rewards [N] and reset flags [N] (int64) go instead of the state's own buffers (a rollout collector's slices)."""
         n = self.num_envs
+        obs = state.obs_buf if obs is None else obs
+        rew = state.rew_buf if rew is None else rew
+        reset = state.reset_buf if reset is None else reset
+        self._check(obs, n * scene.TA_NUM_OBS)
+        self._check(rew, n)
+        assert reset.dtype == torch.int64 and reset.is_contiguous() and reset.device == self.device and reset.numel() == n
         irb_n = 1 if state.params.initial_rb_shared else n
         for t, k in ((actions, n * 27), (initial_rb_states, irb_n * 42 * 13), (root_states, n * 39), (dof_states, n * 54),
                      (dof_force, n * 27), (pre_ball_vx, n)) + (((rb_states, n * 42 * 13),) if rb_states is not None else ()):
@@ -112,7 +120,7 @@ class TASim:
         _lib.check(self.L.ppenv_ta_step(
             self.h, C.byref(state.params), actions.data_ptr(), initial_rb_states.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(),
             rb_states.data_ptr() if rb_states is not None else None, dof_force.data_ptr(), pre_ball_vx.data_ptr(), ov.data_ptr() if ov is not None else None, state.flags.data_ptr(),
-            state.episode.data_ptr(), state.progress_buf.data_ptr(), state.obs_buf.data_ptr(), state.rew_buf.data_ptr(), state.reset_buf.data_ptr(),
+            state.episode.data_ptr(), state.progress_buf.data_ptr(), obs.data_ptr(), rew.data_ptr(), reset.data_ptr(),
             state._any_reset.data_ptr(), self._stream()))
         if ov is not None:
             torch.cuda.current_stream(self.device).synchronize()
@@ -190,13 +198,19 @@ class TAEnv:
         self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf = self.state.obs_buf, self.state.rew_buf, self.state.reset_buf, self.state.progress_buf
         self.reset_buf.fill_(1)   # upstream VecTask.allocate_buffers
 
-    def step(self, actions):
+    def step(self, actions, obs=None, rew=None, reset=None):
+        """obs / rew / reset (fused mode only): tensors that receive this step's observations, rewards and reset flags instead of
+        obs_buf / rew_buf / reset_buf — a rollout collector passes its horizon-major slices, so nothing is copied afterwards."""
         if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if self.fused:
             self.sim.step(self.state, actions, self.initial_rb_states, self.root_states, self.dof_states,
-                          self._rb_states if self.materialize_rb else None, self.dof_force_tensor, self.pre_ball_vx)
+                          self._rb_states if self.materialize_rb else None, self.dof_force_tensor, self.pre_ball_vx, obs=obs, rew=rew, reset=reset)
+            if obs is not None or rew is not None or reset is not None:
+                return ({"obs": self.obs_buf if obs is None else obs}, self.rew_buf if rew is None else rew,
+                        self.reset_buf if reset is None else reset, {})
         else:
+            assert obs is None and rew is None and reset is None, "output slices need the fused step"
             self.sim.simulate(actions, self.root_states, self.dof_states, self._rb_states, self.dof_force_tensor, self.pre_ball_vx)
             self.state.post_physics_step(self._rb_states, self.initial_rb_states, self.root_states, self.dof_states, self.dof_force_tensor, self.pre_ball_vx)
         return {"obs": self.obs_buf}, self.rew_buf, self.reset_buf, {}

@@ -272,5 +272,6 @@ def test_policy_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.ppenv_mlp_sample_actions(f, 4, 8, 4, f, 0, 0, -1.0, 1.0, f, None, None) == EINVAL       # ld_mu < a
     d.lda, d.ldw, d.ldo, d.out_f32, d.n = 16, 16, 40, 1, 40                              # a heads layer wider than the skinny kernel takes
     assert L.ppenv_mlp_heads_sample(C.byref(d), 7, f, 0, 0, -1.0, 1.0, f, None, None) == EINVAL
+    assert L.ppenv_gae(f, f, 1, 8, f, 0, 8, 0.99, 0.95, 1.0, f, f, None) == EINVAL                 # horizon 0
     L.ppenv_ta_sim_set_policy_input.restype = C.c_int
     assert L.ppenv_ta_sim_set_policy_input(None, None, None, 5.0, None, 0) == EINVAL                 # NULL handle
