@@ -247,6 +247,11 @@ int ppenv_config_of(struct ppenv* env, ppenv_config* out);
  * observations (TT:770-799) — one fused kernel launch.
  * actions_dev: [A*N, 7] f32 row-major (the policy's tensor, not copied; A = 2 for PPENV_VARIANT_T4). */
 int ppenv_step(struct ppenv* env, const float* actions_dev, void* stream);
+/* The same step with its outputs redirected: obs [A*N, 80] f32 (16-byte aligned), rew [A*N] f32, reset [A*N] int64 receive this step's
+ * observations, rewards and reset flags instead of the handle's obs_buf / rew_buf / reset_buf (NULL: the handle's own).  A rollout
+ * collector passes the slices of its horizon-major buffers ([horizon, num_actors, ...], rl_games' experience layout), so nothing is
+ * copied after the step.  ppenv_reduce_stats and ppenv_get_state keep reading the handle's own buffers. */
+int ppenv_step_into(struct ppenv* env, const float* actions_dev, float* obs_dev, float* rew_dev, int64_t* reset_dev, void* stream);
 
 /* Reset every env to its initial state with a fresh serve and recompute
  * observations (VecTask.reset()). */

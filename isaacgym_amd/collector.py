@@ -10,8 +10,9 @@ kernels per step next to the forward.  Here every producer writes STRAIGHT into 
     ppenv_gae                                 advantages, returns over the finished horizon
 
 so a horizon costs exactly the launches of `horizon` rollout steps, one bootstrap forward and one GAE launch — no copies, no host
-synchronisation.  The learner (rl_games / PyTorch autograd) consumes the buffers as they are.  TAEnv only (the 27-DoF task of BASELINE
-config 5): its C entry takes the output pointers per call.
+synchronisation.  The learner (rl_games / PyTorch autograd) consumes the buffers as they are.  Works with TAEnv (the 27-DoF task of
+BASELINE config 5: ppenv_ta_step takes its output pointers per call) and with PPEnv (the 7-dof tasks: ppenv_step_into; the 4-actor
+variant has two actor rows per env).
 """
 import ctypes as C
 
@@ -40,7 +41,7 @@ class RolloutCollector:
     def __init__(self, env, net, horizon=32, gamma=0.99, tau=0.95, reward_scale=0.01, sigma=None, seed=0):
         self.env, self.net, self.h = env, net, int(horizon)
         self.gamma, self.tau, self.reward_scale, self.seed = float(gamma), float(tau), float(reward_scale), int(seed)   # yaml:55-59: scale_value 0.01, gamma 0.99, tau 0.95
-        n, dev, a = env.num_envs, env.device, net.num_actions
+        n, dev, a = getattr(env, "num_rows", env.num_envs), env.device, net.num_actions        # actor rows: A * N for the 4-actor variant
         z = lambda *shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
         self.obs = z(self.h + 1, n, env.obs_buf.shape[1])
         self.head = z(self.h + 1, n, a + 1)                     # mu | value, as the heads launch writes them

@@ -1360,33 +1360,46 @@ int ppenv_config_of(ppenv* e, ppenv_config* out) {
     return PPENV_OK;
 }
 
-int ppenv_step(ppenv* e, const float* actions_dev, void* stream) {
+static int launch_step(ppenv* e, const DevBuffers& buf, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = check_status(e)) return rc;
     if (int rc = use_device(e)) return rc;
     if (e->dr_on) {   // domain randomisation: the table-reading instantiation of the one-wave kernel
-        hipLaunchKernelGGL((step_kernel<ModelG1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
+        hipLaunchKernelGGL((step_kernel<ModelG1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, buf, actions_dev,
                            e->serve_on, e->dr);
         PP_HIP(hipGetLastError());
         return PPENV_OK;
     }
     if (e->agents == 2 && e->split == 2)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, buf,
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->agents == 2)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, buf,
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->split == 3)
-        hipLaunchKernelGGL((step_kernel_quad<ModelG1>), dim3(grid_for(e->cfg.num_envs)), dim3(4 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+        hipLaunchKernelGGL((step_kernel_quad<ModelG1>), dim3(grid_for(e->cfg.num_envs)), dim3(4 * kBlock), 0, (hipStream_t)stream, e->K, buf,
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->split)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, e->buf,
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, buf,
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else
-        hipLaunchKernelGGL((step_kernel<ModelG1, false>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->buf, actions_dev,
+        hipLaunchKernelGGL((step_kernel<ModelG1, false>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, buf, actions_dev,
                            e->serve_on, DRTables{});
     PP_HIP(hipGetLastError());
     return PPENV_OK;
+}
+
+int ppenv_step(ppenv* e, const float* actions_dev, void* stream) { return launch_step(e, e ? e->buf : DevBuffers{}, actions_dev, stream); }
+
+/* the same launch with this step's observations / rewards / reset flags going to the caller's tensors (NULL: the handle's own) */
+int ppenv_step_into(ppenv* e, const float* actions_dev, float* obs_dev, float* rew_dev, int64_t* reset_dev, void* stream) {
+    if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
+    if (obs_dev && (reinterpret_cast<uintptr_t>(obs_dev) & 15)) { set_err("ppenv_step_into: obs must be 16-byte aligned"); return PPENV_EINVAL; }
+    DevBuffers b = e->buf;
+    if (obs_dev) b.obs = obs_dev;
+    if (rew_dev) b.rew = rew_dev;
+    if (reset_dev) b.reset = reinterpret_cast<long long*>(reset_dev);
+    return launch_step(e, b, actions_dev, stream);
 }
 
 int ppenv_reset_all(ppenv* e, void* stream) {

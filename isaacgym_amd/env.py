@@ -70,12 +70,20 @@ class PPEnv:
             pass
 
     # ---- hot path
-    def step(self, actions):
-        """actions: float32 [A*N, 7] on this device, contiguous.  One fused kernel launch, no sync."""
+    def step(self, actions, obs=None, rew=None, reset=None):
+        """actions: float32 [A*N, 7] on this device, contiguous.  One fused kernel launch, no sync.
+        obs [A*N, 80] f32 / rew [A*N] f32 / reset [A*N] int64: tensors that receive this step's outputs instead of obs_buf / rew_buf /
+        reset_buf (ppenv_step_into: a rollout collector's horizon-major slices)."""
         if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous() \
                 or tuple(actions.shape) != (self.num_rows, scene.NUM_DOF):
             actions = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_rows, scene.NUM_DOF).contiguous()
-        _lib.check(self.L.ppenv_step(self.h, actions.data_ptr(), self._stream()))
+        if obs is None and rew is None and reset is None:
+            _lib.check(self.L.ppenv_step(self.h, actions.data_ptr(), self._stream()))
+            return
+        for t, dt, numel in ((obs, torch.float32, self.num_rows * scene.NUM_OBS), (rew, torch.float32, self.num_rows), (reset, torch.int64, self.num_rows)):
+            assert t is None or (t.dtype == dt and t.is_contiguous() and t.device == self.device and t.numel() == numel)
+        p = lambda t: t.data_ptr() if t is not None else None
+        _lib.check(self.L.ppenv_step_into(self.h, actions.data_ptr(), p(obs), p(rew), p(reset), self._stream()))
 
     def reset_all(self):
         _lib.check(self.L.ppenv_reset_all(self.h, self._stream()))

@@ -72,3 +72,39 @@ def test_collector_equals_the_loop_done_by_hand():
         assert int(col.dones.sum()) > 0 or horizon == 0                     # episodes of 12 steps: the second horizon sees resets
         col.next_horizon()
     env.close(); ref.close()
+
+
+@pytest.mark.parametrize("variant", ["TT", "T4"])
+def test_collector_on_the_7dof_tasks_equals_the_loop_done_by_hand(variant):
+    """The same for PPEnv (ppenv_step_into redirects obs / rew / reset per call); T4 has two actor rows per env."""
+    import torch
+    from isaacgym_amd import scene
+    from isaacgym_amd.collector import RolloutCollector
+    from isaacgym_amd.env import PPEnv
+    from isaacgym_amd.policy import sample_actions
+    n, h = 700, 6
+    mk = lambda: PPEnv(scene.build_config(variant, num_envs=n, seed=4), device="cuda:0")
+    env, ref = mk(), mk()
+    rows = env.num_rows
+    net = _net(torch, 80, 7, "cuda:0")
+    sigma = torch.full((7,), 0.5, device="cuda")
+    col = RolloutCollector(env, net, horizon=h, sigma=sigma, seed=9)
+    counter = 0
+    for horizon in range(3):
+        col.collect()
+        torch.cuda.synchronize()
+        obs, acts, rews, dns = [ref.obs_buf.clone()], [], [], []
+        for t in range(h):
+            counter += 1
+            mu, v = net.forward(ref.obs_buf)
+            a = torch.zeros(rows, 7, device="cuda")
+            sample_actions(a, mu, sigma, 9, counter, -1.0, 1.0)
+            ref.step(a)
+            obs.append(ref.obs_buf.clone()); acts.append(a); rews.append(ref.rew_buf.clone()); dns.append(ref.reset_buf.clone())
+        assert torch.equal(col.obs, torch.stack(obs)) and torch.equal(col.actions, torch.stack(acts))
+        assert torch.equal(col.rewards, torch.stack(rews)) and torch.equal(col.dones, torch.stack(dns))
+        assert bool(torch.isfinite(col.advantages).all())
+        col.next_horizon()
+    # the handle's own buffers were not written by the redirected steps, its state was
+    assert torch.equal(env.ball, ref.ball) and torch.equal(env.dof_pos, ref.dof_pos) and torch.equal(env.progress_buf, ref.progress_buf)
+    env.close(); ref.close()
