@@ -160,15 +160,16 @@ def cpu_baseline_ta(num_envs, cores, target_seconds):
             "sample": f"{steps} steps of the TA variant at num_envs={n}, OpenMP over envs in the rigid-body step, {dt:.1f} s"}
 
 
-def pmc_traffic(num_envs):
+def pmc_traffic(num_envs, variant=VARIANT):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).
-    bench.py cannot collect counters itself; null when no profile of this workload size is committed."""
+    bench.py cannot collect counters itself; null when no profile of this kernel at this workload size is committed."""
     import glob
     best = None
+    kernel = kernel_name(variant).replace(" ", "")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
         d = json.load(open(f))
-        if d.get("num_envs") == num_envs:
+        if d.get("num_envs") == num_envs and d.get("kernel", "").replace(" ", "") == kernel:
             best = d["hbm_bytes_per_launch"]
     return best
 
@@ -251,25 +252,283 @@ def rehearse(args):
     return 0
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Workloads.  A workload owns one env (and, for the rollout, the policy network), a pool of synthetic inputs resident in HBM, and
+# the HIP graphs of its launch sequence.  `step(s, slot, t)` enqueues ONE step; with `into` buffers (gather modes) step t of a
+# horizon writes its rewards / dones (/ observations) straight into the horizon-major slices [slot, t] a gather then sends.
+MFMA_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16 / bf16
+UNITS = [2048, 1536, 1024, 1024, 512, 512]     # cfg/train/HumanoidPingpongTiltG1PPO.yaml:29
+
+
+class Workload:
+    def __init__(self, variant, n, device, rank=0, world=1, rollout=False, into_depth=0, into_obs=False):
+        import torch
+        from isaacgym_amd import distributed as D
+        from isaacgym_amd import scene
+        self.torch, self.variant, self.n, self.device, self.rollout = torch, variant, n, device, rollout
+        off, cnt = D.shard_range(n * world, rank, world)   # contiguous global env ids; trajectories do not depend on the split
+        gen = torch.Generator(device=device).manual_seed(rank)
+        if variant == "TA":           # the 27-dof task on Isaac-Gym-layout tensors (ppenv_ta_step)
+            from isaacgym_amd.tensor_api import TAEnv
+            with torch.cuda.device(device):
+                self.env = TAEnv(cnt, device=device, seed=0, env_id_offset=off)
+            self.rows, self.num_act, self.num_obs = cnt, 27, 313
+        else:
+            from isaacgym_amd.env import PPEnv
+            self.env = PPEnv(scene.build_config(variant, num_envs=cnt, seed=0, device_id=device.index, env_id_offset=off), device=device)
+            self.rows, self.num_act, self.num_obs = cnt * self.env.num_agents, 7, 80
+        self.pool = [(torch.rand(self.rows, self.num_act, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
+        self.obs_buf = self.env.obs_buf
+        self.graphs = {}
+        # horizon-major output slices for the gather modes: [depth, HORIZON, rows(, num_obs)]
+        self.into = None
+        if into_depth:
+            z = lambda *shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=device)
+            self.into = {"rew": z(into_depth, HORIZON, self.rows), "done": z(into_depth, HORIZON, self.rows, dt=torch.int64),
+                         "obs": z(into_depth, HORIZON, self.rows, self.num_obs) if into_obs else None}
+        self.net = None
+        if rollout:
+            self._make_policy()
+
+    def _make_policy(self):
+        """The reference's a2c network (cfg/train/HumanoidPingpongTiltG1PPO.yaml:10-31,50-52): separate actor and critic MLPs
+        [2048, 1536, 1024, 1024, 512, 512], ELU, fixed sigma, normalize_input, mixed precision; random-initialised (no checkpoint
+        exists offline) on the hand-written MFMA forward (isaacgym_amd.policy.NativeMLP)."""
+        torch = self.torch
+        from isaacgym_amd.policy import NativeMLP
+
+        def mlp(n_out):
+            layers, d = [], self.num_obs
+            for u in UNITS:
+                layers += [torch.nn.Linear(d, u), torch.nn.ELU()]
+                d = u
+            layers.append(torch.nn.Linear(d, n_out))
+            return [(m.weight, m.bias) for m in torch.nn.Sequential(*layers) if isinstance(m, torch.nn.Linear)]
+        torch.manual_seed(0)
+        actor, critic = mlp(self.num_act), mlp(1)
+        dev = self.device
+        self.net = NativeMLP(actor, critic, self.num_obs, dev, mean=torch.zeros(self.num_obs, device=dev),
+                             var=torch.ones(self.num_obs, device=dev) - 1e-5, max_rows=self.rows)
+        self.sigma = torch.ones(self.num_act, device=dev)          # fixed_sigma, const_initializer 0 -> exp(0)
+        self.action_buf = torch.zeros(self.rows, self.num_act, device=dev)
+        self.neglogp = torch.zeros(self.rows, device=dev)
+        self.policy_flops = NativeMLP.flops(self.rows, self.num_obs, UNITS, self.num_act)
+
+    def forward(self, counter=None):
+        if counter is None:
+            return self.net.forward(self.obs_buf)
+        return self.net.forward(self.obs_buf, sample=dict(actions=self.action_buf, sigma=self.sigma, seed=0, counter=counter, neglogp=self.neglogp))
+
+    def step(self, s, slot=None, t=None):
+        kw = {}
+        if self.into is not None and slot is not None:
+            kw = dict(rew=self.into["rew"][slot, t], reset=self.into["done"][slot, t])
+            if self.into["obs"] is not None:
+                kw["obs"] = self.into["obs"][slot, t]
+        if self.rollout:
+            # normalise obs -> actor + critic forward -> heads + Normal(mu, sigma) draw + clamp + neglogp -> env.step on the drawn actions
+            # (the draw's counter is baked into a captured graph: a replay repeats its 32 counters — a throughput run, not training)
+            self.forward(counter=s + 1)
+            if "obs" in kw:       # the policy reads the env's own obs_buf; a gathered copy of the row goes to the slice
+                obs_slice = kw.pop("obs")
+                self.env.step(self.action_buf, **kw)
+                obs_slice.copy_(self.obs_buf)
+            else:
+                self.env.step(self.action_buf, **kw)
+        else:
+            self.env.step(self.pool[s & 7], **kw)
+
+    def capture(self, lengths, slots=(None,)):
+        """One HIP graph per (launch-sequence length, output slot).  Captured BEFORE any process group exists: a capture fails if
+        another thread of the process (the RCCL watchdog) touches the runtime while it is open."""
+        torch = self.torch
+        with torch.no_grad():
+            for s in range(HORIZON):       # lazy initialisation (streams, workspaces) must not happen inside the capture
+                self.step(s, slots[0], s)
+            torch.cuda.synchronize(self.device)
+            for length in lengths:
+                for slot in slots:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        for s in range(length):    # HORIZON is a multiple of the pool size: every replayed sequence is the eager one
+                            self.step(s, slot, s)
+                    self.graphs[(length, slot)] = g
+            torch.cuda.synchronize(self.device)
+
+    def kernel_region_us(self, warm, launches, regions, fn=None):
+        """Average duration of one launch sequence element: regions of back-to-back launches with nothing else on the stream,
+        bracketed by HIP events on the stream the kernels are launched on (torch's current stream); the median region."""
+        torch = self.torch
+        g = self.graphs.get((HORIZON, None)) or self.graphs.get((HORIZON, 0))
+
+        def region(k):
+            if fn is not None:
+                for _ in range(k):
+                    fn()
+            elif g is not None:
+                for _ in range(k // HORIZON):
+                    g.replay()
+            else:
+                for s in range(k):
+                    self.step(s)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.no_grad():
+            region(warm)
+            torch.cuda.synchronize(self.device)
+            out = []
+            for _ in range(regions):
+                ev0.record()
+                region(launches)
+                ev1.record()
+                torch.cuda.synchronize(self.device)
+                out.append(ev0.elapsed_time(ev1) * 1e3 / launches)
+        return sorted(out)[len(out) // 2], out
+
+    def close(self):
+        self.torch.cuda.synchronize(self.device)
+        self.graphs.clear()
+        self.env.close()
+
+
+def hbm_roofline(variant, n, kernel_us, region_us=None, region=None):
+    algo = ALGO_BYTES[variant]
+    achieved = algo * n / (kernel_us * 1e-6) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": pmc_traffic(n, variant), "kernel": kernel_name(variant), "avg_kernel_us": kernel_us,
+         "algorithmic_bytes_per_launch": algo * n}
+    if region_us is not None:
+        r["region_us"], r["region"] = region_us, region
+    return r
+
+
+def cpu_baseline_rollout(num_envs, cores, seconds=4.0):
+    """CPU row of the rollout config: the oracle's 27-dof step + the same MLP pair as a plain PyTorch fp32 forward on the host cores."""
+    import numpy as np
+    import torch
+    from isaacgym_amd import scene
+    from oracle import binding as ob
+    ob.build()
+    n = num_envs
+    torch.set_num_threads(cores)
+    cfg, model, p = scene.build_ta_scene(n), scene.build_ta_model(), scene.build_ta_params(n)
+    root = np.zeros((n, 3, 13), np.float32)
+    for a in range(3):
+        root[:, a, :7] = np.array(list(p.init_root[a]))
+    root[:, 2, 7:10] = (-5.0, 0.0, 1.5)
+    dof = np.zeros((n, 27, 2), np.float32)
+    irb = ob.ta_forward_kinematics(model, root, dof)
+    flags, episode, progress = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64)
+
+    def mlp(n_out):
+        layers, d = [], 313
+        for u in UNITS:
+            layers += [torch.nn.Linear(d, u), torch.nn.ELU()]
+            d = u
+        layers.append(torch.nn.Linear(d, n_out))
+        return torch.nn.Sequential(*layers)
+    torch.manual_seed(0)
+    actor, critic = mlp(27), mlp(1)
+    obs = torch.zeros(n, 313)
+    t0, steps = time.perf_counter(), 0
+    with torch.no_grad():
+        while True:
+            x = torch.clamp(obs, -5.0, 5.0)
+            mu = actor(x)
+            critic(x)
+            act = torch.clamp(mu + torch.randn_like(mu), -1.0, 1.0).numpy()
+            rb, frc, pvx = ob.ta_simulate(cfg, model, act, root, dof, threads=cores)
+            o, _, _ = ob.ta_post_physics_step(p, rb, irb, root, dof, frc, pvx, None, flags, episode, progress)
+            obs = torch.from_numpy(o)
+            steps += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or steps >= 200:
+                break
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} rollout steps at num_envs={n}: PyTorch fp32 MLP pair on {cores} threads + the oracle's 27-dof step, {dt:.1f} s"}
+
+
+def secondary_configs(device, only=None, cpu=True):
+    """The other single-GPU BASELINE.json configs, a few seconds each, for the same JSON line (`configs`): configs[1] 3-actor at
+    N = 4096 (T3 and TT semantics), configs[3] 4-actor tilt at its 8192 envs per GPU, configs[4] 3-actor all-dof at its 4096 envs
+    per GPU — the step alone and the rollout step incl. the native policy forward.  Each row: avg_kernel_us from event-bracketed
+    regions of back-to-back launches (3 x 320 after 128), roofline (HBM bytes for the steps, dense-fp16 MFMA flops for the
+    forward), and a bounded cpu_baseline row."""
+    import torch
+    rows = []
+    cores = usable_cores()
+    plan = [("c2_T3_4096", 2, "T3", 4096, False), ("c2_TT_4096", 2, "TT", 4096, False), ("c4_T4_8192", 4, "T4", 8192, False),
+            ("c5_TA_4096_step", 5, "TA", 4096, False), ("c5_TA_4096_rollout", 5, "TA", 4096, True)]
+    for name, cfg_no, variant, n, rollout in plan:
+        if only and name not in only:
+            continue
+        w = Workload(variant, n, device, rollout=rollout)
+        w.capture([HORIZON])
+        us, regions = w.kernel_region_us(128, 320, 3)
+        row = {"name": name, "baseline_config": f"BASELINE.json configs[{cfg_no - 1}]", "variant": variant, "num_envs": n,
+               "workload": WORKLOAD_NAMES[variant] + (", rollout step = normalise + actor/critic forward + action draw + env step" if rollout else ""),
+               "launch": f"HIP graph of {HORIZON} steps, replayed", "dtype": "f32" if not rollout else "f32 env step, f16 operands / f32 accumulation in the policy",
+               "region": "3 x 320 launches after 128 (median)"}
+        if not rollout:
+            row.update({"avg_kernel_us": us, "env_steps_per_s": n / (us * 1e-6), "agent_steps_per_s": w.rows / (us * 1e-6),
+                        "roofline": hbm_roofline(variant, n, us, regions)})
+        else:
+            fwd_us, _ = w.kernel_region_us(16, 64, 3, fn=w.forward)            # the eight launches of one forward, eager, back to back
+            tf = w.policy_flops / (fwd_us * 1e-6) / 1e12
+            step_us = rows[-1]["avg_kernel_us"] if rows and rows[-1]["name"] == "c5_TA_4096_step" else None
+            row.update({"us_per_rollout_step": us, "env_steps_per_s": n / (us * 1e-6), "us_policy_forward": fwd_us,
+                        "us_env_step_alone": step_us, "policy_gflop_per_step": w.policy_flops / 1e9,
+                        "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+                                     "traffic": None, "kernel": "mlp_layer_pp_kernel / mlp_layer_pp1_kernel (policy forward: 8 launches)",
+                                     "avg_kernel_us": fwd_us, "flops_per_launch_sequence": w.policy_flops}})
+        w.close()
+        del w
+        torch.cuda.empty_cache()
+        if cpu:
+            try:
+                row["cpu_baseline"] = cpu_baseline_rollout(256, cores) if rollout else cpu_baseline(n, target_seconds=2.5, variant=variant)
+            except Exception as e:   # noqa: BLE001 - a CPU row must not cost the GPU rows
+                row["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        rows.append(row)
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs per GPU")
+    ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default 16384; 4096 for --workload rollout)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", default=VARIANT, choices=["TT", "TN", "T3", "T4", "TA"],
+    ap.add_argument("--variant", default=None, choices=["TT", "TN", "T3", "T4", "TA"],
                     help="task variant; the headline workload is TT (BASELINE.json configs[2]), the others are parity-test cases")
+    ap.add_argument("--workload", default="step", choices=["step", "rollout"],
+                    help="step (default): the fused env step on synthetic actions, the BASELINE metric.  rollout: BASELINE configs[4]'s per-GPU "
+                         "slice — the 27-dof env step driven by the native policy forward (4096 envs per GPU), weak-scaled by --gpus N like the step")
+    ap.add_argument("--gather", default="none", choices=["none", "rew", "obs"],
+                    help="the north star's episodic RCCL gather for a central learner (isaacgym_amd.distributed.RolloutGather): rew = rewards + dones of "
+                         "every horizon, once per horizon; obs = also every step's observation rows, once per step (eager launches).  Asynchronous, two "
+                         "rotating slots.  none (default): data-parallel learners, the reference's own mode — no data-path collective")
+    ap.add_argument("--gather-pad", type=int, default=0, help="pad every shard to at least this many rows (exercises the ragged path with one rank)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph of one horizon")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary BASELINE configs (`configs` in the JSON line); they run at N=1 only")
+    ap.add_argument("--only-config", action="append", default=None,
+                    help="run only this secondary config (name as in `configs`; repeatable) and print its row(s) alone — for profiling one at a time")
     ap.add_argument("--rehearse", action="store_true",
                     help="CPU rehearsal of the rank plumbing only (launch, rendezvous, barrier, max-over-ranks, rank-0 line): no env is "
                          "created and nothing is measured; used by tests/test_bench_launch.py")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm launches before the W warm-up steps")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL (default); gloo only to rehearse the rank logic on one GPU")
     ap.add_argument("--force-dist", action="store_true",
-                    help="create the process group and issue the per-horizon all-reduces even with ONE rank: the RCCL code path (communicator "
-                         "init with device_id, asynchronous float64 all-reduce beside the graph replays, barrier, max-reduce) on a one-GPU box")
+                    help="create the process group and issue the per-horizon all-reduces (and gathers) even with ONE rank: the RCCL code path "
+                         "(communicator init with device_id, asynchronous collectives beside the graph replays, barrier, max-reduce) on a one-GPU box")
     args = ap.parse_args()
+    rollout = args.workload == "rollout"
+    if args.variant is None:
+        args.variant = "TA" if rollout else VARIANT
+    if args.num_envs is None:
+        args.num_envs = 4096 if rollout else NUM_ENVS
+    if rollout and args.variant == "T4":
+        sys.exit("--workload rollout drives one policy row per env: variants TA (BASELINE configs[4]) or TT / TN / T3")
 
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
@@ -283,9 +542,8 @@ def main():
         sys.exit(rehearse(args))
 
     import torch
-    from isaacgym_amd import _lib, scene
+    from isaacgym_amd import _lib
     from isaacgym_amd import distributed as D
-    from isaacgym_amd.env import PPEnv
 
     if not os.path.exists(_lib.LIB_PATH):      # a checkout without the built library (it is git-ignored): local rank 0 compiles it, the others wait
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -310,35 +568,22 @@ def main():
     device = torch.device("cuda", local_rank % max(ndev, 1))   # the modulo only matters for the gloo rehearsal
     torch.cuda.set_device(device)
 
-    n = args.num_envs
-    off, cnt = D.shard_range(n * world, rank, world)   # contiguous global env ids; trajectories do not depend on the split
-    gen = torch.Generator(device=device).manual_seed(rank)
-    if args.variant == "TA":           # the 27-dof task: rigid-body kernel + task kernel on Isaac-Gym-layout tensors
-        from isaacgym_amd.tensor_api import TAEnv
-        with torch.cuda.device(device):
-            env = TAEnv(cnt, device=device, seed=0, env_id_offset=off)
-        pool = [(torch.rand(n, 27, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
-    else:
-        env = PPEnv(scene.build_config(args.variant, num_envs=cnt, seed=0, device_id=device.index, env_id_offset=off), device=device)
-        pool = [(torch.rand(n * env.num_agents, 7, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
+    if args.only_config:
+        rows = secondary_configs(device, only=set(args.only_config), cpu=not args.no_cpu_baseline)
+        print(json.dumps({"configs": rows}), flush=True)
+        return
 
-    # The graph is captured BEFORE the process group exists: a capture fails if another thread of the process (the RCCL
-    # watchdog) touches the runtime while it is open.
-    graphs = {}
-    if not args.no_graph:
-        for s in range(HORIZON):           # lazy initialisation (streams, workspaces) must not happen inside the capture
-            env.step(pool[s & 7])
-        torch.cuda.synchronize(device)
+    n = args.num_envs
+    gather = args.gather != "none"
+    per_step_gather = args.gather == "obs"
+    use_graph = not args.no_graph and not per_step_gather     # a per-step collective sits between the launches: eager
+    GSLOTS = 2
+    w = Workload(args.variant, n, device, rank=rank, world=world, rollout=rollout, into_depth=GSLOTS if gather else 0, into_obs=per_step_gather)
+    env = w.env
+    if use_graph:
         # one graph per launch-sequence length in use: the horizon, and what --warmup / --steps leave over after whole horizons
-        # (a driver that asks for fewer steps than a horizon still gets device-paced launches)
-        for length in sorted({HORIZON, args.warmup % HORIZON, args.steps % HORIZON} - {0}):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                for s in range(length):    # HORIZON is a multiple of the pool size: every replayed sequence is the eager one
-                    env.step(pool[s & 7])
-            graphs[length] = g
-        torch.cuda.synchronize(device)
-    graph = graphs.get(HORIZON)
+        # (a driver that asks for fewer steps than a horizon still gets device-paced launches); per output slot in the gather modes
+        w.capture(sorted({HORIZON, args.warmup % HORIZON, args.steps % HORIZON} - {0}), slots=tuple(range(GSLOTS)) if gather else (None,))
 
     if dist is not None:
         if args.dist_backend == "nccl":
@@ -347,32 +592,53 @@ def main():
             dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
     # what the reference prints every 40 steps (TT:763-766) + finished episodes; all-reduced over the ranks
     stats = D.AsyncHorizonStats(env, force=args.force_dist) if args.variant != "TA" else None
+    rg = D.RolloutGather(w.rows, device, depth=GSLOTS, force=args.force_dist, pad_to=args.gather_pad) if gather else None
+    hz = [0]        # horizons issued: picks the output slot
 
-    def horizon_stats():
+    def slot_now():
+        return (hz[0] % GSLOTS) if gather else None
+
+    def horizon_done():
         if stats is not None:
             stats.push()               # one reduction launch + one asynchronous 4-double all-reduce over RCCL
+        if rg is not None:             # rewards + dones of the finished horizon: two asynchronous all-gathers into slot hz % 2
+            sl = slot_now()
+            rg.push(sl, [w.into["rew"][sl], w.into["done"][sl]], env_dims=[1, 1])
+            hz[0] += 1
+            rg.wait(slot_now())        # the slot the next horizon writes into: its previous gathers must have read it
 
+    obs_rg = D.RolloutGather(w.rows, device, depth=4, force=args.force_dist, pad_to=args.gather_pad) if per_step_gather else None
+    obs_calls = [0]
+
+    def eager_step(s):
+        sl, t = slot_now(), s % HORIZON
+        w.step(s, sl, t)
+        if obs_rg is not None:         # every step's observation rows: one asynchronous all-gather per step
+            obs_rg.push(obs_calls[0] % 4, [w.into["obs"][sl, t]])
+            obs_calls[0] += 1
+
+    @torch.no_grad()
     def run(k):
         done = 0
-        if graph is not None:
+        if use_graph:
             for _ in range(k // HORIZON):
-                graph.replay()
-                horizon_stats()
+                w.graphs[(HORIZON, slot_now())].replay()
+                horizon_done()
             done = (k // HORIZON) * HORIZON
-            if k - done in graphs:
-                graphs[k - done].replay()
+            if (k - done, slot_now()) in w.graphs:
+                w.graphs[(k - done, slot_now())].replay()
                 done = k
         for s in range(done, k):
-            env.step(pool[s & 7])
+            eager_step(s)
             if (s + 1) % HORIZON == 0:
-                horizon_stats()
+                horizon_done()
 
     if not args.no_prewarm:
         # Setup, like the graph capture above: PREWARM launches so that a short run (the driver's --steps 20 --warmup 5 is one
         # 0.3 ms graph replay) is not a measurement of the clock ramp.  Not counted in `warmup`; the W warm-up steps follow.
         for _ in range(PREWARM // HORIZON):
-            if graph is not None:
-                graph.replay()
+            if use_graph:
+                w.graphs[(HORIZON, slot_now())].replay()
             else:
                 run(HORIZON)
         torch.cuda.synchronize(device)
@@ -401,35 +667,62 @@ def main():
     # bracketed by HIP events on the stream the kernel is launched on (torch's current stream).  The region does not depend on
     # --steps / --warmup: ROOFLINE_WARM launches to settle the clocks, then ROOFLINE_REGIONS regions of ROOFLINE_LAUNCHES
     # launches each; the median region is reported (profiles/*_kernel_stats.csv is the same command under rocprofv3).
-    def region(k):
-        if graph is not None:
-            for _ in range(k // HORIZON):
-                graph.replay()
-        else:
-            for s in range(k):
-                env.step(pool[s & 7])
-    region(ROOFLINE_WARM)
-    torch.cuda.synchronize(device)
-    region_us = []
-    for _ in range(ROOFLINE_REGIONS):
-        ev0.record()
-        region(ROOFLINE_LAUNCHES)
-        ev1.record()
-        torch.cuda.synchronize(device)
-        region_us.append(ev0.elapsed_time(ev1) * 1e3 / ROOFLINE_LAUNCHES)
-    kernel_us = sorted(region_us)[len(region_us) // 2]
-    horizon_stats()
+    if rg is not None:
+        for sl in range(GSLOTS):
+            rg.wait(sl)
+    if obs_rg is not None:
+        for sl in range(4):
+            obs_rg.wait(sl)
+    kernel_us, region_us = w.kernel_region_us(ROOFLINE_WARM, ROOFLINE_LAUNCHES, ROOFLINE_REGIONS)
+    fwd_us = None
+    if rollout:
+        fwd_us, _ = w.kernel_region_us(32, 96, 5, fn=w.forward)
+    gather_info = None
+    if gather:
+        # the collectives' own cost, blocking, on an otherwise idle device: issue + completion of one horizon's (one step's) gathers
+        def one_call(g_, tensors, dims):
+            g_.push(0, tensors, env_dims=dims)
+            g_.wait(0)
+            torch.cuda.synchronize(device)
+        per = {}
+        for label, g_, tensors, dims in (("horizon_rew_done", rg, [w.into["rew"][0], w.into["done"][0]], [1, 1]),) + \
+                ((("step_obs", obs_rg, [w.into["obs"][0, 0]], [0]),) if per_step_gather else ()):
+            one_call(g_, tensors, dims)
+            tc = time.perf_counter()
+            for _ in range(20):
+                one_call(g_, tensors, dims)
+            per[label] = {"us_per_call_blocking": (time.perf_counter() - tc) / 20 * 1e6,
+                          "bytes_sent_per_rank_per_call": sum(x.numel() * x.element_size() for x in tensors),
+                          "bytes_received_per_rank_per_call": sum(x.numel() * x.element_size() for x in tensors) * rg.world}
+        bytes_per_step = per["horizon_rew_done"]["bytes_sent_per_rank_per_call"] / HORIZON + (per["step_obs"]["bytes_sent_per_rank_per_call"] if per_step_gather else 0)
+        gather_info = {"mode": args.gather, "backend": args.dist_backend if dist is not None else "none (one rank, local copy)", "ranks": rg.world,
+                       "shard_rows": rg.counts, "padded_rows": rg.m, "ragged": rg.ragged, "bytes_per_step_per_rank": bytes_per_step,
+                       "horizon_gathers_issued": hz[0], "step_gathers_issued": obs_calls[0], "collectives": per,
+                       "what": "asynchronous all_gather_into_tensor per tensor into rank-major buffers, two rotating slots; rewards + dones "
+                               "[32, rows] once per horizon" + ("; observation rows [rows, num_obs] once per step" if per_step_gather else "")}
     if stats is not None:
+        stats.push()
         final_stats = stats.latest().cpu().tolist()
     else:
         final_stats = [float(env.rew_buf.mean()), float(env.progress_buf.float().mean()), float(env.state.episode.sum())]
 
     if rank == 0:
         total_env_steps = n * world * args.steps
-        algo_bytes = ALGO_BYTES[args.variant]
-        achieved = algo_bytes * n / (kernel_us * 1e-6) / 1e9
+        if not rollout:
+            roof = hbm_roofline(args.variant, n, kernel_us, region_us, f"{ROOFLINE_REGIONS} x {ROOFLINE_LAUNCHES} launches after {ROOFLINE_WARM} (median)")
+            roof["timed_region_us_per_step"] = dev_ms * 1e3 / args.steps
+            metric = "env-steps/sec at N_envs=16384 (1/2/4/8 GPUs) + achieved HBM GB/s vs roofline"
+            what = "random U(-1,1) actions, 2 physics substeps per step, fused step kernel"
+        else:
+            tf = w.policy_flops / (fwd_us * 1e-6) / 1e12
+            roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None,
+                    "kernel": "mlp_layer_pp_kernel / mlp_layer_pp1_kernel (policy forward: 8 launches)", "avg_kernel_us": fwd_us,
+                    "flops_per_launch_sequence": w.policy_flops, "us_per_rollout_step_region": kernel_us, "region_us": region_us,
+                    "timed_region_us_per_step": dev_ms * 1e3 / args.steps}
+            metric = "env-steps/sec incl. policy forward (BASELINE.json configs[4] per-GPU slice: 3-actor all-dof + native policy forward)"
+            what = "rollout step = normalise obs + actor/critic MLP forward (MFMA) + Normal(mu, sigma) draw + fused env step"
         out = {
-            "metric": "env-steps/sec at N_envs=16384 (1/2/4/8 GPUs) + achieved HBM GB/s vs roofline",
+            "metric": metric,
             "value": total_env_steps / wall,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -441,29 +734,30 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"humanoid_pingpong {WORKLOAD_NAMES[args.variant]}, num_envs={n} per GPU, "
-                                   "random U(-1,1) actions, 2 physics substeps per step, fused step kernel",
-                       "variant": args.variant,
+            "config": {"workload": f"humanoid_pingpong {WORKLOAD_NAMES[args.variant]}, num_envs={n} per GPU, {what}",
+                       "variant": args.variant, "kind": args.workload,
                        "num_envs_per_gpu": n, "global_envs": n * world, "horizon_stats_every": HORIZON,
                        "prewarm_launches": 0 if args.no_prewarm else PREWARM,
-                       "launch": "eager" if graph is None else f"HIP graph of {HORIZON} steps, replayed",
-                       "parallelism": f"env-shard x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(n) if args.variant == VARIANT else None, "kernel": kernel_name(args.variant), "avg_kernel_us": kernel_us, "region_us": region_us,
-                         "region": f"{ROOFLINE_REGIONS} x {ROOFLINE_LAUNCHES} launches after {ROOFLINE_WARM} (median)",
-                         "timed_region_us_per_step": dev_ms * 1e3 / args.steps,
-                         "algorithmic_bytes_per_launch": algo_bytes * n},
+                       "launch": "eager" if not use_graph else f"HIP graph of {HORIZON} steps, replayed",
+                       "parallelism": f"env-shard x{world}, " + ("no data-path collective" if not gather else f"RCCL all-gather ({args.gather}) for a central learner")},
+            "roofline": roof,
             "episode_stats": {"mean_reward_last_step": final_stats[0], "mean_progress": final_stats[1],
                               "episodes_finished": final_stats[2]},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n, variant=args.variant)
-            if args.variant == VARIANT:
-                out["cpu_baseline_rows"] = cpu_baseline_rows(out["cpu_baseline"]["cores"])
-        print(json.dumps(out), flush=True)
-    env.close()
+        if gather_info is not None:
+            out["gather"] = gather_info
+    w.close()
     if dist is not None:
         dist.barrier()
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_rollout(256, usable_cores()) if rollout else cpu_baseline(n, variant=args.variant)
+            if args.variant == VARIANT and not rollout:
+                out["cpu_baseline_rows"] = cpu_baseline_rows(out["cpu_baseline"]["cores"])
+        if world == 1 and not args.no_configs and not rollout and args.variant == VARIANT and not gather and dist is None:
+            out["configs"] = secondary_configs(device, cpu=not args.no_cpu_baseline)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -86,20 +86,94 @@ def horizon_stats(rew_buf, progress_buf, episode, group=None):
     return torch.stack([s[0] / s[3], s[1] / s[3], s[2]])
 
 
-def gather_rollout(local, group=None):
+def gather_rollout(local, group=None, force=False, pad_to=None):
     """All-gather a per-rank tensor whose dim 0 is the env dim into the global tensor, in global env order.
-    Ranks may own different counts (shard_range); ragged shards are padded to the largest and trimmed."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    Ranks may own different counts (shard_range); ragged shards are padded to the largest and trimmed.
+    force: issue the collective even in a one-rank group (the RCCL path on a one-GPU box); pad_to: pad every shard to at least
+    this many rows before the collective (with one rank: exercises the ragged path — pad, gather, trim)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     counts = torch.zeros(world, dtype=torch.int64, device=local.device)
     counts[dist.get_rank(group)] = local.shape[0]
     dist.all_reduce(counts, group=group)
     counts = counts.tolist()
-    m = max(counts)
+    m = max(max(counts), int(pad_to or 0))
     padded = local
     if local.shape[0] < m:
         padded = torch.cat([local, local.new_zeros((m - local.shape[0],) + tuple(local.shape[1:]))])
     out = local.new_empty((world * m,) + tuple(local.shape[1:]))
     dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
     return torch.cat([out[r * m: r * m + counts[r]] for r in range(world)])
+
+
+class RolloutGather:
+    """The north star's "episodic RCCL gather of obs/reward" for a central learner, without a host synchronisation and
+    without making the step stream wait: shard sizes are exchanged ONCE (they are static: shard_range), every later call is one
+    asynchronous all_gather_into_tensor per tensor into a preallocated rank-major buffer, joined only when its slot comes round
+    again (`depth` rotating slots, like AsyncHorizonStats) or in `result()`.
+
+    A tensor's env dim is `env_dim` (0 for per-step tensors [n, ...], 1 for horizon-major ones [H, n, ...]).  Ragged shards: the
+    send buffer is the slot's own padded staging tensor [.., m, ..] (m = the largest shard); equal shards are sent in place.
+    `result(slot, i)` returns tensor i in GLOBAL env order ([.., sum(counts), ..]): a view of the receive buffer when the layout
+    allows (per-step tensors of equal shards), else one gather copy."""
+
+    def __init__(self, count, device, group=None, depth=2, force=False, pad_to=None):
+        self.group, self.depth, self.device = group, int(depth), torch.device(device)
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        c = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        c[self.rank] = int(count)
+        if self.active:
+            dist.all_reduce(c, group=group)
+        self.counts = [int(x) for x in c.tolist()]           # once, at construction: the only host read of this class
+        self.m = max(max(self.counts), int(pad_to or 0))
+        self.ragged = any(x != self.m for x in self.counts)
+        self.slots = [None] * self.depth                     # per slot: list of (recv, staging or None, env_dim)
+        self.works = [[] for _ in range(self.depth)]
+        self.bytes_sent = 0
+
+    def _buffers(self, slot, tensors, env_dims):
+        if self.slots[slot] is None:
+            bufs = []
+            for t, ed in zip(tensors, env_dims):
+                shape = list(t.shape)
+                shape[ed] = self.m
+                recv = torch.empty([self.world] + shape, dtype=t.dtype, device=self.device)
+                stage = torch.zeros(shape, dtype=t.dtype, device=self.device) if t.shape[ed] != self.m else None
+                bufs.append((recv, stage, ed))
+            self.slots[slot] = bufs
+        return self.slots[slot]
+
+    def push(self, slot, tensors, env_dims=None):
+        """Issue the gathers of `tensors` (this rank's shard of each) into slot `slot`; returns immediately."""
+        env_dims = [0] * len(tensors) if env_dims is None else list(env_dims)
+        self.wait(slot)
+        for t, (recv, stage, ed) in zip(tensors, self._buffers(slot, tensors, env_dims)):
+            send = t
+            if stage is not None:                            # ragged: pad this rank's shard to the largest
+                stage.narrow(ed, 0, t.shape[ed]).copy_(t)
+                send = stage
+            send = send if send.is_contiguous() else send.contiguous()
+            self.bytes_sent += send.numel() * send.element_size()
+            if self.active:
+                self.works[slot].append(dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group, async_op=True))
+            else:
+                recv[0].copy_(send)
+
+    def wait(self, slot):
+        for w in self.works[slot]:
+            w.wait()
+        self.works[slot] = []
+
+    def result(self, slot, i):
+        """Tensor i of slot `slot` in global env order."""
+        self.wait(slot)
+        recv, _, ed = self.slots[slot][i]                    # [world, .., m, ..]
+        parts = [recv[r].narrow(ed, 0, self.counts[r]) for r in range(self.world)]
+        if self.world == 1:
+            return parts[0]
+        if ed == 0 and not self.ragged:
+            return recv.reshape((self.world * self.m,) + tuple(recv.shape[2:]))
+        return torch.cat(parts, dim=ed)

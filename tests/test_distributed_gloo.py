@@ -170,3 +170,51 @@ def test_two_rank_sharding_of_the_two_agent_and_27dof_tasks(oracle_lib, tmp_path
     want = scene.ta_reset_draws(p, torch.arange(N4), torch.zeros(N4, dtype=torch.int64)).numpy()
     np.testing.assert_array_equal(got["draws"], want)
     assert (want[:, 0] >= -0.5).all() and (want[:, 0] <= 0.1).all() and (want[:, 2] < -4.0).all()   # TA:133-134, serve towards the humanoid
+
+
+# ---- the episodic gather for a central learner (RolloutGather): horizon-major rewards / dones, per-step observation rows ------
+def _gather_worker(rank, world, port, out_dir, n_global):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from isaacgym_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    off, cnt = D.shard_range(n_global, rank, world)
+    H = 4
+    g = D.RolloutGather(cnt, "cpu", depth=2)
+    assert g.counts == [D.shard_range(n_global, r, world)[1] for r in range(world)] and g.ragged == (n_global % world != 0)
+    ids = torch.arange(off, off + cnt)
+    got = {}
+    for hz in range(3):                                   # three horizons through two slots
+        slot = hz % 2
+        rew = (1000.0 * hz + 10.0 * torch.arange(H)[:, None] + ids[None, :].float() / 1000)          # [H, cnt]
+        done = (ids[None, :] + torch.arange(H)[:, None] + hz).to(torch.int64)                        # [H, cnt]
+        obs = (ids[:, None].float() + torch.arange(5)[None, :] / 10 + hz)                            # [cnt, 5]
+        g.push(slot, [rew, done, obs], env_dims=[1, 1, 0])
+        got[hz] = [g.result(slot, i).clone() for i in range(3)]
+    if rank == 0:
+        torch.save(got, os.path.join(out_dir, f"gather_{n_global}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global", [12, 13])            # equal shards (views of the receive buffer) and ragged ones (7 + 6)
+def test_rollout_gather_two_ranks(tmp_path, n_global):
+    mp.spawn(_gather_worker, args=(2, _free_port(), str(tmp_path), n_global), nprocs=2, join=True)
+    got = torch.load(tmp_path / f"gather_{n_global}.pt")
+    ids, H = torch.arange(n_global), 4
+    for hz in range(3):
+        rew, done, obs = got[hz]
+        assert rew.shape == (H, n_global) and done.shape == (H, n_global) and obs.shape == (n_global, 5) and done.dtype == torch.int64
+        torch.testing.assert_close(rew, 1000.0 * hz + 10.0 * torch.arange(H)[:, None] + ids[None, :].float() / 1000, rtol=0, atol=0)
+        assert torch.equal(done, (ids[None, :] + torch.arange(H)[:, None] + hz).to(torch.int64))
+        torch.testing.assert_close(obs, ids[:, None].float() + torch.arange(5)[None, :] / 10 + hz, rtol=0, atol=0)
+
+
+def test_rollout_gather_single_process_is_a_local_copy_and_pads():
+    from isaacgym_amd import distributed as D
+    g = D.RolloutGather(5, "cpu", depth=2, pad_to=8)      # no process group: the padded staging path alone
+    assert g.counts == [5] and g.m == 8 and g.ragged
+    x = torch.arange(15.0).view(3, 5)
+    g.push(1, [x], env_dims=[1])
+    assert torch.equal(g.result(1, 0), x)
+    assert g.bytes_sent == 3 * 8 * 4

@@ -59,20 +59,20 @@ def test_post_physics_matches_reference_golden(torch_cuda, variant):
     env.close()
 
 
-@pytest.mark.parametrize("variant", ["TT", "TN", "T3"])
-def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant):
-    """The fused step kernel vs the oracle, both restarted from the oracle's state every step."""
+@pytest.mark.parametrize("variant,n", [("TT", 1024), ("TN", 1024), ("T3", 1024), ("TT", 4096), ("T3", 4096)])
+def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant, n):
+    """The fused step kernel vs the oracle, both restarted from the oracle's state every step.  (TT / T3 at 4096 envs: BASELINE.json
+    configs[1] as named — "3-actor, num_envs=4096 on 1 MI355X, fp32, random actions, obs/reward parity".)"""
     torch = torch_cuda
-    n = 1024
     cfg = scene.build_config(variant, num_envs=n, seed=7)
     o = oracle_lib.OracleEnv(cfg, threads=8)
     env = make_env(scene.build_config(variant, num_envs=n, seed=7))
     rng = np.random.default_rng(1)
     oa, ra = obs_atol(), reward_atol(cfg)
-    steps = 180 if variant == "TN" else 120
+    steps = 180 if variant == "TN" else (120 if n <= 1024 else 90)
     resets = 0
     probe = SensitivityProbe(oracle_lib, cfg)
-    log = ExclusionLog(f"gpu fused step vs oracle [{variant}]", bound=0.005)
+    log = ExclusionLog(f"gpu fused step vs oracle [{variant}, n={n}]", bound=0.005)
     for t in range(steps):
         actions = rng.uniform(-1.2, 1.2, (n, 7)).astype(np.float32)
         st = o.get_state()

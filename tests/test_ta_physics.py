@@ -31,6 +31,21 @@ TOL = dict(root_pos=1e-4 * 1.0, root_quat=2e-4, root_vel=5e-4 * 10.0, q=1e-4 * 3
            rb_vel=5e-4 * 20.0, rb_ang=5e-4 * 100.0)   # a link's angular velocity stacks up to seven joint rates of <= 37 rad/s
 
 
+def ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root_after, rel=1e-6, seed=7):
+    """Envs whose ball sits on a switch of the contact model in this step, decided by the ORACLE alone (as helpers.SensitivityProbe
+    does for the 7-dof tasks): two more oracle steps from the same state with the continuous inputs jittered by `rel`; an env whose
+    oracle ball velocity moves by more than 1e-3 m/s under that jitter took a discrete decision (contact on / off, bounce threshold)
+    that fp32 and fp64 may legitimately take differently.  -> bool [N], True = on a switch."""
+    rng = np.random.default_rng(seed)
+    bad = np.zeros(root0.shape[0], bool)
+    for _ in range(2):
+        r2 = (root0 * (1.0 + rel * rng.uniform(-1, 1, root0.shape))).astype(np.float32)
+        d2 = (dof0 * (1.0 + rel * rng.uniform(-1, 1, dof0.shape))).astype(np.float32)
+        oracle_lib.ta_simulate(cfg, m, act, r2, d2, threads=8)
+        bad |= np.abs(r2[:, 2, 7:10] - root_after[:, 2, 7:10]).max(axis=1) > 1e-3
+    return bad
+
+
 def check_step(got, want, what):
     (root_g, dof_g, rb_g, frc_g), (root_w, dof_w, rb_w, frc_w) = got, want
     assert_close(root_g[..., 0:3], root_w[..., 0:3], f"{what}: root pos", atol=TOL["root_pos"])
@@ -115,11 +130,12 @@ def test_kernel_arithmetic_matches_oracle_single_steps(oracle_lib):
             act = rng.uniform(-1.2, 1.2, (n, 27)).astype(np.float32)
             act[: n // 3] *= 0.1                                           # a third of the envs moves gently
         r2, d2 = root.copy(), dof.copy()
+        root0, dof0 = root.copy(), dof.copy()
         rb, frc, pvx = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=8)
         rb2, frc2, pvx2 = sb.ta_simulate(cfg, m, act, r2, d2)
         contacts += int((rb[:, :40, 2].min(axis=1) < scene.TA_GROUND_Z + 0.05).sum())
         np.testing.assert_array_equal(pvx2, pvx)
-        hit = np.abs(r2[:, 2, 7:10] - root[:, 2, 7:10]).max(axis=1) > 1e-3     # ball contact decided differently (discrete, as in the 3-actor scenes)
+        hit = ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root, seed=t)   # the ball's discrete contact decisions, by the oracle's own sensitivity
         ball_flips += int(hit.sum())
         check_step((r2[~hit], d2[~hit], rb2[~hit], frc2[~hit]), (root[~hit], dof[~hit], rb[~hit], frc[~hit]), f"step {t}")
     assert ball_flips <= 3 and contacts > n * 60
@@ -161,17 +177,18 @@ def test_ta_simulate_kernel_matches_oracle(oracle_lib, monkeypatch, mapping, n):
     # forward kinematics entry (initial_body_states of TA:1152)
     sim.forward_kinematics(dev(root), dev(dof), rb_d)
     assert_close(rb_d.cpu().numpy()[..., :3], oracle_lib.ta_forward_kinematics(m, root, dof)[..., :3], "fk pos", atol=1e-5)
-    log = ExclusionLog(f"gpu 27-dof rigid-body step vs oracle [{mapping}, n={n}]", bound=5 / (120 * n))
+    log = ExclusionLog(f"gpu 27-dof rigid-body step vs oracle [{mapping}, n={n}]", bound=0.005)
     for t in range(120):
         if t % 4 == 0:
             act = rng.uniform(-1.2, 1.2, (n, 27)).astype(np.float32)
             act[: n // 3] *= 0.1
         root_d, dof_d = dev(root), dev(dof)
         sim.simulate(dev(act), root_d, dof_d, rb_d, frc_d, pvx_d)
+        root0, dof0 = root.copy(), dof.copy()
         rb, frc, pvx = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=8)
         np.testing.assert_array_equal(pvx_d.cpu().numpy(), pvx)
         rg = root_d.cpu().numpy()
-        keep = ~(np.abs(rg[:, 2, 7:10] - root[:, 2, 7:10]).max(axis=1) > 1e-3)   # ball contact decided differently (discrete)
+        keep = ~ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root, seed=100 + t)   # the oracle's own sensitivity, not the GPU's error
         log.add(keep)
         got = (rg[keep], dof_d.cpu().numpy()[keep], rb_d.cpu().numpy()[keep], frc_d.cpu().numpy()[keep])
         check_step(got, (root[keep], dof[keep], rb[keep], frc[keep]), f"step {t}")
@@ -283,7 +300,7 @@ def test_ta_chain_kernel_step_matches_oracle(oracle_lib, monkeypatch, n):
     flags, episode, progress = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64)
     rng = np.random.default_rng(5)
     oa = _ta_obs_atol()
-    log = ExclusionLog(f"gpu 27-dof chain-wave step vs oracle [n={n}]", bound=20 / (90 * n))
+    log = ExclusionLog(f"gpu 27-dof chain-wave step vs oracle [n={n}]", bound=0.005)
     resets = 0
     act = None
     for t in range(90):
@@ -294,14 +311,14 @@ def test_ta_chain_kernel_step_matches_oracle(oracle_lib, monkeypatch, n):
         env.state.flags.copy_(torch.from_numpy(flags.view(np.int32))); env.state.episode.copy_(torch.from_numpy(episode.view(np.int32)))
         env.state.progress_buf.copy_(torch.from_numpy(progress))
         env.step(torch.from_numpy(act).cuda())
-        ball_before = root[:, 2, 7:10].copy()
+        root0, dof0 = root.copy(), dof.copy()
         rb, frc, pvx = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=8)         # root / dof: stepped in place (pre-reset)
-        pre_root, pre_dof = root.copy(), dof.copy()
+        switch = ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root, seed=200 + t)
         obs, rew, reset = oracle_lib.ta_post_physics_step(p, rb, irb, root, dof, frc, pvx, None, flags, episode, progress)
         g_rb = env._rb_states.cpu().numpy()
         np.testing.assert_array_equal(env.pre_ball_vx.cpu().numpy(), pvx)
-        # the ball's contact decisions are discrete: an env whose stepped ball differs took another branch (cf. the quad test above)
-        keep = ~(np.abs(g_rb[:, 41, 7:10] - rb[:, 41, 7:10]).max(axis=1) > 1e-3)
+        # the ball's contact decisions are discrete: envs whose ORACLE result moves under a 1e-6 jitter are set aside for this step
+        keep = ~switch
         log.add(keep)
         # pre-reset physics through the materialised rigid_body_states; post-reset tensors against the oracle's
         assert_close(g_rb[keep][..., 0:3], rb[keep][..., 0:3], f"step {t}: body pos", atol=TOL["rb_pos"])
