@@ -19,6 +19,7 @@
 #include <new>
 
 using std::min;
+using std::max;
 
 #ifndef PP_ABLATE
 #define PP_ABLATE 0
@@ -34,7 +35,8 @@ namespace {
 
 constexpr int kBlock = 64;   // exactly one wave per workgroup: step_kernel relies on it (no barrier around its LDS tile)
 constexpr int kObsStride = PPENV_NUM_OBS + 1;   // +1 float: lanes write LDS rows bank-conflict-free
-constexpr int kMaxSplitSubsteps = 4;            // the multi-wave step kernels keep one LDS hand-off slot per substep boundary
+constexpr int kMaxSplitSubsteps = 4;
+constexpr int kDefaultBallWaves = 1;            // ball waves per 64 envs (PPENV_BALL_WAVES overrides; see step_kernel_split's BW)            // the multi-wave step kernels keep one LDS hand-off slot per substep boundary
 
 struct DevBuffers {
     float* obs;
@@ -334,9 +336,15 @@ struct MovingGeom {
 // arm wave's start-of-substep sweep is the world-space one and hands its geometry to the ball wave through two alternating
 // LDS slots; the ball wave is left with the contacts.  (Tried and dropped: separate geometry waves — five waves on four
 // SIMDs slow each other more than the hand-off saves.)
-template <class T, int A, int G>
-__global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on,
+// BW = ball waves per 64 envs (round 3).  What a ball wave pays per micro-step is the UNION of its lanes' contact branches (DESIGN.md §6:
+// 250-420 instructions where a ball in free flight needs 40, because with 64 envs in a wave some lane is near nearly every shape).  At
+// N = 16384 half of the chip's SIMDs have no wave at all, so the 64 envs of a workgroup can be dealt to BW ball waves of 64 / BW envs
+// each (the upper lanes idle): fewer lanes per wave = a smaller union = a shorter chain, on SIMDs that were empty anyway.  The arm wave
+// keeps all 64 envs (its instruction stream has no divergence to shrink).
+template <class T, int A, int G, int BW = 1>
+__global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on,
                                                                        uint32_t* status, int dbg_drop_handoff) {
+    static_assert(BW == 1 || G == 0, "narrow ball waves: each sweeps its own geometry (the s_bflag slot protocol has one consumer)");
     constexpr int kGeo = MovingGeom<T>::count();
     // Who writes dof_pos / dof_vel / dof_force.  With one humanoid the arm wave is the critical path and would sit waiting
     // for the ball wave's reset decision just to pick between q and the initial pose: the ball wave, which has both, stores
@@ -455,8 +463,13 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         return;
     }
 
-    // ---------------------------------------------------------------------- ball wave
+    // ---------------------------------------------------------------------- ball wave(s)
     PP_STAMP_AT(16);
+    constexpr int EB = kBlock / BW;                 // envs per ball wave
+    const int bw = wave - A;                        // which of the BW ball waves
+    const int env = bw * EB + lane;                 // this lane's env within the workgroup (lanes >= EB of a narrow ball wave idle)
+    const int bi = base + env;
+    const bool bactive = lane < EB && bi < n;
     EnvStateT<A> st;
     float rew[A], pre_vx = 0.f;
     long long reset = 0;
@@ -466,23 +479,23 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     float qs[A * ND], qds[A * ND];
 #pragma unroll
     for (int a = 0; a < A; a++) rew[a] = 0.f;
-    if (active) {
+    if (bactive) {
         if (!G) {
 #pragma unroll
-            for (int d = 0; d < A * ND; d++) { qs[d] = b.dof_pos[(size_t)d * n + i]; qds[d] = b.dof_vel[(size_t)d * n + i]; }
+            for (int d = 0; d < A * ND; d++) { qs[d] = b.dof_pos[(size_t)d * n + bi]; qds[d] = b.dof_vel[(size_t)d * n + bi]; }
         }
         float bl[13];
 #pragma unroll
-        for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + i];
+        for (int k = 0; k < 13; k++) bl[k] = b.ball[(size_t)k * n + bi];
         st.ball.p = mk(bl[0], bl[1], bl[2]);
 #pragma unroll
         for (int k = 0; k < 4; k++) st.ball.quat[k] = bl[3 + k];
         st.ball.v = mk(bl[7], bl[8], bl[9]);
         st.ball.w = mk(bl[10], bl[11], bl[12]);
-        st.progress = b.progress[(size_t)i * A];
+        st.progress = b.progress[(size_t)bi * A];
 #pragma unroll
-        for (int a = 0; a < A; a++) st.flags[a] = b.flags[(size_t)a * n + i];
-        st.episode = b.episode[i];
+        for (int a = 0; a < A; a++) st.flags[a] = b.flags[(size_t)a * n + bi];
+        st.episode = b.episode[bi];
         pre_vx = st.ball.v.x;   // TT:1020
 #pragma unroll
         for (int a = 0; a < A; a++) { static_geometry<T>(K.site[a], g[a]); bound[a] = ld3(K.site[a].bound_center); }
@@ -495,19 +508,19 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
         } else if (s > 0) {
 #pragma unroll
             for (int a = 0; a < A; a++) PP_AWAIT(&s_flag[a], s);   // the arm waves have published boundary s
-            if (active) {
+            if (bactive) {
 #pragma unroll
                 for (int a = 0; a < A; a++)
 #pragma unroll
-                    for (int d = 0; d < ND; d++) { qs[a * ND + d] = s_q[s - 1][a * 2 * ND + d][lane]; qds[a * ND + d] = s_q[s - 1][a * 2 * ND + ND + d][lane]; }
+                    for (int d = 0; d < ND; d++) { qs[a * ND + d] = s_q[s - 1][a * 2 * ND + d][env]; qds[a * ND + d] = s_q[s - 1][a * 2 * ND + ND + d][env]; }
             }
         }
         PP_STAMP_AT(18 + 2 * s);
-        if (active) {
+        if (bactive) {
 #pragma unroll
             for (int a = 0; a < A; a++) {
                 if (G) {
-                    MovingGeom<T>::each(g[a], [&](int k, float& v) { v = s_geom[s & 1][a][k][lane]; });
+                    MovingGeom<T>::each(g[a], [&](int k, float& v) { v = s_geom[s & 1][a][k][env]; });
                 } else {
                     JointSave js[ND];        // dead: only the geometry (points + velocities) of this sweep is used
                     GeomVisitor<T> gv(g[a]);
@@ -522,24 +535,24 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     }
 #pragma unroll
     for (int a = 0; a < A; a++) PP_AWAIT(&s_flag[a], substeps + 1);   // final dof state, drive torques and paddle position
-    if (active) {
+    if (bactive) {
         BodyState bodies[A * NB];   // the task part reads the pelvis (row 0) and the paddle (row 9) only
         LdsRowStore stores[A];
 #pragma unroll
         for (int a = 0; a < A; a++) {
 #pragma unroll
             for (int d = 0; d < ND; d++) {
-                st.q[a * ND + d] = s_q[substeps - 1][a * 2 * ND + d][lane];
-                st.qd[a * ND + d] = s_q[substeps - 1][a * 2 * ND + ND + d][lane];
-                st.dof_force[a * ND + d] = s_tau[a * ND + d][lane];
+                st.q[a * ND + d] = s_q[substeps - 1][a * 2 * ND + d][env];
+                st.qd[a * ND + d] = s_q[substeps - 1][a * 2 * ND + ND + d][env];
+                st.dof_force[a * ND + d] = s_tau[a * ND + d][env];
             }
             static_body<false>(K.site[a], bodies[a * NB]);
-            bodies[a * NB + NB - 1].pos = mk(s_paddle[a * 3 + 0][lane], s_paddle[a * 3 + 1][lane], s_paddle[a * 3 + 2][lane]);
-            stores[a].row = &s_obs[(a * kBlock + lane) * kObsStride];
+            bodies[a * NB + NB - 1].pos = mk(s_paddle[a * 3 + 0][env], s_paddle[a * 3 + 1][env], s_paddle[a * 3 + 2][env]);
+            stores[a].row = &s_obs[(a * kBlock + env) * kObsStride];
         }
-        next_serve = mk(s_serve[0][lane], s_serve[1][lane], s_serve[2][lane]);   // drawn by arm wave 0
-        post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + i), st, bodies, pre_vx, &next_serve, rew, reset, stores);
-        s_reset[lane] = (int)reset;
+        next_serve = mk(s_serve[0][env], s_serve[1][env], s_serve[2][env]);   // drawn by arm wave 0
+        post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + bi), st, bodies, pre_vx, &next_serve, rew, reset, stores);
+        s_reset[env] = (int)reset;
     }
     publish(&s_flag_ball, 1);          // hands the reset decision to the arm waves
     PP_STAMP_AT(22);
@@ -547,18 +560,19 @@ __global__ __launch_bounds__((A + 1) * kBlock) void step_kernel_split(const Step
     PP_STAMP_AT(23);
 #pragma unroll
     for (int a = 0; a < A; a++)
-        flush_obs_cols<6 * NB, PPENV_NUM_OBS>(s_obs, b.obs, a * kBlock, nvalid, (size_t)base * A + a, A, lane);
-    if (active) {
+        flush_obs_cols<6 * NB, PPENV_NUM_OBS>(s_obs, b.obs, a * kBlock + bw * EB, BW == 1 ? nvalid : max(0, min(EB, nvalid - bw * EB)),
+                                              (size_t)(base + bw * EB) * A + a, A, lane);
+    if (bactive) {
         if (kBallStoresDofs) {             // st.q / st.qd already show the reset state where the env reset (TN keeps its dof state)
 #pragma unroll
             for (int d = 0; d < A * ND; d++) {
-                st_state(&b.dof_pos[(size_t)d * n + i], st.q[d]);
-                st_state(&b.dof_vel[(size_t)d * n + i], st.qd[d]);
-                st_state(&b.dof_force[(size_t)d * n + i], st.dof_force[d]);
+                st_state(&b.dof_pos[(size_t)d * n + bi], st.q[d]);
+                st_state(&b.dof_vel[(size_t)d * n + bi], st.qd[d]);
+                st_state(&b.dof_force[(size_t)d * n + bi], st.dof_force[d]);
             }
         }
-        store_ball(b, n, i, st.ball);
-        store_task<A>(b, n, i, st, rew, reset);
+        store_ball(b, n, bi, st.ball);
+        store_task<A>(b, n, bi, st, rew, reset);
     }
     PP_STAMP_AT(24);
 }
@@ -1224,6 +1238,7 @@ struct ppenv {
     int agents;              // 1, or 2 for PPENV_VARIANT_T4
     uint32_t* status_host;   // PPENV_STATUS_* bits, pinned host memory mapped into the device: kernels write it through, the host reads it without a sync
     uint32_t* status_dev;
+    int ball_waves;          // ball waves per 64 envs of the two-wave schedule (1, 2 or 4: step_kernel_split's BW)
     int dbg_drop_handoff;    // PPENV_DEBUG_DROP_HANDOFF=1 at create (tests): the arm wave withholds its last hand-off, so the partner waves time out
     int dr_on;               // a randomisation is set: ppenv_step launches step_kernel<ModelG1, true> with these tables
     DRTables dr;
@@ -1280,6 +1295,11 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
         if (cfg->substeps > kMaxSplitSubsteps) e->split = 0;   // one LDS hand-off slot per substep boundary
         if (e->agents == 2) e->split = (k && strcmp(k, "split3") == 0) ? 1 : 2;
         else if (e->split == 3 && cfg->substeps > kMaxSplitSubsteps) e->split = 0;   // 4-actor: arm waves sweep the geometry (default), or the ball wave
+    }
+    {   // PPENV_BALL_WAVES=1|2|4: ball waves per 64 envs (single-humanoid two-wave schedule only)
+        const char* bwv = getenv("PPENV_BALL_WAVES");
+        e->ball_waves = bwv ? atoi(bwv) : kDefaultBallWaves;
+        if (e->ball_waves != 1 && e->ball_waves != 2 && e->ball_waves != 4) e->ball_waves = kDefaultBallWaves;
     }
     e->arena = nullptr;
     e->owns_arena = false;
@@ -1378,6 +1398,12 @@ static int launch_step(ppenv* e, const DevBuffers& buf, const float* actions_dev
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->split == 3)
         hipLaunchKernelGGL((step_kernel_quad<ModelG1>), dim3(grid_for(e->cfg.num_envs)), dim3(4 * kBlock), 0, (hipStream_t)stream, e->K, buf,
+                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+    else if (e->split && e->ball_waves == 4)
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 4>), dim3(grid_for(e->cfg.num_envs)), dim3(5 * kBlock), 0, (hipStream_t)stream, e->K, buf,
+                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+    else if (e->split && e->ball_waves == 2)
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 2>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, buf,
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->split)
         hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, buf,

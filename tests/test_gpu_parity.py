@@ -98,11 +98,15 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant,
 
 
 @pytest.mark.parametrize("schedule,n", [("split", 1000), ("fused", 1000), ("fused", 130), ("split", 63), ("split", 1), ("fused", 1),
-                                        ("quad", 1000), ("quad", 63), ("quad", 1)])
+                                        ("quad", 1000), ("quad", 63), ("quad", 1),
+                                        ("split:1", 1000), ("split:2", 1000), ("split:2", 95), ("split:2", 1), ("split:4", 1000), ("split:4", 81), ("split:4", 17)])
 def test_both_schedules_on_ragged_sizes(torch_cuda, oracle_lib, monkeypatch, schedule, n):
     """The two-wave (default), the one-wave and the four-wave (round-2 experiment, DESIGN.md §9) step kernels run the same arithmetic;
-    sizes that are not a multiple of 64."""
+    sizes that are not a multiple of 64.  "split:B": the two-wave schedule with B ball waves of 64 / B envs each (round 3)."""
     torch = torch_cuda
+    if ":" in schedule:
+        schedule, bw = schedule.split(":")
+        monkeypatch.setenv("PPENV_BALL_WAVES", bw)
     monkeypatch.setenv("PPENV_STEP_KERNEL", schedule)
     cfg = scene.build_config("TT", num_envs=n, seed=21)
     o = oracle_lib.OracleEnv(cfg)
