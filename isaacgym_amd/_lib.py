@@ -6,7 +6,10 @@ without a GPU); the built .so lives in-tree so it travels with the source snapsh
 """
 import ctypes as C
 import os
+import shutil
 import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
 
 from . import scene
 
@@ -33,23 +36,56 @@ def is_stale():
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> isaacgym_amd/lib/libppenv.so."""
-    if not force and not is_stale():
-        return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+def build(force=False, verbose=False, out=None, extra_flags=(), extra_deps=()):
+    """hipcc --offload-arch=gfx950 -> isaacgym_amd/lib/libppenv.so.  out / extra_flags: a build of the same sources for another
+    compiled-in arm model (-DPPENV_MODEL_HEADER=..., see build_for_arm_model) — loaded with load(), never the default library."""
+    out = LIB_PATH if out is None else out
+    if not force and os.path.exists(out):
+        t = os.path.getmtime(out)
+        if not any(os.path.getmtime(p) > t for p in SOURCES + HEADERS + list(extra_deps)):
+            return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"          # built aside and renamed: another process never sees half a library
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + SOURCES
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
+    tmp = f"{out}.{os.getpid()}.tmp"          # built aside and renamed: another process never sees half a library
+    objdir = tempfile.mkdtemp(prefix="ppenv_build_")
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + compile_flags + ["-c", "-o", obj, src]
+        return obj, cmd, subprocess.run(cmd, capture_output=True, text=True)
+    try:
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:      # one translation unit per core
+            done = list(pool.map(compile_one, SOURCES))
+        for obj, cmd, res in done:
+            if res.returncode != 0:
+                raise PPEnvError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stderr[-4000:])
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [obj for obj, _, _ in done]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise PPEnvError("hipcc (link) failed:\n" + " ".join(cmd) + "\n" + res.stderr[-4000:])
+        os.replace(tmp, out)
+    finally:
         if os.path.exists(tmp):
             os.remove(tmp)
-        raise PPEnvError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stderr[-4000:])
-    os.replace(tmp, LIB_PATH)
+        shutil.rmtree(objdir, ignore_errors=True)
     if verbose:
         print(" ".join(cmd))
-    return LIB_PATH
+    return out
+
+
+def build_for_arm_model(config, out_dir, force=False):
+    """The library with ANOTHER 7-dof arm compiled in: `config` carries the model (scene.build_config after
+    scene.use_arm_tables(urdf.arm_specs(...))); modelgen writes its header into out_dir and the same sources are built against it.
+    -> path of out_dir/libppenv.so (load it with load(); ppenv_create of THAT library accepts the config, the default one refuses it)."""
+    from . import modelgen
+    os.makedirs(out_dir, exist_ok=True)
+    header = os.path.join(out_dir, "ppenv_model.h")
+    text = modelgen.generate(config)
+    if not os.path.exists(header) or open(header).read() != text:
+        with open(header, "w") as fh:
+            fh.write(text)
+    return build(force=force, out=os.path.join(out_dir, "libppenv.so"), extra_flags=[f'-DPPENV_MODEL_HEADER="{header}"'], extra_deps=[header])
 
 
 def lib():
@@ -61,10 +97,16 @@ def lib():
         raise PPEnvError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (needs hipcc). There is no CPU fallback.")
+    _lib = load(LIB_PATH)
+    return _lib
+
+
+def load(path):
+    """A libppenv build with its argtypes set (lib() for the default one; build_for_arm_model's output for another arm)."""
     try:
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
     except OSError as e:
-        raise PPEnvError(f"could not load {LIB_PATH}: {e}") from e
+        raise PPEnvError(f"could not load {path}: {e}") from e
     if L.ppenv_abi_version() != scene.ABI_VERSION:
         raise PPEnvError("libppenv.so ABI version does not match isaacgym_amd.scene; rebuild the library")
     vp, sz = C.c_void_p, C.c_size_t
@@ -113,10 +155,9 @@ def lib():
     L.ppenv_state_bytes.argtypes = [vp]
     L.ppenv_get_state.argtypes = [vp, vp, sz]
     L.ppenv_set_state.argtypes = [vp, vp, sz]
-    _lib = L
     return L
 
 
-def check(rc):
+def check(rc, L=None):
     if rc != 0:
-        raise PPEnvError(f"ppenv error {rc}: {lib().ppenv_last_error().decode()}")
+        raise PPEnvError(f"ppenv error {rc}: {(L if L is not None else lib()).ppenv_last_error().decode()}")

@@ -1213,8 +1213,9 @@ bool validate(const ppenv_config* c) {
         }
     }
     if (!model_matches<ModelG1>(*c)) {
-        set_err("chain topology (joint axes / shape links / observed-body frames) has no compiled kernel instantiation; "
-                "this build ships the Unitree G1 right-arm chain (ppenv_device.h ModelG1)");
+        set_err("the config's arm model (joint frames / inertials / gains / limits / link shapes / paddle / observed-body frames) differs from "
+                "the one compiled into this library (csrc/ppenv_model_g1.h); generate its header with isaacgym_amd.modelgen and rebuild "
+                "(isaacgym_amd._lib.build_for_arm_model)");
         return false;
     }
     for (int d = 0; d < ND; d++)

@@ -1172,7 +1172,12 @@ inline StepConsts make_step_consts(const ppenv_config& c) {
 }  // namespace pp
 
 // ------------------------------------------------------- the compiled model and its runtime check
-#include "ppenv_model_g1.h"
+// PPENV_MODEL_HEADER: a build for another asset names the header isaacgym_amd/modelgen.py generated from ITS tables
+// (urdf.arm_specs -> scene.use_arm_tables -> modelgen.generate); the default is the committed placeholder model.
+#ifndef PPENV_MODEL_HEADER
+#define PPENV_MODEL_HEADER "ppenv_model_g1.h"
+#endif
+#include PPENV_MODEL_HEADER
 
 namespace pp {
 // Does the runtime config describe exactly the arm model `T` was compiled from?  (bitwise on the floats)

@@ -14,9 +14,11 @@ from . import _lib, scene
 
 
 class PPEnv:
-    def __init__(self, config, device=None):
+    def __init__(self, config, device=None, library=None):
+        """library: a libppenv build other than the default one (_lib.load of _lib.build_for_arm_model's output: another arm
+        model compiled in); the handle then only ever talks to that build."""
         self.config = config
-        self.L = _lib.lib()   # raises when the HIP extension is missing: no fallback
+        self.L = library if library is not None else _lib.lib()   # raises when the HIP extension is missing: no fallback
         if not torch.cuda.is_available():
             raise _lib.PPEnvError("no ROCm GPU visible to PyTorch; the native environment runs on an MI355X only")
         self.device = torch.device(device if device is not None else f"cuda:{config.device_id}")
@@ -29,9 +31,9 @@ class PPEnv:
         self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self.h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.L.ppenv_create(C.byref(config), self.arena.data_ptr(), nbytes, self._stream(), C.byref(self.h)))
+            _lib.check(self.L.ppenv_create(C.byref(config), self.arena.data_ptr(), nbytes, self._stream(), C.byref(self.h)), self.L)
         b = scene.Buffers()
-        _lib.check(self.L.ppenv_buffers_of(self.h, C.byref(b)))
+        _lib.check(self.L.ppenv_buffers_of(self.h, C.byref(b)), self.L)
         base = self.arena.data_ptr()
 
         def view(ptr, count, dtype, shape):
@@ -78,15 +80,15 @@ class PPEnv:
                 or tuple(actions.shape) != (self.num_rows, scene.NUM_DOF):
             actions = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_rows, scene.NUM_DOF).contiguous()
         if obs is None and rew is None and reset is None:
-            _lib.check(self.L.ppenv_step(self.h, actions.data_ptr(), self._stream()))
+            _lib.check(self.L.ppenv_step(self.h, actions.data_ptr(), self._stream()), self.L)
             return
         for t, dt, numel in ((obs, torch.float32, self.num_rows * scene.NUM_OBS), (rew, torch.float32, self.num_rows), (reset, torch.int64, self.num_rows)):
             assert t is None or (t.dtype == dt and t.is_contiguous() and t.device == self.device and t.numel() == numel)
         p = lambda t: t.data_ptr() if t is not None else None
-        _lib.check(self.L.ppenv_step_into(self.h, actions.data_ptr(), p(obs), p(rew), p(reset), self._stream()))
+        _lib.check(self.L.ppenv_step_into(self.h, actions.data_ptr(), p(obs), p(rew), p(reset), self._stream()), self.L)
 
     def reset_all(self):
-        _lib.check(self.L.ppenv_reset_all(self.h, self._stream()))
+        _lib.check(self.L.ppenv_reset_all(self.h, self._stream()), self.L)
 
     def reset_idx(self, env_ids, refresh_obs=True):
         """reset_idx(env_ids) -> _reset_idx (TT:809-812, 847-906) for the listed local env ids only (int64 tensor / sequence)."""
@@ -97,21 +99,21 @@ class PPEnv:
             if int(ids.min()) < 0 or int(ids.max()) >= self.num_envs:
                 raise IndexError(f"env id outside [0, {self.num_envs})")
         ids = ids.to(self.device).contiguous()
-        _lib.check(self.L.ppenv_reset_idx(self.h, ids.data_ptr(), ids.numel(), int(bool(refresh_obs)), self._stream()))
+        _lib.check(self.L.ppenv_reset_idx(self.h, ids.data_ptr(), ids.numel(), int(bool(refresh_obs)), self._stream()), self.L)
         ids.record_stream(torch.cuda.current_stream(self.device))   # the kernel reads `ids` after this frame is gone
 
     def pd_targets(self, actions):
         """pre_physics_step's PD targets (TT:1008-1014) for actions [A*N, 7]: what set_dof_position_target_tensor receives."""
         a = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_rows, scene.NUM_DOF).contiguous()
         out = torch.empty_like(a)
-        _lib.check(self.L.ppenv_pd_targets(self.h, a.data_ptr(), out.data_ptr(), self._stream()))
+        _lib.check(self.L.ppenv_pd_targets(self.h, a.data_ptr(), out.data_ptr(), self._stream()), self.L)
         return out
 
     def serve_from_draws(self, draws):
         """generate_random_speed_for_ball of this variant on [M,3] draws (speed, tilt deg, tilt_z deg) -> [M,3] velocities."""
         d = torch.as_tensor(draws, dtype=torch.float32).to(self.device).reshape(-1, 3).contiguous()
         out = torch.empty_like(d)
-        _lib.check(self.L.ppenv_serve_from_draws(self.h, d.data_ptr(), d.shape[0], out.data_ptr(), self._stream()))
+        _lib.check(self.L.ppenv_serve_from_draws(self.h, d.data_ptr(), d.shape[0], out.data_ptr(), self._stream()), self.L)
         return out
 
     def set_randomization(self, dof_stiffness_scale=None, dof_damping_scale=None, link_mass_scale=None, restitution_scale=None,
@@ -128,14 +130,14 @@ class PPEnv:
         r = scene.Randomization()
         (r.dof_stiffness_scale, r.dof_damping_scale, r.link_mass_scale, r.restitution_scale, r.friction_scale) = [t.data_ptr() if t is not None else None for t in self._dr]
         r.action_noise_sigma, r.observation_noise_sigma = float(action_noise_sigma), float(observation_noise_sigma)
-        _lib.check(self.L.ppenv_set_randomization(self.h, C.byref(r)))
+        _lib.check(self.L.ppenv_set_randomization(self.h, C.byref(r)), self.L)
 
     def clear_randomization(self):
-        _lib.check(self.L.ppenv_set_randomization(self.h, None))
+        _lib.check(self.L.ppenv_set_randomization(self.h, None), self.L)
         self._dr = None
 
     def set_gravity(self, gravity_z):
-        _lib.check(self.L.ppenv_set_gravity(self.h, float(gravity_z)))
+        _lib.check(self.L.ppenv_set_gravity(self.h, float(gravity_z)), self.L)
 
     @property
     def status(self):
@@ -149,7 +151,7 @@ class PPEnv:
                 self._stats = torch.zeros(4, dtype=torch.float64, device=self.device)
             out = self._stats
         assert out.dtype == torch.float64 and out.numel() == 4 and out.device == self.device and out.is_contiguous()
-        _lib.check(self.L.ppenv_reduce_stats(self.h, out.data_ptr(), self._stream()))
+        _lib.check(self.L.ppenv_reduce_stats(self.h, out.data_ptr(), self._stream()), self.L)
         return out
 
     # ---- Isaac-Gym tensor-API mode
@@ -160,11 +162,11 @@ class PPEnv:
         assert rigid_body_states.numel() == n * scene.NUM_BODIES * 13 and root_states.numel() == n * scene.NUM_ACTORS * 13
         assert dof_states.numel() == n * scene.NUM_DOF * 2 and dof_force.numel() == n * scene.NUM_DOF and pre_ball_vx.numel() == n
         _lib.check(self.L.ppenv_post_physics_step(self.h, rigid_body_states.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(),
-                                                  dof_force.data_ptr(), pre_ball_vx.data_ptr(), self._stream()))
+                                                  dof_force.data_ptr(), pre_ball_vx.data_ptr(), self._stream()), self.L)
 
     def _refresh(self, fn, shape):
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
-        _lib.check(fn(self.h, out.data_ptr(), self._stream()))
+        _lib.check(fn(self.h, out.data_ptr(), self._stream()), self.L)
         return out
 
     def refresh_root_states(self):
@@ -183,18 +185,18 @@ class PPEnv:
     def set_serve_override(self, serve, on=True):
         """serve: [N,3] tensor/array of serve velocities used at the next resets instead of the RNG."""
         if serve is None or not on:
-            _lib.check(self.L.ppenv_set_serve_override(self.h, None, int(bool(on)), self._stream()))
+            _lib.check(self.L.ppenv_set_serve_override(self.h, None, int(bool(on)), self._stream()), self.L)
             return
         s = torch.as_tensor(serve, dtype=torch.float32).to(self.device).reshape(self.num_envs, 3).contiguous()
-        _lib.check(self.L.ppenv_set_serve_override(self.h, s.data_ptr(), 1, self._stream()))
+        _lib.check(self.L.ppenv_set_serve_override(self.h, s.data_ptr(), 1, self._stream()), self.L)
         torch.cuda.current_stream(self.device).synchronize()   # `s` must outlive the transpose kernel
 
     def get_state(self):
         n = self.L.ppenv_state_bytes(self.h)
         buf = np.empty(n, np.uint8)
-        _lib.check(self.L.ppenv_get_state(self.h, buf.ctypes.data, n))
+        _lib.check(self.L.ppenv_get_state(self.h, buf.ctypes.data, n), self.L)
         return buf
 
     def set_state(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
-        _lib.check(self.L.ppenv_set_state(self.h, blob.ctypes.data, blob.size))
+        _lib.check(self.L.ppenv_set_state(self.h, blob.ctypes.data, blob.size), self.L)

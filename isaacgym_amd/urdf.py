@@ -15,6 +15,11 @@ inertial data: `ball_shapes` (the capsule / sphere shapes the ball collides with
 `paddle_blade` (a cylinder on the paddle link -> blade centre, normal, radius, half thickness) and `ground_contacts` (the points
 tested against the ground plane: the bottom corners of box collisions such as the G1's feet, the low points of the others).
 
+`<mesh>` collisions carry no analytic shape.  The real G1 asset's collision geometry is mostly meshes, so dropping them in silence
+would leave the ball flying through the robot: `parse` raises and lists every link whose mesh has no stand-in, unless the caller
+names one per link (`mesh_bounds`: a sphere / capsule / cylinder / box placed at the mesh's own <origin>) or asks for
+`on_mesh="warn"` (the dropped links are then listed in a warning and kept in `Robot.dropped_mesh_collisions`).
+
 `write_g1_urdf()` emits the placeholder model as a URDF; tests/golden/g1_27dof_placeholder.urdf is its output, and the tests
 check that parsing it reproduces the hand-built tables.  No real asset has been seen by this code.
 """
@@ -70,8 +75,9 @@ class Joint:
 
 
 class Robot:
-    def __init__(self, name, links, joints):
+    def __init__(self, name, links, joints, dropped_mesh_collisions=()):
         self.name, self.links, self.joints = name, links, joints
+        self.dropped_mesh_collisions = list(dropped_mesh_collisions)   # [(link, mesh file)]: only with parse(on_mesh="warn")
         self.joint_of_child = {j.child: j for j in joints.values()}
 
     def root(self):
@@ -91,12 +97,44 @@ def _floats(text, n, default):
     return v
 
 
-def parse(text):
-    """URDF text -> Robot.  Only what the dynamics need: inertials, joint origins / axes / limits, the tree."""
+def _mesh_stand_in(link_name, spec, mesh_xyz, mesh_rpy):
+    """A primitive named by the caller in place of a link's <mesh> collision, placed at the mesh's own <origin>:
+    dict(kind="sphere", radius=) | dict(kind="capsule" | "cylinder", radius=, length=) | dict(kind="box", size=(x, y, z)), each with
+    optional xyz / rpy relative to that origin."""
+    kind = spec.get("kind")
+    if kind == "sphere":
+        size = (float(spec["radius"]),)
+    elif kind in ("capsule", "cylinder"):
+        size = (float(spec["radius"]), float(spec["length"]))
+    elif kind == "box":
+        size = tuple(float(v) for v in spec["size"])
+        if len(size) != 3:
+            raise ValueError(f"mesh_bounds[{link_name!r}]: a box needs size = (x, y, z)")
+    else:
+        raise ValueError(f"mesh_bounds[{link_name!r}]: kind {kind!r} is not sphere / capsule / cylinder / box")
+    if any(v <= 0.0 for v in size):
+        raise ValueError(f"mesh_bounds[{link_name!r}]: sizes must be positive")
+    c = Collision(kind, size, spec.get("xyz", (0.0, 0.0, 0.0)), spec.get("rpy", (0.0, 0.0, 0.0)))
+    m_rot = scene.rpy_to_rot(*mesh_rpy)
+    c.xyz = np.asarray(mesh_xyz, dtype=np.float64) + m_rot @ c.xyz
+    c.rot = m_rot @ c.rot
+    return c
+
+
+def parse(text, mesh_bounds=None, on_mesh="error"):
+    """URDF text -> Robot.  Only what the dynamics need: inertials, joint origins / axes / limits, the tree, and the collision
+    primitives.  mesh_bounds: {link name: stand-in primitive (or a list of them, one per mesh collision of that link)} for <mesh>
+    collisions; a mesh without one is an error that names every such link (on_mesh="error", the default) or a warning
+    (on_mesh="warn") — never a silent skip."""
+    if on_mesh not in ("error", "warn"):
+        raise ValueError("on_mesh is 'error' or 'warn'")
+    mesh_bounds = dict(mesh_bounds or {})
     root = ET.fromstring(text)
     if root.tag != "robot":
         raise ValueError("not a URDF: the root element is not <robot>")
     links, joints = {}, {}
+    dropped, mesh_seen = [], {}
+
     def collisions_of(e):
         out = []
         for c in e.findall("collision"):
@@ -113,7 +151,15 @@ def parse(text):
             elif k.tag in ("cylinder", "capsule"):
                 out.append(Collision(k.tag, (float(k.get("radius")), float(k.get("length"))), xyz, rpy))
             elif k.tag == "mesh":
-                continue        # meshes carry no analytic shape: the ball-collision tables need primitives
+                name = e.get("name")
+                spec = mesh_bounds.get(name)
+                if isinstance(spec, (list, tuple)):                      # one stand-in per mesh collision of the link, in order
+                    spec = spec[mesh_seen.get(name, 0)] if mesh_seen.get(name, 0) < len(spec) else None
+                mesh_seen[name] = mesh_seen.get(name, 0) + 1
+                if spec is None:
+                    dropped.append((name, k.get("filename", "")))     # reported below: never skipped in silence
+                    continue
+                out.append(_mesh_stand_in(name, spec, xyz, rpy))
             else:
                 raise ValueError(f"link {e.get('name')}: collision geometry <{k.tag}> is not supported")
         return out
@@ -152,12 +198,57 @@ def parse(text):
     for j in joints.values():
         if j.parent not in links or j.child not in links:
             raise ValueError(f"joint {j.name} names a link that does not exist")
-    return Robot(root.get("name", ""), links, joints)
+    unknown = sorted(set(mesh_bounds) - set(links))
+    if unknown:
+        raise ValueError(f"mesh_bounds names links the URDF does not have: {unknown}")
+    if dropped:
+        what = ", ".join(f"{n} ({f})" if f else n for n, f in dropped)
+        msg = (f"{len(dropped)} <mesh> collision(s) have no analytic stand-in and would be dropped — the ball would pass through these links: {what}. "
+               "Give each a primitive through parse(..., mesh_bounds={link: dict(kind='capsule', radius=…, length=…)}) or accept the loss "
+               "explicitly with on_mesh='warn'.")
+        if on_mesh == "error":
+            raise ValueError(msg)
+        import warnings
+        warnings.warn(msg, stacklevel=2)
+    return Robot(root.get("name", ""), links, joints, dropped)
 
 
-def load(path):
+def load(path, mesh_bounds=None, on_mesh="error"):
     with open(path) as f:
-        return parse(f.read())
+        return parse(f.read(), mesh_bounds=mesh_bounds, on_mesh=on_mesh)
+
+
+def perturbed(text, mass_scale=1.0, origin_shift=None, limits=None):
+    """URDF text -> URDF text of a different asset: every link's mass and inertia scaled by mass_scale, joint origins moved by
+    origin_shift {joint: (dx, dy, dz)} (a link length), joint ranges replaced by limits {joint: (lower, upper)}.  What the N3 tests use
+    to drive the kernels from a model that is NOT the placeholder tables; also a cheap what-if tool once a real asset exists."""
+    root = ET.fromstring(text)
+    for link in root.findall("link"):
+        inert = link.find("inertial")
+        if inert is None:
+            continue
+        m = inert.find("mass")
+        m.set("value", repr(float(m.get("value")) * mass_scale))
+        i = inert.find("inertia")
+        for k in ("ixx", "iyy", "izz", "ixy", "ixz", "iyz"):
+            i.set(k, repr(float(i.get(k, 0.0)) * mass_scale))
+    seen = set()
+    for j in root.findall("joint"):
+        name = j.get("name")
+        if origin_shift and name in origin_shift:
+            o = j.find("origin")
+            xyz = np.asarray(_floats(o.get("xyz"), 3, (0, 0, 0))) + np.asarray(origin_shift[name], dtype=np.float64)
+            o.set("xyz", " ".join(repr(float(v)) for v in xyz))
+            seen.add(name)
+        if limits and name in limits:
+            lim = j.find("limit")
+            lim.set("lower", repr(float(limits[name][0])))
+            lim.set("upper", repr(float(limits[name][1])))
+            seen.add(name)
+    missing = (set(origin_shift or ()) | set(limits or ())) - seen
+    if missing:
+        raise ValueError(f"no such joint(s): {sorted(missing)}")
+    return ET.tostring(root, encoding="unicode")
 
 
 def _axis_index(axis, name):

@@ -16,6 +16,14 @@ _LIB = os.path.join(_HERE, "csrc", "libppenv_hostshim.so")
 _lib = None
 
 
+def lib_for_model(header, out):
+    """The host shim with ANOTHER arm model compiled in (-DPPENV_MODEL_HEADER, as isaacgym_amd._lib.build_for_arm_model does for
+    the HIP library): `header` = modelgen.generate(config) written to a file; -> a CDLL."""
+    subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=fast", "-fno-signed-zeros", "-ffinite-math-only", "-Wno-unknown-pragmas",
+                    f'-DPPENV_MODEL_HEADER="{header}"', "-o", out, _SRC], check=True, capture_output=True)
+    return C.CDLL(out)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -33,10 +41,10 @@ def _p(a):
 class ShimEnv:
     """Same SoA state layout as the oracle / the HIP handle; stepped by the kernel arithmetic on the CPU."""
 
-    def __init__(self, config):
-        self.L = lib()
+    def __init__(self, config, L=None):
+        self.L = L if L is not None else lib()
         self.config = config
-        assert self.L.shim_model_matches(C.byref(config)) == 1
+        assert self.L.shim_model_matches(C.byref(config)) == 1, "the config's arm model is not the one compiled into this shim"
         n = self.num_envs = config.num_envs
         A = self.num_agents = config.num_humanoids
         nd = A * scene.NUM_DOF

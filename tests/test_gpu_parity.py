@@ -212,7 +212,7 @@ def test_state_blob_roundtrip_and_errors(torch_cuda):
     env.close()
     bad = scene.build_config("TT", num_envs=n)
     bad.joint[2].axis = 0   # a chain this build has no kernel instantiation for
-    with pytest.raises(_lib.PPEnvError, match="topology"):
+    with pytest.raises(_lib.PPEnvError, match="differs from the one compiled"):
         make_env(bad)
 
 

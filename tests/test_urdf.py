@@ -150,3 +150,222 @@ def test_foot_contact_points_of_the_27dof_model_from_collision_boxes():
     assert m.num_contacts == want.num_contacts
     np.testing.assert_allclose(np.array([list(m.contact_point[k]) for k in range(m.num_contacts)]),
                                np.array([list(want.contact_point[k]) for k in range(want.num_contacts)]), atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# <mesh> collisions (the real G1 asset's collision geometry is mostly meshes): a stand-in per link or a loud failure
+MESH_URDF = HAND_URDF.replace('<collision><origin xyz="0.15 0 0" rpy="0 1.5707963267948966 0"/><geometry><cylinder radius="0.03" length="0.2"/></geometry></collision>',
+                              '<collision><origin xyz="0.15 0 0" rpy="0 1.5707963267948966 0"/><geometry><mesh filename="meshes/upper.STL"/></geometry></collision>') \
+                     .replace('<collision><origin xyz="0 0 0.05"/><geometry><sphere radius="0.12"/></geometry></collision>',
+                              '<collision><origin xyz="0 0 0.05"/><geometry><mesh filename="meshes/base.STL"/></geometry></collision>')
+
+
+def test_mesh_collisions_are_never_dropped_in_silence():
+    assert MESH_URDF.count("<mesh") == 2
+    with pytest.raises(ValueError) as e:
+        urdf.parse(MESH_URDF)
+    assert "base (meshes/base.STL)" in str(e.value) and "upper (meshes/upper.STL)" in str(e.value) and "2 <mesh>" in str(e.value)
+    with pytest.raises(ValueError, match="upper"):                      # one stand-in given, the other still missing: still an error
+        urdf.parse(MESH_URDF, mesh_bounds={"base": dict(kind="sphere", radius=0.12)})
+    with pytest.warns(UserWarning, match="base .meshes/base.STL., upper"):
+        robot = urdf.parse(MESH_URDF, on_mesh="warn")
+    assert robot.dropped_mesh_collisions == [("base", "meshes/base.STL"), ("upper", "meshes/upper.STL")]
+    assert robot.links["upper"].collisions == [] and len(robot.links["foot"].collisions) == 1
+    with pytest.raises(ValueError, match="does not have"):
+        urdf.parse(MESH_URDF, mesh_bounds={"nowhere": dict(kind="sphere", radius=0.1)}, on_mesh="warn")
+    with pytest.raises(ValueError, match="not sphere"):
+        urdf.parse(MESH_URDF, mesh_bounds={"base": dict(kind="cone", radius=0.1)}, on_mesh="warn")
+
+
+def test_mesh_stand_ins_sit_at_the_mesh_origin():
+    """A capsule named for the `upper` mesh is placed at the mesh's own <origin> (its axis = the origin's local z, pitched onto the
+    link's x): the same two end points the analytic cylinder of HAND_URDF gives; the sphere likewise."""
+    bounds = {"base": dict(kind="sphere", radius=0.12), "upper": [dict(kind="capsule", radius=0.03, length=0.2)]}
+    robot = urdf.parse(MESH_URDF, mesh_bounds=bounds)
+    assert robot.dropped_mesh_collisions == []
+    shapes = urdf.ball_shapes(robot, ["base", "upper", "foot"], ["base", "upper"])
+    want = urdf.ball_shapes(urdf.parse(HAND_URDF), ["base", "upper", "foot"], ["base", "upper"])
+    for g, w in zip(shapes, want):
+        assert g["link"] == w["link"] and g["radius"] == w["radius"]
+        np.testing.assert_allclose(g["a"], w["a"], atol=1e-12)
+        np.testing.assert_allclose(g["b"], w["b"], atol=1e-12)
+    # a stand-in with its own offset is composed with the mesh origin: 0.05 along the mesh frame's z = the link's x
+    robot = urdf.parse(MESH_URDF, mesh_bounds={"base": bounds["base"], "upper": dict(kind="sphere", radius=0.04, xyz=(0, 0, 0.05))})
+    s = urdf.ball_shapes(robot, ["base", "upper", "foot"], ["upper"])[0]
+    np.testing.assert_allclose(s["a"], (0.20, 0, 0), atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A URDF-derived model that DIFFERS from the placeholder tables, all the way into the kernels' arithmetic (tests/urdf_assets.py)
+def test_second_27dof_asset_differs_and_runs_on_the_kernel_arithmetic(oracle_lib):
+    """urdf.perturbed -> urdf.ta_model: not the compiled-in model; the table-driven kernel arithmetic (ppenv_ta_device.h on the host)
+    follows it and agrees with the oracle given the same tables — and both differ from the placeholder model's step."""
+    import ctypes as C
+
+    import shim_binding as sb
+    import urdf_assets
+    from test_ta_physics import ball_switch_probe, check_step, initial_tensors
+    m, base = urdf_assets.second_27dof_model(), scene.build_ta_model()
+    assert abs(sum(m.link[i].mass for i in range(28)) / sum(base.link[i].mass for i in range(28)) - 1.3) < 1e-6
+    assert abs(m.link[4].origin_xyz[2] - (base.link[4].origin_xyz[2] - 0.03)) < 1e-7          # left knee 3 cm lower
+    assert (m.link[16].lower, m.link[16].upper) == (-1.0, np.float32(1.2))
+    n = 48
+    cfg = scene.build_ta_scene(n)
+    root, dof = initial_tensors(n, seed=5)
+    rng = np.random.default_rng(6)
+    moved = 0.0
+    for t in range(60):
+        if t % 4 == 0:
+            act = rng.uniform(-1.1, 1.1, (n, 27)).astype(np.float32)
+        r2, d2, r3, d3 = root.copy(), dof.copy(), root.copy(), dof.copy()
+        root0, dof0 = root.copy(), dof.copy()
+        rb, frc, _ = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=8)
+        rb2, frc2, _ = sb.ta_simulate(cfg, m, act, r2, d2)
+        oracle_lib.ta_simulate(cfg, base, act, r3, d3, threads=8)
+        moved = max(moved, float(np.abs(d3[..., 1] - dof[..., 1]).max()))
+        hit = ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root, seed=t)
+        check_step((r2[~hit], d2[~hit], rb2[~hit], frc2[~hit]), (root[~hit], dof[~hit], rb[~hit], frc[~hit]), f"second asset, step {t}")
+    assert moved > 0.5          # rad/s: the placeholder model would have stepped elsewhere — the tables did reach the arithmetic
+
+
+def test_second_arm_asset_through_modelgen_into_the_kernel_arithmetic(oracle_lib, tmp_path):
+    """7-dof path: urdf.arm_specs -> scene.use_arm_tables -> modelgen.generate -> the kernel arithmetic rebuilt against that header
+    agrees with the oracle on the changed arm; the stock build refuses the config (pp::model_matches)."""
+    import ctypes as C
+
+    import shim_binding as sb
+    import urdf_assets
+    from helpers import ExclusionLog, SensitivityProbe, assert_close, assert_state_close, mask_envs, obs_atol, reward_atol
+    from isaacgym_amd import modelgen
+    n = 128
+    stock_cfg = scene.build_config("TT", num_envs=n, seed=3)
+    with urdf_assets.second_arm_tables():
+        cfg = scene.build_config("TT", num_envs=n, seed=3)
+    assert bytes(cfg) != bytes(stock_cfg)
+    assert abs(cfg.joint[3].mass / stock_cfg.joint[3].mass - 1.3) < 1e-6 and cfg.joint[1].upper == np.float32(0.9)
+    assert sb.lib().shim_model_matches(C.byref(cfg)) == 0                          # the stock compiled-in model is stale for this asset
+    header = tmp_path / "ppenv_model.h"
+    header.write_text(modelgen.generate(cfg))
+    L = sb.lib_for_model(str(header), str(tmp_path / "libshim_second_arm.so"))
+    assert L.shim_model_matches(C.byref(cfg)) == 1 and L.shim_model_matches(C.byref(stock_cfg)) == 0
+    o, s, o_stock = oracle_lib.OracleEnv(cfg), sb.ShimEnv(cfg, L=L), oracle_lib.OracleEnv(stock_cfg)
+    probe = SensitivityProbe(oracle_lib, cfg)
+    log = ExclusionLog("host shim rebuilt for the second arm asset vs oracle [TT]", bound=0.005)
+    rng = np.random.default_rng(1)
+    oa, ra = obs_atol(), reward_atol(cfg)
+    moved = 0.0
+    for t in range(80):
+        actions = rng.uniform(-1.2, 1.2, (n, 7)).astype(np.float32)
+        s.copy_state_from(o)
+        st = o.get_state()
+        o_stock.set_state(st)
+        o.step(actions)
+        s.step(actions)
+        o_stock.step(actions)
+        moved = max(moved, float(np.abs(o_stock.dof_vel - o.dof_vel).max()))
+        keep = ~probe.sensitive(st, actions, o)
+        log.add(keep)
+        sm, om = mask_envs(s, keep), mask_envs(o, keep)
+        np.testing.assert_array_equal(sm.reset_buf, om.reset_buf)
+        np.testing.assert_array_equal(sm.flags, om.flags)
+        assert_state_close(sm, om, f"second arm, step {t}")
+        assert_close(sm.obs_buf, om.obs_buf, f"second arm, obs step {t}", atol=oa)
+        assert_close(sm.rew_buf, om.rew_buf, f"second arm, rew step {t}", atol=ra)
+    log.close()
+    assert moved > 0.5          # rad/s: the stock arm steps elsewhere from the same state
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("mapping", ["default", "lane"])
+def test_gpu_27dof_kernels_follow_a_urdf_model_that_differs_from_the_placeholder(oracle_lib, monkeypatch, mapping):
+    """The changed asset -> urdf.ta_model -> TASim(model=...): the library sees it is not the compiled-in model, takes a table-driven
+    kernel (the quad mapping by default — same tree — or one lane per env) and steps it like the oracle does with the same tables."""
+    import ctypes as C
+
+    import torch
+    import urdf_assets
+    from helpers import ExclusionLog
+    from isaacgym_amd import _lib
+    from isaacgym_amd.tensor_api import TASim
+    from test_ta_physics import ball_switch_probe, check_step, initial_tensors
+    if mapping == "lane":
+        monkeypatch.setenv("PPENV_TA_KERNEL", "lane")
+    else:
+        monkeypatch.delenv("PPENV_TA_KERNEL", raising=False)
+    n = 200
+    cfg, m = scene.build_ta_scene(n), urdf_assets.second_27dof_model()
+    assert _lib.lib().ppenv_ta_model_is_compiled(C.byref(cfg), C.byref(m)) == 0
+    sim = TASim(n, device="cuda:0", model=m)
+    assert sim.kernel == ("lane" if mapping == "lane" else "quad")
+    base = scene.build_ta_model()
+    root, dof = initial_tensors(n, seed=11)
+    rng = np.random.default_rng(12)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    rb_d, frc_d, pvx_d = torch.zeros(n, 42, 13, device="cuda"), torch.zeros(n, 27, device="cuda"), torch.zeros(n, device="cuda")
+    log = ExclusionLog(f"gpu 27-dof step from the second URDF asset vs oracle [{sim.kernel}, n={n}]", bound=0.005)
+    moved = 0.0
+    for t in range(80):
+        if t % 4 == 0:
+            act = rng.uniform(-1.2, 1.2, (n, 27)).astype(np.float32)
+            act[: n // 3] *= 0.1
+        root_d, dof_d = dev(root), dev(dof)
+        sim.simulate(dev(act), root_d, dof_d, rb_d, frc_d, pvx_d)
+        root0, dof0 = root.copy(), dof.copy()
+        r3, d3 = root.copy(), dof.copy()
+        rb, frc, pvx = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=8)
+        oracle_lib.ta_simulate(cfg, base, act, r3, d3, threads=8)
+        moved = max(moved, float(np.abs(d3[..., 1] - dof[..., 1]).max()))
+        keep = ~ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root, seed=300 + t)
+        log.add(keep)
+        got = (root_d.cpu().numpy()[keep], dof_d.cpu().numpy()[keep], rb_d.cpu().numpy()[keep], frc_d.cpu().numpy()[keep])
+        check_step(got, (root[keep], dof[keep], rb[keep], frc[keep]), f"second asset on the GPU, step {t}")
+    log.close()
+    assert moved > 0.5
+    sim.close()
+    monkeypatch.setenv("PPENV_TA_KERNEL", "chain")                  # the compile-time-tree kernel is for the compiled model only
+    with pytest.raises(_lib.PPEnvError, match="differs from the one compiled"):
+        TASim(n, device="cuda:0", model=m)
+
+
+@pytest.mark.gpu
+def test_gpu_7dof_step_on_a_library_built_for_the_second_arm_asset(oracle_lib):
+    """urdf.arm_specs -> use_arm_tables -> modelgen -> _lib.build_for_arm_model: the fused 7-dof step of THAT library follows the
+    changed arm (vs the oracle on the same config); the default library refuses the config instead of stepping the stale model."""
+    import torch
+    import urdf_assets
+    from helpers import ExclusionLog, SensitivityProbe, assert_close, assert_state_close, mask_envs, obs_atol, reward_atol
+    from isaacgym_amd import _lib
+    from isaacgym_amd.env import PPEnv
+    from test_gpu_parity import DevView
+    n = 512
+    with urdf_assets.second_arm_tables():
+        cfg, cfg2 = scene.build_config("TT", num_envs=n, seed=3), scene.build_config("TT", num_envs=n, seed=3)
+    with pytest.raises(_lib.PPEnvError, match="differs from the one compiled"):
+        PPEnv(cfg2, device="cuda:0")
+    L = _lib.load(urdf_assets.build_second_arm_library())
+    env = PPEnv(cfg2, device="cuda:0", library=L)
+    o = oracle_lib.OracleEnv(cfg)
+    probe = SensitivityProbe(oracle_lib, cfg)
+    log = ExclusionLog(f"gpu fused step of the library built for the second arm asset vs oracle [TT, n={n}]", bound=0.005)
+    rng = np.random.default_rng(2)
+    oa, ra = obs_atol(), reward_atol(cfg)
+
+    for t in range(80):
+        a = rng.uniform(-1.2, 1.2, (n, 7)).astype(np.float32)
+        st = o.get_state()
+        env.set_state(st)
+        o.step(a)
+        env.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        keep = ~probe.sensitive(st, a, o)
+        log.add(keep)
+        g = DevView(env)
+        gm, om = mask_envs(g, keep), mask_envs(o, keep)
+        np.testing.assert_array_equal(gm.reset_buf, om.reset_buf)
+        np.testing.assert_array_equal(gm.flags, om.flags)
+        assert_state_close(gm, om, f"second arm on the GPU, step {t}")
+        assert_close(gm.obs_buf, om.obs_buf, f"second arm on the GPU, obs step {t}", atol=oa)
+        assert_close(gm.rew_buf, om.rew_buf, f"second arm on the GPU, rew step {t}", atol=ra)
+    log.close()
+    env.close()
