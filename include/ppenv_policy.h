@@ -72,6 +72,64 @@ int ppenv_mlp_heads_sample(const ppenv_mlp_layer* heads, int32_t num_actions, co
 int ppenv_gae(const float* rewards, const float* values, int32_t ld_values, int64_t values_step, const int64_t* dones, int32_t horizon, int32_t n,
               float gamma, float tau, float reward_scale, float* advantages, float* returns, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * The learner's side of the same network (second half): rl_games' a2c agent runs mini_epochs x minibatches of
+ * forward + backward on the horizon's observations (cfg/train/HumanoidPingpongTiltG1PPO.yaml:73-76: horizon 32, minibatch 32768,
+ * 5 mini-epochs; mixed_precision :50, normalize_input :51).  For a layer y = ELU(z), z = x w^T + b with gradient dz = dy * ELU'(z):
+ *     dx    = dz . w          ppenv_mlp_layer_backward_input  (the forward kernels on the transposed weight image)
+ *     dw    = dz^T . x        ppenv_mlp_layer_backward_weight (transposed LDS reads, ds_read_b64_tr_b16; split over m)
+ *     db    = column sums of dz, produced by the launch that produces dz: per-64-row-block partials + ppenv_mlp_reduce_rows
+ * ELU' needs no saved pre-activation: ELU'(z) = 1 for y > 0, y + 1 otherwise — the launch that computes the dx of layer l + 1 multiplies
+ * it by ELU'(y_l) on the way out (y_l = that layer's input, saved by the forward), so what it writes IS dz_l.
+ * Gradients are fp16 where autocast's are (dz, dx) and fp32 where the parameters are (dw, db); a loss scale is the caller's (linear). */
+
+/* dx in forward form: g->in = dz [m, g->k] (g->k = the forward layer's n), g->w = the TRANSPOSED weights [g->n, g->k] (g->n = the forward
+ * layer's k; ppenv_mlp_cast_weights writes that image), g->out = dx fp16 [m, g->n]; g->bias NULL, g->elu 0, g->out_f32 0.  g->in_f32 = 1
+ * takes the fp32 head gradients [m, num_actions + 1] directly.
+ *   elu_out (fp16 [m, g->n], may be NULL): dx *= ELU'(elu_out) elementwise — elu_out is the ELU output the gradient flows back through.
+ *   colsum_partial (fp32 [ceil(m / 64), ld_colsum], may be NULL): row i receives the column sums of the written dx over rows 64 i ..
+ *   64 i + 63; ppenv_mlp_reduce_rows over those rows is the bias gradient of the layer below.
+ * Strides per batch entry as in ppenv_mlp_layer. */
+int ppenv_mlp_layer_backward_input(const ppenv_mlp_layer* g, const uint16_t* elu_out, int64_t elu_out_stride, int32_t ld_elu_out,
+                                   float* colsum_partial, int64_t colsum_stride, int32_t ld_colsum, void* stream);
+
+typedef struct ppenv_mlp_dw {
+    int32_t m, n, k, batch;   /* of the forward layer: dw[n, k] = sum over the m rows of dz[m, n] x[m, k] */
+    const uint16_t* dz;       int64_t dz_stride;  int32_t lddz;   /* fp16 [m, lddz]  */
+    const uint16_t* x;        int64_t x_stride;   int32_t ldx;    /* fp16 [m, ldx]: the layer's input as the forward read it */
+    float* dw;                int64_t dw_stride;  int32_t lddw;   /* fp32 [n, lddw] */
+    int32_t accumulate;       /* 1: dw += (gradient accumulation), 0: dw = */
+    int32_t splits;           /* workgroups along m per output tile: 0 = chosen by the library; else a power of two <= m / 64 */
+    void* workspace;          size_t workspace_bytes;             /* >= ppenv_mlp_dw_workspace_bytes(d) (0 when splits == 1) */
+} ppenv_mlp_dw;
+
+/* Needs m % 64 == 0, n % 8 == 0, k % 8 == 0, 16-byte aligned rows (lddz, ldx, strides multiples of 8; base pointers 16-byte aligned).
+ * With splits > 1 the partial tiles are summed in a fixed order by a second small launch: results are deterministic. */
+size_t ppenv_mlp_dw_workspace_bytes(const ppenv_mlp_dw* d);
+int ppenv_mlp_layer_backward_weight(const ppenv_mlp_dw* d, void* stream);
+
+/* out[i] (+)= sum over r < rows of partial[r * row_stride + i], i < n, in row order (the bias gradient from backward_input's partials). */
+int ppenv_mlp_reduce_rows(const float* partial, int32_t rows, int64_t row_stride, int64_t n, float* out, int32_t accumulate, void* stream);
+
+/* Column sums of an fp32 [m, n] matrix (the heads' bias gradient from the loss's d mu | d value): workspace of
+ * ppenv_mlp_bias_grad_workspace_bytes(m, n). */
+size_t ppenv_mlp_bias_grad_workspace_bytes(int32_t m, int32_t n);
+int ppenv_mlp_bias_grad_f32(const float* dz, int32_t m, int32_t n, int32_t ld, void* workspace, float* out, int32_t accumulate, void* stream);
+
+/* The per-optimizer-step cast of mixed precision, both operand images at once: fp32 master weights w32 [n, k] -> w16 [n, ldw16] (rows
+ * zero-padded to ldw16; NULL: not wanted) and wt16 [wt_rows, ldwt16] = the transpose, zero beyond k rows / n columns (NULL: not wanted). */
+int ppenv_mlp_cast_weights(const float* w32, int32_t n, int32_t k, int32_t ldw32, uint16_t* w16, int32_t ldw16, uint16_t* wt16, int32_t ldwt16,
+                           int32_t wt_rows, void* stream);
+
+/* rl_games' RunningMeanStd in training mode (normalize_input, yaml:51) on one batch obs [m, k] fp32: batch mean and unbiased batch
+ * variance per column merged into the running float64 (mean, var, count) by the parallel-moments rule; also writes the fp32 mean and
+ * 1 / sqrt(var + eps) that ppenv_mlp_prepare_input reads (either may be NULL).  One launch, one pass over obs.  workspace:
+ * ppenv_running_mean_std_workspace_bytes(m, k) bytes, 8-byte aligned, its first 16 bytes zeroed once by the caller (a ticket the kernel
+ * re-arms itself).  rl_games is not part of the reference: restated from its published running_mean_std.py — parity unpinned. */
+size_t ppenv_running_mean_std_workspace_bytes(int32_t m, int32_t k);
+int ppenv_running_mean_std_update(const float* obs, int32_t m, int32_t k, int32_t ld, double* mean, double* var, double* count, float* mean_f32,
+                                  float* inv_std_f32, float eps, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("PPENV_LIB", os.path.join(_PKG, "lib", "libppenv.so"))   # PPENV_LIB: profiling builds only
 SOURCES = [os.path.join(_PKG, "csrc", "ppenv.hip"), os.path.join(_PKG, "csrc", "ppenv_ta.hip"), os.path.join(_PKG, "csrc", "ppenv_ta_sim.hip"),
-           os.path.join(_PKG, "csrc", "ppenv_ta_chain.hip"), os.path.join(_PKG, "csrc", "ppenv_policy.hip")]
+           os.path.join(_PKG, "csrc", "ppenv_ta_chain.hip"), os.path.join(_PKG, "csrc", "ppenv_policy.hip"), os.path.join(_PKG, "csrc", "ppenv_policy_bwd.hip")]
 HEADERS = [os.path.join(_PKG, "csrc", "ppenv_device.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1.h"), os.path.join(_PKG, "csrc", "ppenv_ta_device.h"), os.path.join(_PKG, "csrc", "ppenv_ta_task.h"), os.path.join(_PKG, "csrc", "ppenv_ta_chain.h"), os.path.join(_PKG, "csrc", "ppenv_model_g1_ta.h"),
            os.path.join(ROOT, "include", "ppenv.h"), os.path.join(ROOT, "include", "ppenv_policy.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-fno-signed-zeros", "-ffinite-math-only", "-fPIC", "-shared"]

@@ -38,6 +38,10 @@ struct Args {
     const _Float16* w; long long w_stride;
     const _Float16* bias; long long bias_stride;
     void* out; long long out_stride;
+    // backward-input mode (ppenv_mlp_layer_backward_input): out = (in . w^T) * ELU'(aux), aux = the saved ELU output this gradient flows
+    // back through; colsum = per-64-row-block column sums of `out` (the bias gradient of the layer below, summed by ppenv_mlp_reduce_rows)
+    const _Float16* aux; long long aux_stride; int ldaux;
+    float* colsum; long long colsum_stride; int ldcs;
 };
 
 // global -> registers: this thread's share of a ROWS x BK fp16 tile (rows row0.., k from k0), zero outside [rows, kmax).
@@ -125,6 +129,25 @@ __device__ __forceinline__ void epilogue(const Args& a, f16v (&acc)[TI][TJ], _Fl
         for (int ib = 0; ib < TI; ib += 2)
 #pragma unroll
             for (int jb = 0; jb < TJ; jb += JW) {
+                // backward-input mode: the block's ELU outputs are fetched BEFORE the accumulators go through the patch, so the loads'
+                // latency hides behind the conversions and LDS writes instead of sitting in front of every store
+                h8 yv[CH];
+                if (a.aux) {
+#pragma unroll
+                    for (int it = 0; it < CH; it++) {
+                        const int row = wrow0 + ib * 32 + it * (64 / CH) + rl, col = wcol0 + jb * 32 + ch * 8;
+                        h8 y = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (row < a.m && col < a.n) {
+                            const _Float16* ap = a.aux + (size_t)b * a.aux_stride + (size_t)row * a.ldaux + col;
+                            if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(ap) & 15) == 0)) y = *reinterpret_cast<const h8*>(ap);
+                            else {
+#pragma unroll
+                                for (int q = 0; q < 8; q++) if (col + q < a.n) y[q] = ap[q];
+                            }
+                        }
+                        yv[it] = y;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < JW; j++) {
                     const int col = wcol0 + (jb + j) * 32 + r;
@@ -139,16 +162,40 @@ __device__ __forceinline__ void epilogue(const Args& a, f16v (&acc)[TI][TJ], _Fl
                         }
                 }
                 __builtin_amdgcn_wave_barrier();   // the patch is this wave's own: DS operations of a wave execute in order
+                float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // backward-input mode: this lane's eight columns summed over the block's rows
 #pragma unroll
                 for (int it = 0; it < CH; it++) {
                     const int prow = it * (64 / CH) + rl, row = wrow0 + ib * 32 + prow, col = wcol0 + jb * 32 + ch * 8;
                     if (row >= a.m || col >= a.n) continue;
-                    const h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
+                    h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
+                    if (a.aux) {                                   // gradient through the ELU whose OUTPUT is aux: ELU'(z) = y > 0 ? 1 : y + 1
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const float yf = (float)yv[it][q];
+                            v[q] = (_Float16)((float)v[q] * (yf > 0.f ? 1.0f : yf + 1.0f));
+                        }
+                    }
+                    if (a.colsum) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) cs[q] += col + q < a.n ? (float)v[q] : 0.f;
+                    }
                     _Float16* dst = out + (size_t)row * a.ldo + col;
                     if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
                     else {
 #pragma unroll
                         for (int q = 0; q < 8; q++) if (col + q < a.n) dst[q] = v[q];
+                    }
+                }
+                if (a.colsum) {                                    // lanes that share ch differ in rl: butterfly over the rl bits, lane rl = 0 writes
+#pragma unroll
+                    for (int d = CH; d < 64; d <<= 1)
+#pragma unroll
+                        for (int q = 0; q < 8; q++) cs[q] += __shfl_xor(cs[q], d);
+                    const int col = wcol0 + jb * 32 + ch * 8, brow = wrow0 + ib * 32;
+                    if (rl == 0 && brow < a.m) {
+                        float* dst = a.colsum + (size_t)b * a.colsum_stride + (size_t)(brow >> 6) * a.ldcs + col;
+#pragma unroll
+                        for (int q = 0; q < 8; q++) if (col + q < a.n) dst[q] = cs[q];
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -802,7 +849,12 @@ extern "C" int ppenv_mlp_heads_sample(const ppenv_mlp_layer* L, int32_t num_acti
     return PPENV_OK;
 }
 
-extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
+namespace {
+struct BwdInput {                  // what ppenv_mlp_layer_backward_input adds to a layer launch (Args::aux / colsum)
+    const _Float16* aux; long long aux_stride; int ldaux;
+    float* colsum; long long colsum_stride; int ldcs;
+};
+int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream) {
     if (!L || !L->in || !L->w || !L->out || L->m <= 0 || L->n <= 0 || L->k <= 0 || L->batch <= 0 || L->lda < L->k || L->ldw < L->k || L->ldo < L->n) {
         ppenv_set_error("ppenv_mlp_layer_forward: NULL pointer or inconsistent sizes (need lda >= k, ldw >= k, ldo >= n)");
         return PPENV_EINVAL;
@@ -811,6 +863,7 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
     Args a{L->m, L->n, L->k, L->lda, L->ldw, L->ldo, L->elu, L->out_f32, L->in, (long long)L->in_stride, L->mean, L->inv_std, L->clip,
            reinterpret_cast<const _Float16*>(L->w), (long long)L->w_stride, reinterpret_cast<const _Float16*>(L->bias), (long long)L->bias_stride,
            L->out, (long long)L->out_stride};
+    if (bw) { a.aux = bw->aux; a.aux_stride = bw->aux_stride; a.ldaux = bw->ldaux; a.colsum = bw->colsum; a.colsum_stride = bw->colsum_stride; a.ldcs = bw->ldcs; }
     // Tile choice.  Measured on the reference's layers (tools/gpu_mlp_layers.py, M = 16384, TFLOP/s on the 2048 -> 1536 layer):
     //   128 x 128, 4 waves of 64 x 64, BK 64, register staging (two workgroups per CU)            600
     //   256 x 128, 4 waves of 128 x 64 (one workgroup of four waves per CU)                        507   too few waves to hide anything
@@ -843,7 +896,9 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
             else cfg = wgs(128, 256) >= 192 ? 513 : 514;
         }
         else cfg = 128;
+        if (bw && (cfg == 516 || cfg == 517)) cfg = 512;   // the ELU' / column-sum store pass lives in the 32 x 32 epilogue
     }
+    if (bw && (cfg == 516 || cfg == 517 || cfg == 600)) { ppenv_set_error("ppenv_mlp_layer_backward_input: PPENV_MLP_TILE names a kernel without the backward store pass"); return PPENV_EINVAL; }
 #define PP_LAUNCH(WM_, WN_, TI_, TJ_, BK_)                                                                                                    \
     do {                                                                                                                                      \
         const dim3 grid((L->n + 32 * TJ_ * WN_ - 1) / (32 * TJ_ * WN_), (L->m + 32 * TI_ * WM_ - 1) / (32 * TI_ * WM_), L->batch), block(64 * WM_ * WN_); \
@@ -879,4 +934,23 @@ extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) {
 #undef PP_LAUNCH
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching mlp_layer_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
+}
+}  // namespace
+
+extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) { return launch_layer(L, nullptr, stream); }
+
+// dX of a layer as a launch of the forward kernels (include/ppenv_policy.h): g describes dx[m, k_fwd] = dz[m, n_fwd] . wt[k_fwd, n_fwd]^T in
+// forward form (in = dz, w = wt: the transposed weights, K-contiguous for this product), bias NULL, elu 0, fp16 out.
+extern "C" int ppenv_mlp_layer_backward_input(const ppenv_mlp_layer* g, const uint16_t* elu_out, int64_t elu_out_stride, int32_t ld_elu_out,
+                                              float* colsum_partial, int64_t colsum_stride, int32_t ld_colsum, void* stream) {
+    if (!g || g->bias || g->elu || g->out_f32) {
+        ppenv_set_error("ppenv_mlp_layer_backward_input: the descriptor must have bias NULL, elu 0 and an fp16 output");
+        return PPENV_EINVAL;
+    }
+    if ((elu_out && ld_elu_out < g->n) || (colsum_partial && ld_colsum < g->n)) {
+        ppenv_set_error("ppenv_mlp_layer_backward_input: ld_elu_out / ld_colsum smaller than the row length");
+        return PPENV_EINVAL;
+    }
+    const BwdInput bw{reinterpret_cast<const _Float16*>(elu_out), (long long)elu_out_stride, ld_elu_out, colsum_partial, (long long)colsum_stride, ld_colsum};
+    return launch_layer(g, &bw, stream);
 }

@@ -31,8 +31,34 @@ class MLPLayer(C.Structure):
                 ("out", C.c_void_p), ("out_stride", C.c_int64), ("ldo", C.c_int32), ("out_f32", C.c_int32)]
 
 
+class MLPDw(C.Structure):
+    """ctypes mirror of ppenv_mlp_dw (include/ppenv_policy.h)."""
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("batch", C.c_int32),
+                ("dz", C.c_void_p), ("dz_stride", C.c_int64), ("lddz", C.c_int32),
+                ("x", C.c_void_p), ("x_stride", C.c_int64), ("ldx", C.c_int32),
+                ("dw", C.c_void_p), ("dw_stride", C.c_int64), ("lddw", C.c_int32),
+                ("accumulate", C.c_int32), ("splits", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 def _lib_policy():
     L = _lib.lib()
+    if getattr(L, "_policy_bound", False):
+        return L
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.ppenv_mlp_layer_backward_input.argtypes = [C.POINTER(MLPLayer), vp, i64, i32, vp, i64, i32, vp]
+    L.ppenv_mlp_dw_workspace_bytes.restype = C.c_size_t
+    L.ppenv_mlp_dw_workspace_bytes.argtypes = [C.POINTER(MLPDw)]
+    L.ppenv_mlp_layer_backward_weight.argtypes = [C.POINTER(MLPDw), vp]
+    L.ppenv_mlp_reduce_rows.argtypes = [vp, i32, i64, i64, vp, i32, vp]
+    L.ppenv_mlp_bias_grad_workspace_bytes.restype = C.c_size_t
+    L.ppenv_mlp_bias_grad_workspace_bytes.argtypes = [i32, i32]
+    L.ppenv_mlp_bias_grad_f32.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp]
+    L.ppenv_mlp_cast_weights.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, vp]
+    L.ppenv_running_mean_std_workspace_bytes.restype = C.c_size_t
+    L.ppenv_running_mean_std_workspace_bytes.argtypes = [i32, i32]
+    L.ppenv_running_mean_std_update.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.c_float, vp, vp]
+    L._policy_bound = True
     L.ppenv_mlp_layer_forward.argtypes = [C.POINTER(MLPLayer), C.c_void_p]
     L.ppenv_mlp_prepare_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
     L.ppenv_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -94,6 +120,103 @@ def heads_sample(out, x, w, bias, num_actions, actions, sigma, seed, counter, lo
                                                     torch.cuda.current_stream(x.device).cuda_stream))
 
 
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def layer_backward_input(dx, dz, wt, elu_out=None, colsum_partial=None, batch=1, dz_stride=0, wt_stride=0, dx_stride=0, elu_out_stride=0,
+                         colsum_stride=0, m=None, n=None, k=None):
+    """ppenv_mlp_layer_backward_input on torch tensors: dx [M, n] (fp16) = (dz [M, k] . wt [n, k]^T) * ELU'(elu_out) — n = the forward
+    layer's input width, k = its output width, wt = its weights transposed; colsum_partial [ceil(M / 64), >= n] fp32 receives the
+    per-64-row column sums of dx (the bias gradient of the layer below, once reduce_rows has summed them)."""
+    d = _descriptor(dx, dz, wt, None, False, batch=batch, in_stride=dz_stride, w_stride=wt_stride, out_stride=dx_stride, m=m, n=n, k=k)
+    _lib.check(_lib_policy().ppenv_mlp_layer_backward_input(
+        C.byref(d), _ptr(elu_out), elu_out_stride, elu_out.stride(0) if elu_out is not None else 0,
+        _ptr(colsum_partial), colsum_stride, colsum_partial.stride(0) if colsum_partial is not None else 0, _stream(dz)))
+
+
+def _dw_descriptor(dw, dz, x, batch, dz_stride, x_stride, dw_stride, m, n, k, accumulate, splits, workspace):
+    d = MLPDw()
+    d.m, d.n, d.k, d.batch = (dz.shape[0] if m is None else m), (dw.shape[-2] if n is None else n), (dw.shape[-1] if k is None else k), batch
+    d.dz, d.dz_stride, d.lddz = dz.data_ptr(), dz_stride, dz.stride(0)
+    d.x, d.x_stride, d.ldx = x.data_ptr(), x_stride, x.stride(0)
+    d.dw, d.dw_stride, d.lddw = dw.data_ptr(), dw_stride, dw.stride(-2)
+    d.accumulate, d.splits = int(accumulate), int(splits)
+    d.workspace, d.workspace_bytes = _ptr(workspace), (workspace.numel() * workspace.element_size() if workspace is not None else 0)
+    return d
+
+
+def dw_workspace_bytes(m, n, k, batch=1, splits=0):
+    d = MLPDw()
+    d.m, d.n, d.k, d.batch, d.splits = m, n, k, batch, splits
+    return int(_lib_policy().ppenv_mlp_dw_workspace_bytes(C.byref(d)))
+
+
+def layer_backward_weight(dw, dz, x, batch=1, dz_stride=0, x_stride=0, dw_stride=0, m=None, n=None, k=None, accumulate=False, splits=0, workspace=None):
+    """ppenv_mlp_layer_backward_weight on torch tensors: dw [n, k] fp32 (+)= dz [M, n]^T . x [M, k] (fp16 operands, fp32 accumulation on
+    the matrix cores; transposed LDS reads).  workspace: a byte tensor of dw_workspace_bytes(...) (allocated here when missing)."""
+    if workspace is None:
+        need = dw_workspace_bytes(dz.shape[0] if m is None else m, dw.shape[-2] if n is None else n, dw.shape[-1] if k is None else k, batch, splits)
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=dz.device)
+    d = _dw_descriptor(dw, dz, x, batch, dz_stride, x_stride, dw_stride, m, n, k, accumulate, splits, workspace)
+    _lib.check(_lib_policy().ppenv_mlp_layer_backward_weight(C.byref(d), _stream(dz)))
+
+
+def reduce_rows(out, partial, rows=None, n=None, accumulate=False):
+    """out [n] (+)= the sum of partial's first `rows` rows (fp32, in row order)."""
+    rows = partial.shape[0] if rows is None else rows
+    n = out.numel() if n is None else n
+    _lib.check(_lib_policy().ppenv_mlp_reduce_rows(partial.data_ptr(), rows, partial.stride(0), n, out.data_ptr(), int(accumulate), _stream(out)))
+
+
+def bias_grad_f32(out, dz, accumulate=False, workspace=None):
+    """out [n] fp32 (+)= column sums of dz [M, n] fp32 (the heads' bias gradient)."""
+    L = _lib_policy()
+    m, n = dz.shape
+    if workspace is None:
+        workspace = torch.empty(int(L.ppenv_mlp_bias_grad_workspace_bytes(m, n)), dtype=torch.uint8, device=dz.device)
+    _lib.check(L.ppenv_mlp_bias_grad_f32(dz.data_ptr(), m, n, dz.stride(0), workspace.data_ptr(), out.data_ptr(), int(accumulate), _stream(dz)))
+
+
+def cast_weights(w32, w16=None, wt16=None):
+    """fp32 master weights [n, k] -> w16 [n, >= k] (zero-padded rows) and / or wt16 [>= k, >= n] = the transpose (zero-padded), fp16."""
+    n, k = w32.shape
+    _lib.check(_lib_policy().ppenv_mlp_cast_weights(w32.data_ptr(), n, k, w32.stride(0), _ptr(w16), w16.stride(0) if w16 is not None else 0,
+                                                    _ptr(wt16), wt16.stride(0) if wt16 is not None else 0, wt16.shape[0] if wt16 is not None else 0, _stream(w32)))
+
+
+class RunningMeanStd:
+    """rl_games' RunningMeanStd (normalize_input: True, cfg/train/HumanoidPingpongTiltG1PPO.yaml:51) with the training-mode update as
+    one launch (ppenv_running_mean_std_update): float64 running mean / var / count as rl_games keeps them, plus the fp32 mean and
+    1 / sqrt(var + eps) the policy's normaliser reads.  rl_games itself is absent from the reference: restated from its published
+    running_mean_std.py (unbiased batch variance, parallel-moments merge) — parity unpinned."""
+
+    def __init__(self, num_obs, device, eps=1e-5):
+        self.device, self.eps, self.num_obs = torch.device(device), float(eps), int(num_obs)
+        self.running_mean = torch.zeros(num_obs, dtype=torch.float64, device=self.device)
+        self.running_var = torch.ones(num_obs, dtype=torch.float64, device=self.device)
+        self.count = torch.ones((), dtype=torch.float64, device=self.device)
+        self.mean = torch.zeros(num_obs, dtype=torch.float32, device=self.device)
+        self.inv_std = torch.rsqrt(torch.ones(num_obs, dtype=torch.float32, device=self.device) + eps)
+        self._ws, self._ws_rows = None, 0
+
+    def update(self, obs):
+        """obs [M, num_obs] fp32 on the device: one pass; mean / inv_std are refreshed in place (a NativeMLP given these tensors by
+        set_normalization_tensors sees the new statistics at its next forward)."""
+        L = _lib_policy()
+        m, k = obs.shape
+        assert obs.dtype == torch.float32 and obs.device == self.device and obs.stride(1) == 1 and k == self.num_obs
+        if self._ws is None or self._ws_rows < m:
+            self._ws = torch.zeros(int(L.ppenv_running_mean_std_workspace_bytes(m, k)) // 8 + 1, dtype=torch.float64, device=self.device)   # zeroed: the ticket
+            self._ws_rows = m
+        _lib.check(L.ppenv_running_mean_std_update(obs.data_ptr(), m, k, obs.stride(0), self.running_mean.data_ptr(), self.running_var.data_ptr(),
+                                                   self.count.data_ptr(), self.mean.data_ptr(), self.inv_std.data_ptr(), self.eps, self._ws.data_ptr(), _stream(obs)))
+
+
 class NativeMLP:
     """Actor + critic forward on the MFMA kernel.  `actor` / `critic`: lists of (weight [out, in], bias [out]) fp32 tensors, hidden
     layers first, the head last (what `[m for m in net if isinstance(m, nn.Linear)]` yields for the reference's architecture)."""
@@ -145,6 +268,12 @@ class NativeMLP:
         else:
             self.mean = mean.detach().to(self.device, torch.float32).contiguous()
             self.inv_std = torch.rsqrt(var.detach().to(self.device, torch.float32) + eps).contiguous()
+
+    def set_normalization_tensors(self, mean, inv_std):
+        """Use the caller's fp32 [num_obs] statistics tensors in place (RunningMeanStd.mean / .inv_std: updated by its kernel, read by
+        the next forward without a copy)."""
+        assert mean.dtype == inv_std.dtype == torch.float32 and mean.device == self.device and mean.numel() == inv_std.numel() == self.num_obs
+        self.mean, self.inv_std = mean, inv_std
 
     def _alloc(self, m):
         z = lambda n, dt: torch.empty((m, n), dtype=dt, device=self.device)
@@ -204,6 +333,108 @@ class NativeMLP:
         dims = [num_obs] + list(units)
         per_net = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
         return 2 * m * (2 * per_net + units[-1] * (num_actions + 1))
+
+
+class NativeMLPLearner:
+    """The learner's forward + backward of the same network on the matrix cores (rl_games' a2c minibatch step under
+    mixed_precision, cfg/train/HumanoidPingpongTiltG1PPO.yaml:50,73-76).  fp32 MASTER parameters live here in the layout of the fp16
+    operand images (per hidden layer `w32[i]` [2, n, k] = actor | critic and `b32[i]` [2, n]; the heads `mu_w` [A, u], `mu_b` [A],
+    `value_w` [1, u], `value_b` [1]); `sync_weights()` is the per-optimizer-step cast (both operand images in one launch per matrix);
+    `forward(obs)` is NativeMLP's (its activation buffers are what the backward reads); `backward(d_head)` takes d loss / d [mu | value]
+    ([M, A + 1] fp32, already multiplied by the loss scale if one is used) and fills `grads` — fp32 tensors of the parameters' shapes.
+    An optimizer (rl_games: Adam) steps on `parameters()` / `grads` and calls `sync_weights()`; that part stays PyTorch."""
+
+    def __init__(self, actor, critic, num_obs, device, mean=None, var=None, eps=1e-5, clip=5.0):
+        self.net = NativeMLP(actor, critic, num_obs, device, mean=mean, var=var, eps=eps, clip=clip)
+        self.device = self.net.device
+        f = lambda t: t.detach().to(self.device, torch.float32).contiguous()
+        self.w32 = [torch.stack([f(wa), f(wc)]).contiguous() for (wa, _), (wc, _) in zip(actor[:-1], critic[:-1])]
+        self.b32 = [torch.stack([f(ba), f(bc)]).contiguous() for (_, ba), (_, bc) in zip(actor[:-1], critic[:-1])]
+        self.mu_w, self.mu_b, self.value_w, self.value_b = f(actor[-1][0]), f(actor[-1][1]), f(critic[-1][0]), f(critic[-1][1])
+        u, na, net = self.net.units, self.net.num_actions, self.net
+        assert all(x % 64 == 0 for x in u), "hidden widths must be multiples of 64 (the LDS-DMA tile kernels' K step)"
+        self.nh = (na + 1 + 7) // 8 * 8                                   # head columns padded to whole 16-byte chunks
+        z16 = lambda *shape: torch.zeros(shape, dtype=torch.float16, device=self.device)
+        z32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
+        # transposed operand images for dX: layer i >= 1 [2, k_i, n_i]; the heads [2 u, nh] (block-diagonal like head_w)
+        self.wt = [None] + [z16(2, u[i - 1], u[i]) for i in range(1, len(u))]
+        self.head_w32 = z32(na + 1, 2 * u[-1])                              # the block-diagonal master image the head launches read
+        self.head_wt = z16(2 * u[-1], self.nh)
+        self.grads = dict(w=[z32(*w.shape) for w in net.w], b=[z32(2, n) for n in u], head_w=z32(self.nh, 2 * u[-1]), head_b=z32(na + 1))
+        self._rows = 0
+        self.sync_weights()
+
+    def parameters(self):
+        return self.w32 + self.b32 + [self.mu_w, self.mu_b, self.value_w, self.value_b]
+
+    def gradients(self):
+        """Gradients in the order and shapes of parameters() (views of `grads`; layer 1's weight gradient without its K padding)."""
+        g, u, na = self.grads, self.net.units, self.net.num_actions
+        return ([g["w"][i][..., :self.w32[i].shape[-1]] for i in range(len(u))] + g["b"] +
+                [g["head_w"][:na, :u[-1]], g["head_b"][:na], g["head_w"][na:na + 1, u[-1]:], g["head_b"][na:]])
+
+    def sync_weights(self):
+        """fp32 masters -> the fp16 operand images of the forward (w, zero-padded rows) and of dX (wt, transposed)."""
+        net, u, na = self.net, self.net.units, self.net.num_actions
+        for i in range(len(u)):
+            for j in range(2):
+                cast_weights(self.w32[i][j], net.w[i][j], self.wt[i][j] if i else None)
+            net.b[i].copy_(self.b32[i])
+        self.head_w32[:na, :u[-1]] = self.mu_w
+        self.head_w32[na:, u[-1]:] = self.value_w
+        cast_weights(self.head_w32, net.head_w, self.head_wt)
+        net.head_b.copy_(torch.cat([self.mu_b, self.value_b]))
+
+    def _alloc(self, m):
+        u, dev = self.net.units, self.device
+        wmax = 2 * max(u)
+        self.dz = [torch.empty((m, wmax), dtype=torch.float16, device=dev) for _ in range(2)]      # ping-pong: dz of layer i / i - 1
+        self.dhead16 = torch.zeros((m, self.nh), dtype=torch.float16, device=dev)
+        self.colsum = torch.empty(((m + 63) // 64, wmax), dtype=torch.float32, device=dev)
+        need = max([dw_workspace_bytes(m, 2 * u[0], self.net.w[0].shape[-1])] + [dw_workspace_bytes(m, u[i], u[i - 1], batch=2) for i in range(1, len(u))] +
+                   [dw_workspace_bytes(m, self.nh, 2 * u[-1]), 16])
+        self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.ws_b = torch.empty(int(_lib_policy().ppenv_mlp_bias_grad_workspace_bytes(m, self.net.num_actions + 1)) + 16, dtype=torch.uint8, device=dev)
+        self._rows = m
+
+    def attach_running_mean_std(self, rms):
+        """Input statistics that learn (normalize_input: True): `forward(obs, update_stats=True)` first merges the batch into `rms`
+        (RunningMeanStd.update, one launch), then normalises with the refreshed statistics — rl_games' order in training mode."""
+        self.rms = rms
+        self.net.set_normalization_tensors(rms.mean, rms.inv_std)
+
+    def forward(self, obs, update_stats=False):
+        if update_stats:
+            self.rms.update(obs)
+        return self.net.forward(obs)
+
+    def backward(self, d_head, accumulate=False):
+        """d_head [M, A + 1] fp32 = d loss / d [mu | value] of the rows of the last forward (M a multiple of 64)."""
+        net, u, na = self.net, self.net.units, self.net.num_actions
+        m = d_head.shape[0]
+        assert m == net._rows and m % 64 == 0 and d_head.dtype == torch.float32 and d_head.shape[1] == na + 1 and d_head.stride(1) == 1
+        if m != self._rows:
+            self._alloc(m)
+        g, nl, blocks = self.grads, len(u), (m + 63) // 64
+        prepare_input(self.dhead16, d_head)                                # cast + pad to whole chunks (no statistics)
+        bias_grad_f32(g["head_b"], d_head, accumulate, self.ws_b)
+        layer_backward_weight(g["head_w"], self.dhead16, net.h[-1], accumulate=accumulate, workspace=self.ws)
+        cur = self.dz[(nl - 1) & 1][:, :2 * u[-1]]
+        layer_backward_input(cur, self.dhead16, self.head_wt, elu_out=net.h[-1], colsum_partial=self.colsum)
+        for i in range(nl - 1, -1, -1):
+            n = u[i]
+            reduce_rows(g["b"][i].view(-1), self.colsum, rows=blocks, n=2 * n, accumulate=accumulate)
+            if i == 0:                                                     # both networks read the same rows: one problem over the stacked weights
+                layer_backward_weight(g["w"][0].view(2 * n, -1), cur, net.x16, accumulate=accumulate, workspace=self.ws)
+                break
+            k = u[i - 1]
+            layer_backward_weight(g["w"][i], cur, net.h[i - 1], batch=2, dz_stride=n, x_stride=k, dw_stride=n * k, m=m, n=n, k=k,
+                                  accumulate=accumulate, workspace=self.ws)
+            nxt = self.dz[(i - 1) & 1][:, :2 * k]
+            layer_backward_input(nxt, cur, self.wt[i], elu_out=net.h[i - 1], colsum_partial=self.colsum, batch=2, dz_stride=n, wt_stride=k * n,
+                                 dx_stride=k, elu_out_stride=k, colsum_stride=k, m=m, n=k, k=n)
+            cur = nxt
+        return self.gradients()
 
 
 # ---- a trained rl_games checkpoint on the native forward (the reference's `train.py test=True checkpoint=...` play mode) ---------------
