@@ -341,10 +341,14 @@ struct MovingGeom {
 // N = 16384 half of the chip's SIMDs have no wave at all, so the 64 envs of a workgroup can be dealt to BW ball waves of 64 / BW envs
 // each (the upper lanes idle): fewer lanes per wave = a smaller union = a shorter chain, on SIMDs that were empty anyway.  The arm wave
 // keeps all 64 envs (its instruction stream has no divergence to shrink).
-template <class T, int A, int G, int BW = 1>
+// DR (round 3): the domain-randomisation tables read by the wave that owns the quantity — drive gains and link masses, the
+// action noise and the body block's observation noise on the arm wave; restitution / friction scales and the rest of the row's noise on the
+// ball wave.  Same arithmetic as step_kernel<T, true> (the one-wave instantiation: 427 VGPRs + spills), on the fast schedule.
+template <class T, int A, int G, int BW = 1, bool DR = false>
 __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on,
-                                                                       uint32_t* status, int dbg_drop_handoff) {
+                                                                       uint32_t* status, int dbg_drop_handoff, const DRTables drt = DRTables{}) {
     static_assert(BW == 1 || G == 0, "narrow ball waves: each sweeps its own geometry (the s_bflag slot protocol has one consumer)");
+    static_assert(!DR || A == 1, "the randomisation tables are [7][N]: one humanoid");
     constexpr int kGeo = MovingGeom<T>::count();
     // Who writes dof_pos / dof_vel / dof_force.  With one humanoid the arm wave is the critical path and would sit waiting
     // for the ball wave's reset decision just to pick between q and the initial pose: the ball wave, which has both, stores
@@ -379,13 +383,28 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
         PP_STAMP_AT(0);
         float q[ND], qd[ND], target[ND], tau[ND];
         JointSave js[ND];
+        EnvDR dr;
+        uint32_t dr_ep0 = 0;
         if (active) {
+            if (DR) {   // this env's gains / masses (a NULL table = scale 1) and the keys of its noise draws: episode and progress at the step's start
+#pragma unroll
+                for (int d = 0; d < ND; d++) {
+                    dr.kp[d] = drt.kp ? drt.kp[(size_t)d * n + i] : 1.f;
+                    dr.kd[d] = drt.kd ? drt.kd[(size_t)d * n + i] : 1.f;
+                    dr.ms[d] = drt.ms ? drt.ms[(size_t)d * n + i] : 1.f;
+                }
+                dr.act_sigma = drt.act_sigma; dr.obs_sigma = drt.obs_sigma;
+                dr.key_progress = (uint32_t)b.progress[(size_t)i * A];
+                dr_ep0 = b.episode[i];
+            }
 #pragma unroll
             for (int d = 0; d < ND; d++) {
                 q[d] = b.dof_pos[(size_t)(arm * ND + d) * n + i];
                 qd[d] = b.dof_vel[(size_t)(arm * ND + d) * n + i];
                 tau[d] = 0.f;
-                target[d] = pd_target(actions[((size_t)i * A + arm) * ND + d], T::drive(d).lower, T::drive(d).upper, K.clip_actions);   // VecTask.step clamp + TT:1008
+                float act = actions[((size_t)i * A + arm) * ND + d];
+                if (DR) { if (dr.act_sigma > 0.f) act += dr.act_sigma * dr_gauss(K.seed, (uint32_t)(K.env_id_offset + i), dr_ep0, dr.key_progress, (uint32_t)d); }   // as simulate_env: before the clamp
+                target[d] = pd_target(act, T::drive(d).lower, T::drive(d).upper, K.clip_actions);   // VecTask.step clamp + TT:1008
             }
         }
         PP_STAMP_AT(1);
@@ -405,7 +424,7 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
                     NullVisitor nv;   // velocity recursion only: the world transforms of this sweep are dead code
                     fk_sweep<T>(S, q, qd, js, nv);
                 }
-                arm_substep<T>(S, js, q, qd, target, K.h, tau);
+                arm_substep<T, DR>(S, js, q, qd, target, K.h, tau, &dr);
 #pragma unroll
                 for (int d = 0; d < ND; d++) { s_q[s][arm * 2 * ND + d][lane] = q[d]; s_q[s][arm * 2 * ND + ND + d][lane] = qd[d]; }
                 if (s + 1 == substeps) {
@@ -443,7 +462,9 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
 #pragma unroll
             for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
             LdsRowStore store{&s_obs[(arm * kBlock + lane) * kObsStride]};
-            write_obs_bodies(bpos, bvel, S.hinv, store);
+            NoisyRowStore nstore{&s_obs[(arm * kBlock + lane) * kObsStride], dr.obs_sigma, K.seed, (uint32_t)(K.env_id_offset + i), dr_ep0, dr.key_progress};
+            if (DR && drt.obs_sigma > 0.f) write_obs_bodies(bpos, bvel, S.hinv, nstore);
+            else write_obs_bodies(bpos, bvel, S.hinv, store);
         }
         PP_STAMP_AT(6);
         __builtin_amdgcn_wave_barrier();   // columns [0,60) of this agent's rows were written by this wave only: no rendezvous needed
@@ -477,6 +498,8 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
     ArmGeom<T::kShapes> g[A];
     V3 bound[A];
     float qs[A * ND], qds[A * ND];
+    EnvDR bdr;
+    uint32_t bdr_ep0 = 0;
 #pragma unroll
     for (int a = 0; a < A; a++) rew[a] = 0.f;
     if (bactive) {
@@ -499,6 +522,13 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
         pre_vx = st.ball.v.x;   // TT:1020
 #pragma unroll
         for (int a = 0; a < A; a++) { static_geometry<T>(K.site[a], g[a]); bound[a] = ld3(K.site[a].bound_center); }
+        if (DR) {
+            bdr.es = drt.es ? drt.es[bi] : 1.f;
+            bdr.fs = drt.fs ? drt.fs[bi] : 1.f;
+            bdr.obs_sigma = drt.obs_sigma;
+            bdr.key_progress = (uint32_t)st.progress;
+            bdr_ep0 = st.episode;
+        }
     }
     PP_STAMP_AT(17);
     for (int s = 0; s < substeps; s++) {
@@ -528,7 +558,7 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
                 }
             }
             PP_STAMP_AT(25);
-            ball_substep<T, A>(K, st.ball, g, bound);
+            ball_substep<T, A, DR>(K, st.ball, g, bound, &bdr);
         }
         if (G) publish(&s_bflag, s + 1);
         PP_STAMP_AT(19 + 2 * s);
@@ -551,7 +581,13 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
             stores[a].row = &s_obs[(a * kBlock + env) * kObsStride];
         }
         next_serve = mk(s_serve[0][env], s_serve[1][env], s_serve[2][env]);   // drawn by arm wave 0
-        post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + bi), st, bodies, pre_vx, &next_serve, rew, reset, stores);
+        if (DR && drt.obs_sigma > 0.f) {
+            NoisyRowStore nstores[A];
+#pragma unroll
+            for (int a = 0; a < A; a++) nstores[a] = NoisyRowStore{stores[a].row, bdr.obs_sigma, K.seed, (uint32_t)(K.env_id_offset + bi), bdr_ep0, bdr.key_progress};
+            post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + bi), st, bodies, pre_vx, &next_serve, rew, reset, nstores);
+        } else
+            post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + bi), st, bodies, pre_vx, &next_serve, rew, reset, stores);
         s_reset[env] = (int)reset;
     }
     publish(&s_flag_ball, 1);          // hands the reset decision to the arm waves
@@ -1385,9 +1421,13 @@ static int launch_step(ppenv* e, const DevBuffers& buf, const float* actions_dev
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = check_status(e)) return rc;
     if (int rc = use_device(e)) return rc;
-    if (e->dr_on) {   // domain randomisation: the table-reading instantiation of the one-wave kernel
-        hipLaunchKernelGGL((step_kernel<ModelG1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, buf, actions_dev,
-                           e->serve_on, e->dr);
+    if (e->dr_on) {   // domain randomisation: the table-reading instantiation — of the two-wave schedule (default) or of the one-wave kernel (PPENV_STEP_KERNEL=fused)
+        if (e->split)
+            hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, buf,
+                               actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff, e->dr);
+        else
+            hipLaunchKernelGGL((step_kernel<ModelG1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, buf, actions_dev,
+                               e->serve_on, e->dr);
         PP_HIP(hipGetLastError());
         return PPENV_OK;
     }

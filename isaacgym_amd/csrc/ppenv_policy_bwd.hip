@@ -223,6 +223,45 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
+// the same sum for MANY rows of a narrow matrix (the 512 per-block column sums behind a bias gradient at M = 32768): one thread walking all the
+// rows would be 512 dependent round trips to memory.  A workgroup owns 64 columns: thread -> float4 column tid & 15, row class tid >> 4 (rows
+// rc, rc + 16, ... four loads in flight), then the 16 classes are added through LDS in class order — a fixed order, so still deterministic.
+__global__ __launch_bounds__(256) void reduce_tall_kernel(const float* __restrict__ src, int rows, long long row_stride, long long n, float* __restrict__ dst,
+                                                          int accumulate) {
+    __shared__ float part[16][65];
+    const int cg = threadIdx.x & 15, rc = threadIdx.x >> 4;
+    const long long c0 = (long long)blockIdx.x * 64 + cg * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < n) {
+        const bool vec = c0 + 4 <= n && (row_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        int r = rc;
+        for (; r + 48 < rows && vec; r += 64) {
+            f4v v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const f4v*>(src + (size_t)(r + 16 * u) * row_stride + c0);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) s[e] += v[u][e];
+        }
+        for (; r < rows; r += 16)
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (c0 + e < n) s[e] += src[(size_t)r * row_stride + c0 + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) part[rc][cg * 4 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+        if (c < n) {
+            float t = accumulate ? dst[c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) t += part[i][threadIdx.x];
+            dst[c] = t;
+        }
+    }
+}
+
 // column sums of an fp32 [m, n] matrix per block of 1024 rows (the heads' bias gradient: n = num_actions + 1): thread -> column t & 31 of
 // the 32-column group blockIdx.y, row class t >> 5; partial[blockIdx.x][n]
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ in, int m, int n, int ld, float* __restrict__ partial) {
@@ -371,8 +410,11 @@ extern "C" int ppenv_mlp_layer_backward_weight(const ppenv_mlp_dw* d, void* stre
 
 extern "C" int ppenv_mlp_reduce_rows(const float* partial, int32_t rows, int64_t row_stride, int64_t n, float* out, int32_t accumulate, void* stream) {
     if (!partial || !out || rows <= 0 || n <= 0 || row_stride < n) { ppenv_set_error("ppenv_mlp_reduce_rows: NULL pointer or inconsistent sizes"); return PPENV_EINVAL; }
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, partial, rows, (long long)row_stride,
-                       (long long)n, out, accumulate);
+    if (rows > 32)      // many rows (the per-64-row-block column sums): rows spread over the workgroup
+        hipLaunchKernelGGL(reduce_tall_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partial, rows, (long long)row_stride, (long long)n, out, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, partial, rows, (long long)row_stride,
+                           (long long)n, out, accumulate);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching reduce_rows_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }

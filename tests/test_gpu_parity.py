@@ -520,10 +520,11 @@ def test_randomization_off_is_bit_identical_and_unit_tables_change_nothing(torch
     a.close(); b.close()
 
 
-def test_unit_randomization_tables_reproduce_the_plain_kernel(torch_cuda, monkeypatch):
+@pytest.mark.parametrize("schedule", ["split", "fused"])
+def test_unit_randomization_tables_reproduce_the_plain_kernel(torch_cuda, monkeypatch, schedule):
     torch = torch_cuda
     n = 512
-    monkeypatch.setenv("PPENV_STEP_KERNEL", "fused")       # the DR instantiation is the one-wave kernel with table reads
+    monkeypatch.setenv("PPENV_STEP_KERNEL", schedule)      # the DR instantiation of either schedule = that schedule with table reads
     a, b = make_env(scene.build_config("TT", num_envs=n, seed=9)), make_env(scene.build_config("TT", num_envs=n, seed=9))
     b.set_randomization(**{k: np.ones_like(v) for k, v in _dr_tables(n, np.random.default_rng(0)).items()})
     gen = torch.Generator(device="cuda").manual_seed(3)
@@ -539,10 +540,13 @@ def test_unit_randomization_tables_reproduce_the_plain_kernel(torch_cuda, monkey
     a.close(); b.close()
 
 
-def test_randomized_step_matches_oracle(torch_cuda, oracle_lib):
+@pytest.mark.parametrize("schedule", ["split", "fused"])
+def test_randomized_step_matches_oracle(torch_cuda, oracle_lib, monkeypatch, schedule):
     """Randomisation on: per-env stiffness / damping / mass / restitution / friction tables, action and observation noise, another
-    gravity — the kernel against the oracle with the same tables, restarted from the oracle's state every step."""
+    gravity — the kernel against the oracle with the same tables, restarted from the oracle's state every step.  Both table-reading
+    instantiations: the two-wave schedule (round 3, the default) and the one-wave kernel."""
     torch = torch_cuda
+    monkeypatch.setenv("PPENV_STEP_KERNEL", schedule)
     n = 768
     cfg = scene.build_config("TT", num_envs=n, seed=17)
     o = oracle_lib.OracleEnv(cfg, threads=8)
@@ -557,7 +561,7 @@ def test_randomized_step_matches_oracle(torch_cuda, oracle_lib):
     env.set_randomization(**tabs, **kw)
     env.set_gravity(-9.8 - 0.3)
     oa, ra = obs_atol() + 2e-6, reward_atol(cfg)
-    log = ExclusionLog("gpu randomised fused step vs oracle [TT]", bound=0.01)
+    log = ExclusionLog(f"gpu randomised fused step vs oracle [TT, {schedule}]", bound=0.01)
     resets = 0
     for t in range(120):
         actions = rng.uniform(-1.2, 1.2, (n, 7)).astype(np.float32)

@@ -2,7 +2,7 @@
 """Per-layer timing of the native policy BACKWARD at the learner's minibatch (default M = 32768, cfg/train/HumanoidPingpongTiltG1PPO.yaml:75)
 next to PyTorch / hipBLASLt on the same fp16 operands:
     dX  = (dZ . W) * ELU'(y)   native: one launch (forward tile kernels on the transposed weight image, ELU' and the bias-gradient
-                               column sums in the store pass)          torch: matmul + elementwise ELU' + a column-sum reduction
+                               column sums in the store pass)          torch: matmul + aten.elu_backward + a column sum (what autograd launches)
     dW  = dZ^T . X             native: transposed LDS reads, split over M + fixed-order reduce      torch: matmul of the transposes
 Run on the GPU box:  python tools/gpu_mlp_bwd_layers.py [M] [num_obs] [--splits S]"""
 import os
@@ -67,13 +67,12 @@ for i in range(len(UNITS) - 1, -1, -1):
         layer_backward_input(dx, dz, wt, elu_out=x, colsum_partial=cs, batch=2, dz_stride=n, wt_stride=k * n, dx_stride=k, elu_out_stride=k, colsum_stride=k, m=m, n=k, k=n)
         reduce_rows(db, cs, rows=blocks, n=2 * k)
 
-    def t_dx():
+    def t_dx():     # what autograd launches per network: the matmul, elu_backward on the saved output, the bias gradient's column sum
         out = []
         for j in range(2):
             g = torch.matmul(dz[:, j * n:(j + 1) * n], w[j])
-            y = x[:, j * k:(j + 1) * k]
-            g = g * torch.where(y > 0, torch.ones_like(y), y + 1)
-            out.append((g, g.float().sum(dim=0)))
+            g = torch.ops.aten.elu_backward(g, 1.0, 1.0, 1.0, True, x[:, j * k:(j + 1) * k])
+            out.append((g, g.sum(dim=0)))
         return out
     dwn, dwt, dxn, dxt = timeit(f_dw), timeit(t_dw), timeit(f_dx), timeit(t_dx)
     print("layer %d: %4d -> %4d x2   dX native %7.1f us %5.0f TF  torch %7.1f us %5.0f TF   |   dW native %7.1f us %5.0f TF  torch %7.1f us %5.0f TF" %

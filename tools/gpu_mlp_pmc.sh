@@ -1,10 +1,11 @@
 #!/bin/bash
-# PMC passes over the policy layers (tools/gpu_mlp_layers.py): matrix-core busy cycles and LDS bank conflicts per kernel.
+# PMC passes over the policy layers (tools/gpu_mlp_layers.py; MLP_TOOL=tools/gpu_mlp_bwd_layers.py: the backward): matrix-core busy cycles and LDS bank
+# conflicts per kernel.
 # Counters in their own runs with --kernel-trace only (gpurun refuses --pmc together with the API trace domains).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmc_mlp; rm -rf $out; mkdir -p $out
 pass() { name=$1; shift
-  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python tools/gpu_mlp_layers.py ${MLP_M:-16384} ${MLP_K:-80} > $out/$name.log 2>&1 || { tail -5 $out/$name.log; return 1; }
+  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python ${MLP_TOOL:-tools/gpu_mlp_layers.py} ${MLP_M:-16384} ${MLP_K:-80} > $out/$name.log 2>&1 || { tail -5 $out/$name.log; return 1; }
 }
 pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES || exit 1
 pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS || exit 1
@@ -14,7 +15,7 @@ import collections, csv, glob, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_mlp/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(mlp_[a-z0-9_]+(<[^>]*>)?|prepare_input_kernel)", row["Kernel_Name"])
+        m = re.search(r"(mlp_[a-z0-9_]+(<[^>]*>)?|prepare_input_kernel|reduce_[a-z]+_kernel)", row["Kernel_Name"])
         if m:
             acc[m.group(1) + " grid " + row.get("Grid_Size", "?")][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open("gpurun_out/pmc_mlp/summary.csv", "w") as out:
