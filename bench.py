@@ -447,6 +447,93 @@ def cpu_baseline_rollout(num_envs, cores, seconds=4.0):
             "sample": f"{steps} rollout steps at num_envs={n}: PyTorch fp32 MLP pair on {cores} threads + the oracle's 27-dof step, {dt:.1f} s"}
 
 
+def learner_config(device, m, cores, cpu=True):
+    """The learner's side of BASELINE configs[4] (train.py + RL-Games PPO on the 27-dof task): one minibatch of the a2c network —
+    RunningMeanStd update + forward + backward of the actor / critic pair — on the native kernels (isaacgym_amd.policy.NativeMLPLearner).
+    m: minibatch rows.  The reference's yaml carries a debug value (`minibatch_size: 4 # 8192`, cfg/train/HumanoidPingpongTiltG1PPO.yaml:74);
+    rows here: its commented production value 8192 and the 32768 of a 4096-env x 32-step horizon split in four."""
+    import torch
+    from isaacgym_amd.policy import NativeMLP, NativeMLPLearner, RunningMeanStd
+    num_obs, num_act = 313, 27
+
+    def mlp(n_out):
+        layers, d = [], num_obs
+        for u in UNITS:
+            layers.append(torch.nn.Linear(d, u))
+            d = u
+        layers.append(torch.nn.Linear(d, n_out))
+        return [(l.weight, l.bias) for l in layers]
+    torch.manual_seed(0)
+    learner = NativeMLPLearner(mlp(num_act), mlp(1), num_obs, device)
+    rms = RunningMeanStd(num_obs, device)
+    learner.attach_running_mean_std(rms)
+    gen = torch.Generator(device=device).manual_seed(1)
+    obs = torch.randn(m, num_obs, device=device, generator=gen) * 2.0
+    d_head = torch.randn(m, num_act + 1, device=device, generator=gen)
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        out = []
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            ev0.record()
+            for _ in range(reps):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize(device)
+            out.append(ev0.elapsed_time(ev1) * 1e3 / reps)
+        return sorted(out)[1]
+    with torch.no_grad():
+        fwd_us = timed(lambda: learner.forward(obs, update_stats=True))
+        bwd_us = timed(lambda: learner.backward(d_head))
+        sync_us = timed(learner.sync_weights, reps=5)
+    dims = [num_obs] + UNITS
+    fwd_fl = NativeMLP.flops(m, num_obs, UNITS, num_act)
+    bwd_fl = 2 * fwd_fl - 2 * m * 2 * dims[0] * dims[1]                    # dW for every layer, dX for every layer but the first (observations need no gradient)
+    tf = (fwd_fl + bwd_fl) / ((fwd_us + bwd_us) * 1e-6) / 1e12
+    row = {"name": f"c5_TA_learner_minibatch_{m}", "baseline_config": "BASELINE.json configs[4]", "variant": "TA", "minibatch_rows": m,
+           "workload": "a2c network of cfg/train/HumanoidPingpongTiltG1PPO.yaml:10-31 (actor + critic [2048, 1536, 1024, 1024, 512, 512], ELU, 313 obs, 27 actions): "
+                       "RunningMeanStd update + forward + backward of one minibatch; random-init weights, synthetic rows",
+           "dtype": "f16 operands / f32 accumulation, f32 weight and bias gradients",
+           "us_forward_incl_stats_update": fwd_us, "us_backward": bwd_us, "us_weight_cast_per_optimizer_step": sync_us,
+           "rows_per_s_forward_backward": m / ((fwd_us + bwd_us) * 1e-6), "gflop_forward": fwd_fl / 1e9, "gflop_backward": bwd_fl / 1e9,
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "mlp_layer_pp_kernel (forward, dX) + mlp_dw_kernel (dW): forward + backward launch sequence",
+                        "avg_kernel_us": fwd_us + bwd_us, "flops_per_launch_sequence": fwd_fl + bwd_fl}}
+    del learner
+    torch.cuda.empty_cache()
+    if cpu:
+        try:
+            torch.set_num_threads(cores)
+            mc = 512
+            torch.manual_seed(0)
+
+            def net(n_out):
+                layers, d = [], num_obs
+                for u in UNITS:
+                    layers += [torch.nn.Linear(d, u), torch.nn.ELU()]
+                    d = u
+                layers.append(torch.nn.Linear(d, n_out))
+                return torch.nn.Sequential(*layers)
+            actor, critic = net(num_act), net(1)
+            x, g = torch.randn(mc, num_obs), torch.randn(mc, num_act + 1)
+            t0, it = time.perf_counter(), 0
+            while True:
+                out = torch.cat([actor(x), critic(x)], dim=1)
+                out.backward(g)
+                it += 1
+                dt = time.perf_counter() - t0
+                if dt >= 4.0 or it >= 50:
+                    break
+            row["cpu_baseline"] = {"value": mc * it / dt, "unit": "minibatch rows/s (forward + backward)", "cores": cores, "kind": "port",
+                                   "sample": f"{it} forward + backward passes of {mc} rows, PyTorch fp32 autograd on {cores} threads, {dt:.1f} s"}
+        except Exception as e:   # noqa: BLE001
+            row["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    return row
+
+
 def secondary_configs(device, only=None, cpu=True):
     """The other single-GPU BASELINE.json configs, a few seconds each, for the same JSON line (`configs`): configs[1] 3-actor at
     N = 4096 (T3 and TT semantics), configs[3] 4-actor tilt at its 8192 envs per GPU, configs[4] 3-actor all-dof at its 4096 envs
@@ -489,6 +576,10 @@ def secondary_configs(device, only=None, cpu=True):
             except Exception as e:   # noqa: BLE001 - a CPU row must not cost the GPU rows
                 row["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         rows.append(row)
+    for m in (8192, 32768):
+        if only and f"c5_TA_learner_minibatch_{m}" not in only:
+            continue
+        rows.append(learner_config(device, m, cores, cpu=cpu))
     return rows
 
 

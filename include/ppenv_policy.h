@@ -124,8 +124,8 @@ int ppenv_mlp_cast_weights(const float* w32, int32_t n, int32_t k, int32_t ldw32
 /* rl_games' RunningMeanStd in training mode (normalize_input, yaml:51) on one batch obs [m, k] fp32: batch mean and unbiased batch
  * variance per column merged into the running float64 (mean, var, count) by the parallel-moments rule; also writes the fp32 mean and
  * 1 / sqrt(var + eps) that ppenv_mlp_prepare_input reads (either may be NULL).  One launch, one pass over obs.  workspace:
- * ppenv_running_mean_std_workspace_bytes(m, k) bytes, 8-byte aligned, its first 16 bytes zeroed once by the caller (a ticket the kernel
- * re-arms itself).  rl_games is not part of the reference: restated from its published running_mean_std.py — parity unpinned. */
+ * ppenv_running_mean_std_workspace_bytes(m, k) bytes, 8-byte aligned, its first 1024 bytes zeroed once by the caller (tickets the kernel
+ * re-arms itself); k <= 16256.  rl_games is not part of the reference: restated from its published running_mean_std.py — parity unpinned. */
 size_t ppenv_running_mean_std_workspace_bytes(int32_t m, int32_t k);
 int ppenv_running_mean_std_update(const float* obs, int32_t m, int32_t k, int32_t ld, double* mean, double* var, double* count, float* mean_f32,
                                   float* inv_std_f32, float eps, void* workspace, void* stream);

@@ -264,17 +264,52 @@ __device__ __forceinline__ void epilogue16(const Args& a, f4v (&acc)[MT][NT], _F
         _Float16* out = reinterpret_cast<_Float16*>(a.out) + (size_t)b * a.out_stride;
         __builtin_amdgcn_wave_barrier();
         constexpr int CPR = 2 * NT;                        // 16-byte chunks per patch row
+        // backward-input mode (NT = 4 only: 64 lanes = 8 rows x 8 chunks, so a lane keeps its eight columns over the passes — as in epilogue())
+        const bool bwd = NT == 4 && (a.aux || a.colsum);
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < CPR; it++) {                 // 64 rows x CPR chunks = 64 CPR chunks, 64 per pass
             const int c = it * 64 + lane, prow = c / CPR, ch = c % CPR;
             const int row = wrow0 + mb * 16 + prow, col = wcol0 + ch * 8;
             if (row >= a.m || col >= a.n) continue;
-            const h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
+            h8 v = *reinterpret_cast<const h8*>(&patch[prow * PATCH_LD + ch * 8]);
+            if (bwd) {
+                if (a.aux) {                               // (the loads sit in the store pass here: this kernel's blocks come two to a wave, the next block's
+                    const _Float16* ap = a.aux + (size_t)b * a.aux_stride + (size_t)row * a.ldaux + col;   // conversions hide them)
+                    h8 y = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(ap) & 15) == 0)) y = *reinterpret_cast<const h8*>(ap);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) if (col + e < a.n) y[e] = ap[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float yf = (float)y[e];
+                        v[e] = (_Float16)((float)v[e] * (yf > 0.f ? 1.0f : yf + 1.0f));
+                    }
+                }
+                if (a.colsum) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) cs[e] += col + e < a.n ? (float)v[e] : 0.f;
+                }
+            }
             _Float16* dst = out + (size_t)row * a.ldo + col;
             if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
             else {
 #pragma unroll
                 for (int e = 0; e < 8; e++) if (col + e < a.n) dst[e] = v[e];
+            }
+        }
+        if (bwd && a.colsum) {                             // NT = 4: lane = 8 rl + ch; butterfly over rl, lane rl = 0 writes the block's sums
+#pragma unroll
+            for (int d = 8; d < 64; d <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; e++) cs[e] += __shfl_xor(cs[e], d);
+            const int col = wcol0 + (lane & 7) * 8, brow = wrow0 + mb * 16;
+            if ((lane >> 3) == 0 && brow < a.m) {
+                float* dst = a.colsum + (size_t)b * a.colsum_stride + (size_t)(brow >> 6) * a.ldcs + col;
+#pragma unroll
+                for (int e = 0; e < 8; e++) if (col + e < a.n) dst[e] = cs[e];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -896,9 +931,9 @@ int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream) {
             else cfg = wgs(128, 256) >= 192 ? 513 : 514;
         }
         else cfg = 128;
-        if (bw && (cfg == 516 || cfg == 517)) cfg = 512;   // the ELU' / column-sum store pass lives in the 32 x 32 epilogue
+        if (bw && cfg == 517) cfg = 516;                   // the ELU' / column-sum store pass needs 64-column blocks (NT = 4)
     }
-    if (bw && (cfg == 516 || cfg == 517 || cfg == 600)) { ppenv_set_error("ppenv_mlp_layer_backward_input: PPENV_MLP_TILE names a kernel without the backward store pass"); return PPENV_EINVAL; }
+    if (bw && (cfg == 517 || cfg == 600)) { ppenv_set_error("ppenv_mlp_layer_backward_input: PPENV_MLP_TILE names a kernel without the backward store pass"); return PPENV_EINVAL; }
 #define PP_LAUNCH(WM_, WN_, TI_, TJ_, BK_)                                                                                                    \
     do {                                                                                                                                      \
         const dim3 grid((L->n + 32 * TJ_ * WN_ - 1) / (32 * TJ_ * WN_), (L->m + 32 * TI_ * WM_ - 1) / (32 * TI_ * WM_), L->batch), block(64 * WM_ * WN_); \

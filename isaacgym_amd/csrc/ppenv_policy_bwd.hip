@@ -306,30 +306,56 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(const float* __restri
 
 // rl_games' RunningMeanStd in training mode on one batch of observations [m, k] (fp32): per column the batch mean and the UNBIASED batch
 // variance (torch.var's default), merged into the running (mean, var, count) by the parallel-moments rule of
-// _update_mean_var_count_from_moments; state in float64 as rl_games keeps it.  Pass 1: every workgroup accumulates sum and sum of squares
-// of its 256-row block in float64 (thread = column: coalesced rows); the workgroup that draws the last ticket merges the blocks in a fixed
-// order, updates the state, writes the fp32 mean and 1 / sqrt(var + eps) the forward's normaliser reads, and re-arms the ticket.
-__global__ __launch_bounds__(256) void rms_update_kernel(const float* __restrict__ obs, int m, int k, int ld, double* __restrict__ partial /*[blocks][2][k]*/,
-                                                         unsigned int* __restrict__ ticket, double* __restrict__ mean, double* __restrict__ var,
-                                                         double* __restrict__ count, float* __restrict__ mean32, float* __restrict__ inv_std32, float eps) {
+// _update_mean_var_count_from_moments; state in float64 as rl_games keeps it.  One launch, one pass over obs: workgroup (x, y) sums rows
+// 128 x .. 128 x + 127 of columns 64 y .. 64 y + 63 in float64 (thread -> column tid & 63, row class tid >> 6: coalesced rows, eight loads
+// in flight); the workgroup that draws the last ticket OF ITS COLUMN CHUNK merges that chunk's row blocks in a fixed order, updates the
+// state of its 64 columns and writes the fp32 mean and 1 / sqrt(var + eps) the forward's normaliser reads; the last chunk to finish
+// advances the count and re-arms the tickets (every chunk has read the old count by then).
+constexpr int kRmsRows = 128, kRmsMaxChunks = 254;
+__global__ __launch_bounds__(256) void rms_update_kernel(const float* __restrict__ obs, int m, int k, int ld, double* __restrict__ partial /*[row blocks][2][k]*/,
+                                                         unsigned int* __restrict__ tickets /*[kRmsMaxChunks] per chunk, [255] chunks done*/, double* __restrict__ mean,
+                                                         double* __restrict__ var, double* __restrict__ count, float* __restrict__ mean32, float* __restrict__ inv_std32,
+                                                         float eps) {
+    __shared__ double red[2][4][64];
     __shared__ bool last;
-    const int nblocks = gridDim.x, r0 = blockIdx.x * 256, r1 = r0 + 256 < m ? r0 + 256 : m;
-    for (int c = threadIdx.x; c < k; c += 256) {
-        double s = 0.0, s2 = 0.0;
-        for (int r = r0; r < r1; r++) { const double v = (double)obs[(size_t)r * ld + c]; s += v; s2 += v * v; }
-        partial[((size_t)blockIdx.x * 2 + 0) * k + c] = s;
-        partial[((size_t)blockIdx.x * 2 + 1) * k + c] = s2;
+    const int nrb = gridDim.x, nchunks = gridDim.y, cx = threadIdx.x & 63, rc = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cx, r0 = blockIdx.x * kRmsRows, r1 = r0 + kRmsRows < m ? r0 + kRmsRows : m;
+    const bool col = c < k;
+    double s = 0.0, s2 = 0.0;
+    if (col) {
+        int r = r0 + rc;
+        for (; r + 28 < r1; r += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = obs[(size_t)(r + 4 * u) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { s += (double)v[u]; s2 += (double)v[u] * (double)v[u]; }
+        }
+        for (; r < r1; r += 4) { const double v = (double)obs[(size_t)r * ld + c]; s += v; s2 += v * v; }
+    }
+    red[0][rc][cx] = s; red[1][rc][cx] = s2;
+    __syncthreads();
+    if (rc == 0 && col) {
+        partial[((size_t)blockIdx.x * 2 + 0) * k + c] = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+        partial[((size_t)blockIdx.x * 2 + 1) * k + c] = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
     }
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == (unsigned)nblocks - 1;
+    if (threadIdx.x == 0) last = atomicAdd(&tickets[blockIdx.y], 1u) == (unsigned)nrb - 1;
     __syncthreads();
     if (!last) return;
     __threadfence();
-    const double bc = (double)m, c0 = *count, tot = c0 + bc;
-    for (int c = threadIdx.x; c < k; c += 256) {
-        double s = 0.0, s2 = 0.0;
-        for (int b = 0; b < nblocks; b++) { s += partial[((size_t)b * 2 + 0) * k + c]; s2 += partial[((size_t)b * 2 + 1) * k + c]; }
+    // this chunk's row blocks, rows rc, rc + 4, ... per thread, then the four classes in order
+    s = 0.0; s2 = 0.0;
+    if (col)
+        for (int b = rc; b < nrb; b += 4) { s += partial[((size_t)b * 2 + 0) * k + c]; s2 += partial[((size_t)b * 2 + 1) * k + c]; }
+    __syncthreads();
+    red[0][rc][cx] = s; red[1][rc][cx] = s2;
+    __syncthreads();
+    if (rc == 0 && col) {
+        s = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+        s2 = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+        const double bc = (double)m, c0 = *count, tot = c0 + bc;
         const double bmean = s / bc;
         const double bvar = m > 1 ? (s2 - bc * bmean * bmean) / (bc - 1.0) : 0.0;       // torch.var: unbiased
         const double delta = bmean - mean[c];
@@ -341,8 +367,15 @@ __global__ __launch_bounds__(256) void rms_update_kernel(const float* __restrict
         if (mean32) mean32[c] = (float)new_mean;
         if (inv_std32) inv_std32[c] = 1.0f / sqrtf((float)new_var + eps);
     }
+    __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) { *count = tot; *ticket = 0u; }
+    if (threadIdx.x == 0) {
+        tickets[blockIdx.y] = 0u;                                                       // re-armed for the next launch
+        if (atomicAdd(&tickets[255], 1u) == (unsigned)nchunks - 1) {                    // every chunk has read the old count
+            *count = *count + (double)m;
+            tickets[255] = 0u;
+        }
+    }
 }
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -445,19 +478,20 @@ extern "C" int ppenv_mlp_cast_weights(const float* w32, int32_t n, int32_t k, in
 }
 
 extern "C" size_t ppenv_running_mean_std_workspace_bytes(int32_t m, int32_t k) {
-    return (m <= 0 || k <= 0) ? 0 : 16 + (size_t)((m + 255) / 256) * 2 * k * sizeof(double);
+    return (m <= 0 || k <= 0) ? 0 : 1024 + (size_t)((m + kRmsRows - 1) / kRmsRows) * 2 * k * sizeof(double);
 }
 
 extern "C" int ppenv_running_mean_std_update(const float* obs, int32_t m, int32_t k, int32_t ld, double* mean, double* var, double* count, float* mean_f32,
                                              float* inv_std_f32, float eps, void* workspace, void* stream) {
-    if (!obs || !mean || !var || !count || !workspace || m <= 0 || k <= 0 || ld < k || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
-        ppenv_set_error("ppenv_running_mean_std_update: NULL pointer or inconsistent sizes (need ld >= k, an 8-byte aligned workspace of ppenv_running_mean_std_workspace_bytes() "
-                        "whose first 16 bytes were zeroed once)");
+    if (!obs || !mean || !var || !count || !workspace || m <= 0 || k <= 0 || ld < k || (reinterpret_cast<uintptr_t>(workspace) & 7) || (k + 63) / 64 > kRmsMaxChunks) {
+        ppenv_set_error("ppenv_running_mean_std_update: NULL pointer or inconsistent sizes (need ld >= k, k <= 16256, an 8-byte aligned workspace of "
+                        "ppenv_running_mean_std_workspace_bytes() whose first 1024 bytes were zeroed once)");
         return PPENV_EINVAL;
     }
-    unsigned int* ticket = reinterpret_cast<unsigned int*>(workspace);
-    double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 16);
-    hipLaunchKernelGGL(rms_update_kernel, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs, m, k, ld, partial, ticket, mean, var, count, mean_f32, inv_std_f32, eps);
+    unsigned int* tickets = reinterpret_cast<unsigned int*>(workspace);
+    double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 1024);
+    hipLaunchKernelGGL(rms_update_kernel, dim3((m + kRmsRows - 1) / kRmsRows, (k + 63) / 64), dim3(256), 0, (hipStream_t)stream, obs, m, k, ld, partial, tickets, mean, var,
+                       count, mean_f32, inv_std_f32, eps);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching rms_update_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }

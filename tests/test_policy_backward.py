@@ -40,7 +40,7 @@ def test_backward_entry_points_reject_bad_arguments_before_any_device_call():
     assert L.ppenv_mlp_reduce_rows(None, 1, 1, 1, None, 0, None) == -1
     assert L.ppenv_mlp_cast_weights(None, 1, 1, 1, None, 0, None, 0, 0, None) == -1
     assert L.ppenv_running_mean_std_update(None, 1, 1, 1, None, None, None, None, None, 1e-5, None, None) == -1
-    assert L.ppenv_running_mean_std_workspace_bytes(1000, 313) == 16 + 4 * 2 * 313 * 8
+    assert L.ppenv_running_mean_std_workspace_bytes(1000, 313) == 1024 + 8 * 2 * 313 * 8
     with pytest.raises(_lib.PPEnvError):
         _lib.check(-1)
 
@@ -71,7 +71,7 @@ def test_weight_gradient_kernel_exact_on_integer_data(m, n, k, batch, splits):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", [0, 128, 384, 512, 513, 514])
+@pytest.mark.parametrize("tile", [0, 128, 384, 512, 513, 514, 516])
 @pytest.mark.parametrize("m,n,k,batch", [(333, 328, 192, 1), (640, 256, 128, 2), (1500, 136, 64, 2)])
 def test_input_gradient_launch_exact_on_integer_data(monkeypatch, tile, m, n, k, batch):
     """dX = (dZ . Wt^T) * ELU'(y) and its per-64-row column sums on every tile kernel the launcher can pick (PPENV_MLP_TILE): exact
@@ -218,3 +218,34 @@ def test_native_backward_matches_fp32_autograd(m, num_obs, num_act, units):
     learner.sync_weights()
     mu2, _ = learner.forward(obs.cuda())
     assert torch.isfinite(mu2).all() and not torch.equal(mu2, mu)
+
+
+@pytest.mark.gpu
+def test_learner_trains_with_a_torch_optimizer():
+    """The pieces in a loop, as rl_games would drive them: forward (statistics learning), a loss on mu / value in PyTorch, the native backward,
+    Adam on the fp32 masters, recast — the loss falls."""
+    import torch
+    from isaacgym_amd.policy import NativeMLPLearner, RunningMeanStd
+    gen = torch.Generator().manual_seed(0)
+    m, num_obs, num_act, units = 1024, 80, 7, (256, 128)
+    actor, critic = _mlp(torch, num_obs, units, num_act, gen), _mlp(torch, num_obs, units, 1, gen)
+    learner = NativeMLPLearner(actor, critic, num_obs, "cuda:0")
+    learner.attach_running_mean_std(RunningMeanStd(num_obs, "cuda:0"))
+    params = learner.parameters()
+    opt = torch.optim.Adam(params, lr=1e-3)
+    obs = (torch.randn(m, num_obs, generator=gen) * 3 + 1).cuda()
+    target = torch.tanh(obs[:, :num_act + 1] * 0.3)                  # something learnable from the observations
+    scale = 1024.0                                                   # a loss scale, as GradScaler would apply: fp16 gradients
+    losses = []
+    for it in range(60):
+        mu, value = learner.forward(obs, update_stats=it < 5)
+        out = torch.cat([mu, value], dim=1)
+        losses.append(float(((out - target) ** 2).mean()))
+        d_head = (2.0 * (out - target) / out.numel() * scale).contiguous()
+        grads = learner.backward(d_head)
+        for p, g in zip(params, grads):
+            p.grad = (g / scale).contiguous()
+        opt.step()
+        learner.sync_weights()
+    assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
+    assert all(torch.isfinite(p).all() for p in params)
