@@ -931,7 +931,9 @@ int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream) {
             else cfg = wgs(128, 256) >= 192 ? 513 : 514;
         }
         else cfg = 128;
-        if (bw && cfg == 517) cfg = 516;                   // the ELU' / column-sum store pass needs 64-column blocks (NT = 4)
+        // backward-input mode: the 32 x 32 x 16 kernel, whose store pass prefetches the ELU outputs (measured at M = 32768, dX of the 1024 -> 1024 /
+        // 1536 -> 1024 / 2048 -> 1536 layers: 204 / 313 / 507 us against 227 / 322 / 521 on the 16 x 16 x 32 kernel, which PPENV_MLP_TILE=516 still selects)
+        if (bw && (cfg == 516 || cfg == 517)) cfg = 512;
     }
     if (bw && (cfg == 517 || cfg == 600)) { ppenv_set_error("ppenv_mlp_layer_backward_input: PPENV_MLP_TILE names a kernel without the backward store pass"); return PPENV_EINVAL; }
 #define PP_LAUNCH(WM_, WN_, TI_, TJ_, BK_)                                                                                                    \
