@@ -362,6 +362,7 @@ class NativeMLPLearner:
         self.head_wt = z16(2 * u[-1], self.nh)
         self.grads = dict(w=[z32(*w.shape) for w in net.w], b=[z32(2, n) for n in u], head_w=z32(self.nh, 2 * u[-1]), head_b=z32(na + 1))
         self._rows = 0
+        self.rms = None
         self.sync_weights()
 
     def parameters(self):
@@ -435,6 +436,81 @@ class NativeMLPLearner:
                                  dx_stride=k, elu_out_stride=k, colsum_stride=k, m=m, n=k, k=n)
             cur = nxt
         return self.gradients()
+
+
+class _ActorCriticFn(torch.autograd.Function):
+    """autograd edge of NativeActorCritic: forward = NativeMLPLearner.forward, backward = NativeMLPLearner.backward."""
+
+    @staticmethod
+    def forward(ctx, module, obs, *params):          # params: only so that autograd routes their gradients here
+        mu, value = module.learner.forward(obs, update_stats=module.training and module.learner.rms is not None)
+        ctx.module = module
+        return mu.clone(), value.clone()             # the network's own buffers are reused by the next forward
+
+    @staticmethod
+    def backward(ctx, d_mu, d_value):
+        lr = ctx.module.learner
+        m, na = lr.net._rows, lr.net.num_actions
+        d_head = torch.zeros((m, na + 1), dtype=torch.float32, device=lr.device)
+        if d_mu is not None:
+            d_head[:, :na] = d_mu
+        if d_value is not None:
+            d_head[:, na:] = d_value
+        return (None, None) + tuple(g.clone() for g in lr.backward(d_head))
+
+
+class NativeActorCritic(torch.nn.Module):
+    """rl_games' a2c network of the reference (`separate: True` actor / critic MLPs, ELU, linear mu and value heads, fixed sigma,
+    `normalize_input`; cfg/train/HumanoidPingpongTiltG1PPO.yaml:10-31,50-52) as a torch module whose forward AND backward run on the native
+    kernels: `mu, value = net(obs)` are ordinary differentiable tensors, `loss.backward()` fills the fp32 `.grad` of the parameters (through
+    NativeMLPLearner.backward: a GradScaler's scaled loss gives scaled gradients, `unscale_` works as on any fp32 gradient), any torch
+    optimizer steps them, and the next forward recasts the fp16 operand images when a parameter has changed.  Parameters are the stacked
+    masters of NativeMLPLearner (`hidden_w.i` [2, n, k] = actor | critic, `hidden_b.i`, `mu_w`, `mu_b`, `value_w`, `value_b`); `from_rlgames`
+    builds one from an rl_games state dict.  The minibatch must be a multiple of 64 rows (the weight-gradient kernel's contraction tile)."""
+
+    def __init__(self, actor, critic, num_obs, device, normalize_input=True, eps=1e-5, clip=5.0):
+        super().__init__()
+        self.learner = NativeMLPLearner(actor, critic, num_obs, device, eps=eps, clip=clip)
+        self.learner.rms = None
+        if normalize_input:
+            self.learner.attach_running_mean_std(RunningMeanStd(num_obs, device, eps=eps))
+        lr = self.learner
+        P = torch.nn.Parameter
+        self.hidden_w = torch.nn.ParameterList([P(w) for w in lr.w32])       # the same storage as the learner's masters
+        self.hidden_b = torch.nn.ParameterList([P(b) for b in lr.b32])
+        self.mu_w, self.mu_b, self.value_w, self.value_b = P(lr.mu_w), P(lr.mu_b), P(lr.value_w), P(lr.value_b)
+        self.sigma = P(torch.zeros(lr.net.num_actions, device=lr.device), requires_grad=False)   # fixed_sigma: log-std, const 0 (yaml:21-27)
+        self._seen = self._versions()
+
+    @classmethod
+    def from_rlgames(cls, state_dict, device, **kw):
+        actor, critic = layers_from_rlgames_state_dict(state_dict)
+        net = cls(actor, critic, actor[0][0].shape[1], device, normalize_input="running_mean_std.running_mean" in state_dict, **kw)
+        if net.learner.rms is not None:
+            rms = net.learner.rms
+            rms.running_mean.copy_(state_dict["running_mean_std.running_mean"])
+            rms.running_var.copy_(state_dict["running_mean_std.running_var"])
+            rms.count.copy_(state_dict["running_mean_std.count"])
+            rms.mean.copy_(rms.running_mean.float())
+            rms.inv_std.copy_(torch.rsqrt(rms.running_var.float() + rms.eps))
+        if "a2c_network.sigma" in state_dict:
+            net.sigma.data.copy_(state_dict["a2c_network.sigma"])
+        return net
+
+    def _ordered(self):
+        return list(self.hidden_w) + list(self.hidden_b) + [self.mu_w, self.mu_b, self.value_w, self.value_b]
+
+    def _versions(self):
+        return tuple(p._version for p in self._ordered())
+
+    def forward(self, obs):
+        if obs.shape[0] % 64:
+            raise ValueError(f"NativeActorCritic: {obs.shape[0]} rows; the minibatch must be a multiple of 64")
+        v = self._versions()
+        if v != self._seen:                          # an optimizer stepped (or a state dict was loaded): recast the operand images
+            self.learner.sync_weights()
+            self._seen = v
+        return _ActorCriticFn.apply(self, obs, *self._ordered())
 
 
 # ---- a trained rl_games checkpoint on the native forward (the reference's `train.py test=True checkpoint=...` play mode) ---------------

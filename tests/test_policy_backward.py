@@ -249,3 +249,57 @@ def test_learner_trains_with_a_torch_optimizer():
         learner.sync_weights()
     assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
     assert all(torch.isfinite(p).all() for p in params)
+
+
+@pytest.mark.gpu
+def test_native_actor_critic_module_is_an_ordinary_differentiable_torch_module():
+    """NativeActorCritic: loss.backward() fills .grad through the native backward (against fp32 autograd on the same weights), a torch
+    optimizer's step is picked up by the next forward (recast on parameter-version change), eval mode leaves the statistics alone."""
+    import torch
+    from isaacgym_amd.policy import NativeActorCritic
+    gen = torch.Generator().manual_seed(11)
+    m, num_obs, num_act, units = 256, 80, 7, (256, 128)
+    actor, critic = _mlp(torch, num_obs, units, num_act, gen), _mlp(torch, num_obs, units, 1, gen)
+    net = NativeActorCritic(actor, critic, num_obs, "cuda:0", normalize_input=False)
+    assert sum(p.numel() for p in net.parameters() if p.requires_grad) == sum(w.numel() + b.numel() for w, b in actor + critic)
+    obs = torch.randn(m, num_obs, generator=gen)
+    adv = torch.randn(m, generator=gen)
+    ret = torch.randn(m, 1, generator=gen)
+    act = torch.randn(m, num_act, generator=gen)
+
+    def loss_of(mu, value):                          # a PPO-shaped loss: Gaussian log-probability weighted by an advantage + a value loss
+        return (((act.to(mu.device) - mu) ** 2).sum(dim=1) * adv.to(mu.device)).mean() * 0.5 + ((value - ret.to(mu.device)) ** 2).mean()
+    mu, value = net(obs.cuda())
+    assert mu.requires_grad and value.requires_grad
+    loss_of(mu, value).backward()
+    ref = []
+
+    def run(layers):
+        h = torch.clamp(obs, -5.0, 5.0)
+        for i, (w, b) in enumerate(layers):
+            w, b = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            ref.append((w, b))
+            h = h @ w.t() + b
+            if i + 1 < len(layers):
+                h = torch.nn.functional.elu(h)
+        return h
+    loss_of(run(actor), run(critic)).backward()
+    nl = len(units)
+    for i in range(nl):
+        for j, off in ((0, 0), (1, nl + 1)):
+            for got, want in ((net.hidden_w[i].grad[j], ref[off + i][0].grad), (net.hidden_b[i].grad[j], ref[off + i][1].grad)):
+                scale = float(want.abs().max())
+                assert float((got.cpu() - want).abs().max()) <= 2e-2 * scale, (i, j, scale)
+    for got, want in ((net.mu_w.grad, ref[nl][0].grad), (net.mu_b.grad, ref[nl][1].grad), (net.value_w.grad, ref[2 * nl + 1][0].grad), (net.value_b.grad, ref[2 * nl + 1][1].grad)):
+        assert float((got.cpu() - want).abs().max()) <= 2e-2 * float(want.abs().max())
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    before = mu.detach().clone()
+    opt.step()
+    mu2, _ = net(obs.cuda())                          # the step changed the masters: the fp16 images were recast
+    assert not torch.allclose(mu2.detach(), before)
+    with pytest.raises(ValueError, match="multiple of 64"):
+        net(obs[:100].cuda())
+    net.eval()
+    with torch.no_grad():
+        mu3, _ = net(obs.cuda())
+    assert torch.equal(mu3, mu2.detach())
