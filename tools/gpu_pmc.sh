@@ -5,7 +5,7 @@ mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 run() { # name, counters...
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc/$name -- python bench.py --steps 200 --warmup 50 --no-cpu-baseline ${BENCH_ARGS} > gpurun_out/pmc/$name.json 2> gpurun_out/pmc/$name.err || { tail -5 gpurun_out/pmc/$name.err; return 1; }
+  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc/$name -- python bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-configs ${BENCH_ARGS} > gpurun_out/pmc/$name.json 2> gpurun_out/pmc/$name.err || { tail -5 gpurun_out/pmc/$name.err; return 1; }
   echo "pass $name done" >> gpurun_out/progress.log
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU || exit 1

@@ -16,7 +16,7 @@ import json
 d = json.load(open("gpurun_out/bench.json"))
 print("headline %.3f G env-steps/s, kernel %.2f us, frac %.4f" % (d["value"] / 1e9, d["roofline"]["avg_kernel_us"], d["roofline"]["frac"]))
 for r in d.get("configs", []):
-    k = r.get("avg_kernel_us", r.get("us_per_rollout_step"))
-    print("%-22s %8.2f us  %8.1f M env-steps/s  %s frac %.4f  cpu %s" % (r["name"], k, r["env_steps_per_s"] / 1e6, r["roofline"]["bound"], r["roofline"]["frac"],
+    k = r.get("avg_kernel_us", r.get("us_per_rollout_step", r["roofline"]["avg_kernel_us"]))
+    print("%-22s %8.2f us  %8.1f M env-steps/s  %s frac %.4f  cpu %s" % (r["name"], k, r.get("env_steps_per_s", r.get("rows_per_s_forward_backward", 0.0)) / 1e6, r["roofline"]["bound"], r["roofline"]["frac"],
           ("%.3f M" % (r["cpu_baseline"]["value"] / 1e6)) if "value" in r.get("cpu_baseline", {}) else r.get("cpu_baseline")))
 PY
