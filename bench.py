@@ -178,11 +178,11 @@ def kernel_name(variant):
     """The schedule ppenv_create picks (isaacgym_amd/csrc/ppenv.hip): two waves per 64 envs unless the one-wave kernel is
     forced; three waves (two arm waves + the ball wave) for the 4-actor variant."""
     if variant == "T4":
-        return "step_kernel_split<ModelG1, 2, 0>" if os.environ.get("PPENV_STEP_KERNEL") == "split3" else "step_kernel_split<ModelG1, 2, 1>"
+        return "step_kernel_split<ModelG1, 2, 0, 1, false>" if os.environ.get("PPENV_STEP_KERNEL") == "split3" else "step_kernel_split<ModelG1, 2, 1, 1, false>"
     if variant == "TA":
-        return {"lane": "ta_sim_kernel<true>", "quad": "ta_sim_quad_kernel<true, true>"}.get(os.environ.get("PPENV_TA_KERNEL"), "ta_chain_kernel")
+        return {"lane": "ta_sim_kernel<true>", "quad": "ta_sim_quad_kernel<true, true>"}.get(os.environ.get("PPENV_TA_KERNEL"), "ta_chain_kernel<false>")
     split = os.environ.get("PPENV_STEP_KERNEL") != "fused"
-    return "step_kernel_split<ModelG1, 1, 0>" if split else "step_kernel<ModelG1>"
+    return "step_kernel_split<ModelG1, 1, 0, 1, false>" if split else "step_kernel<ModelG1, false>"   # <model, humanoids, who sweeps the geometry, ball waves, randomisation tables>
 
 
 def launch_ranks(n, argv):

@@ -481,6 +481,22 @@ int ppenv_ta_sim_device(const ppenv_ta_sim* sim);
  * 0 = one lane per env (any tree).  PPENV_TA_KERNEL=chain|quad|lane forces one. */
 uint32_t ppenv_ta_sim_status(const ppenv_ta_sim* sim);
 int ppenv_ta_sim_kernel(const ppenv_ta_sim* sim);
+/* Domain randomisation of the 27-DoF task (cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml carries the same task.randomization_params block as the
+ * 7-dof yamls; TA's apply_randomizations call sits in its reset path as TT:849-850's does): per-env tables in device memory, SoA, NULL = not
+ * randomised — drive stiffness / damping scales [27][N], link mass scales [28][N] (link 0 = pelvis; mass and inertia together), restitution and
+ * friction scales [N] of the humanoid's shapes and the paddle; additive Gaussian noise on the raw actions (before the clipActions clamp) and on every
+ * observation value, drawn from the counter RNG keyed by (params.seed, global env id, episode, progress at the step's start, index).  The tables are read
+ * by every following ppenv_ta_step (the caller keeps them alive); dr NULL switches the randomisation off.  Only with ppenv_ta_sim_kernel() == 2 (the
+ * chain-wave kernel: the scales multiply its compiled-in literals). */
+typedef struct ppenv_ta_randomization {
+    const float* dof_stiffness_scale;   /* [27][N] */
+    const float* dof_damping_scale;     /* [27][N] */
+    const float* link_mass_scale;       /* [28][N] */
+    const float* restitution_scale;     /* [N] */
+    const float* friction_scale;        /* [N] */
+    float action_noise_sigma, observation_noise_sigma;
+} ppenv_ta_randomization;
+int ppenv_ta_sim_set_randomization(ppenv_ta_sim* sim, const ppenv_ta_randomization* dr);
 /* The policy's first-layer input written by ppenv_ta_step itself (observation normalisation fused into the step
  * kernel): next to obs_buf the chain-wave kernel stores out[N, ld_out] fp16 = clamp((obs - mean) * inv_std, -clip, clip), columns
  * 313 .. ld_out-1 zero — bit for bit what ppenv_mlp_prepare_input (ppenv_policy.h) makes of obs_buf, without that launch.  mean /

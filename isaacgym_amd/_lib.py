@@ -137,6 +137,7 @@ def load(path):
     L.ppenv_ta_sim_status.argtypes = [vp]
     L.ppenv_ta_sim_kernel.argtypes = [vp]
     L.ppenv_ta_sim_set_policy_input.argtypes = [vp, vp, vp, C.c_float, vp, C.c_int32]
+    L.ppenv_ta_sim_set_randomization.argtypes = [vp, C.POINTER(scene.Randomization)]
     L.ppenv_ta_model_is_compiled.argtypes = [cfgp, C.POINTER(scene.TAModel)]
     L.ppenv_post_physics_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     for name in ("ppenv_refresh_root_states", "ppenv_refresh_dof_states", "ppenv_refresh_dof_force",

@@ -32,6 +32,14 @@ struct TAChainArgs {
     float pin_clip;
     unsigned short* pin_out;      // fp16 [N, pin_ld], columns >= 313 zero
     int pin_ld;
+    // domain randomisation (ppenv_ta_sim_set_randomization; every pointer NULL and both sigmas 0: off, the plain kernel is launched)
+    const float* dr_kp;           // [27][N] drive stiffness scales
+    const float* dr_kd;           // [27][N] drive damping scales
+    const float* dr_ms;           // [28][N] link mass scales (link 0 = pelvis; mass and inertia together)
+    const float* dr_es;           // [N] restitution scale of the humanoid's shapes and the paddle
+    const float* dr_fs;           // [N] friction scale of the same
+    float dr_act_sigma, dr_obs_sigma;
+    bool dr_on() const { return dr_kp || dr_kd || dr_ms || dr_es || dr_fs || dr_act_sigma > 0.f || dr_obs_sigma > 0.f; }
 };
 
 // does the run-time model equal, bit for bit, the tables the chain-wave kernel was compiled from?

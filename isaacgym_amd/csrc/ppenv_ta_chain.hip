@@ -210,12 +210,37 @@ __device__ __forceinline__ void point_of(const Frame& f, V3 r, V3& p, V3& vel) {
     vel = mul(f.Rw, f.v + cross(f.w, r));
 }
 
+// ---- domain randomisation (cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml carries the same randomization_params block as the
+// 7-dof yamls) -----------------------------------------------------------------------------------------------------------------------------
+// A link with this env's scales applied: the literals of the compiled model times three run-time factors (mass, m c and the inertia about the
+// origin all scale with the mass, as recomputeInertia does; the drive gains on their own).  DR = false returns the literal link untouched.
+template <bool DR>
+__device__ __forceinline__ LinkC dr_link(const LinkC& L, float ms, float kps, float kds) {
+    if (!DR) return L;
+    LinkC R = L;
+    R.mass *= ms;
+#pragma unroll
+    for (int t = 0; t < 3; t++) R.mc[t] *= ms;
+#pragma unroll
+    for (int t = 0; t < 6; t++) R.Io[t] *= ms;
+    R.kp *= kps; R.kd *= kds;
+    return R;
+}
+// the noise draws of this task: index < 512 (27 action draws, then 32 + k for observation value k < 313) folded into dr_gauss's 256-per-step key space
+__device__ __forceinline__ float ta_dr_gauss(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t progress, uint32_t index) {
+    return dr_gauss(seed, gid, episode, 2u * progress + (index >> 8), index & 255u);
+}
+struct DrKeys { const TAChainArgs* a; int env, n; uint32_t gid, ep, prog; };   // what a limb's load() needs to fetch its table entries and draw its action noise
+
 // ---- one limb: the three passes over a compile-time chain ---------------------------------------------------------------
-template <int FIRST, int N>
+template <int FIRST, int N, bool DR = false>
 struct Limb {
     float q[N], qd[N], target[N], force[N];
+    float kps[DR ? N : 1], kds[DR ? N : 1], mss[DR ? N : 1];   // DR: this env's scales of the limb's links
     LinkSave sv[N];
     JointOut jo[N];
+    template <int K>
+    __device__ __forceinline__ LinkC link_of() const { return dr_link<DR>(T::link(FIRST + K), mss[DR ? K : 0], kps[DR ? K : 0], kds[DR ? K : 0]); }
 
     // pass 1: kinematics outwards from the parent's frame; GEO(link, frame) sees every link (collision geometry capture)
     template <class GEO>
@@ -236,7 +261,7 @@ struct Limb {
         constexpr CPTable cp = cp_table();
         static_for<N>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            constexpr LinkC L = T::link(FIRST + k);
+            const LinkC L = link_of<k>();
             own[k] = link_dynamics(P, L, cp.p, sv[k].Rw, sv[k].pw, sv[k].w, sv[k].v);
             pin_art(own[k]);
         });
@@ -246,7 +271,7 @@ struct Limb {
         constexpr CPTable cp = cp_table();
         static_for<N>([&](auto kc) {
             constexpr int k = N - 1 - decltype(kc)::value;
-            constexpr LinkC L = T::link(FIRST + k);
+            const LinkC L = link_of<k>();
             ArtI I = OWN ? own[k] : link_dynamics(P, L, cp.p, sv[k].Rw, sv[k].pw, sv[k].w, sv[k].v);
             add_art(I, acc);
             const M3 E = joint_E<FIRST + k>(sv[k].c, sv[k].s);
@@ -259,19 +284,28 @@ struct Limb {
     __device__ __forceinline__ void pass3(const TAScal& P, V3& aw, V3& av) {
         static_for<N>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            constexpr LinkC L = T::link(FIRST + k);
+            const LinkC L = link_of<k>();
             const M3 E = joint_E<FIRST + k>(sv[k].c, sv[k].s);
             outward_step(P, L, E, sv[k].w, sv[k].v, jo[k], aw, av, target[k], q[k], qd[k], force[k]);
         });
     }
     // (the staging leaves the raw actions in S.act_frc: the clamp and the map onto the joint range happen here, where the joint is a
     // compile-time constant — in the staging loop the lanes of a wave look at different dofs and the limits were a table lookup)
-    __device__ __forceinline__ void load(const Shared& S, int e, float clip_actions) {
+    __device__ __forceinline__ void load(const Shared& S, int e, float clip_actions, const DrKeys& dk = DrKeys{}) {
         static_for<N>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr LinkC L = T::link(FIRST + k);
-            q[k] = S.q[FIRST - 1 + k][e]; qd[k] = S.qd[FIRST - 1 + k][e]; force[k] = 0.f;
-            target[k] = pd_target(S.act_frc[FIRST - 1 + k][e], L.lo, L.hi, clip_actions);   // VecTask.step clamp + TA:1131, 729-733
+            constexpr int d = FIRST - 1 + k;                          // the dof of link FIRST + k
+            q[k] = S.q[d][e]; qd[k] = S.qd[d][e]; force[k] = 0.f;
+            float act = S.act_frc[d][e];
+            if constexpr (DR) {                                       // this env's table entries (a NULL table = scale 1); the action noise goes in before the clamp
+                const TAChainArgs& a = *dk.a;
+                kps[k] = a.dr_kp ? a.dr_kp[(size_t)d * dk.n + dk.env] : 1.f;
+                kds[k] = a.dr_kd ? a.dr_kd[(size_t)d * dk.n + dk.env] : 1.f;
+                mss[k] = a.dr_ms ? a.dr_ms[(size_t)(FIRST + k) * dk.n + dk.env] : 1.f;
+                if (a.dr_act_sigma > 0.f) act += a.dr_act_sigma * ta_dr_gauss(a.p.seed, dk.gid, dk.ep, dk.prog, (uint32_t)d);
+            }
+            target[k] = pd_target(act, L.lo, L.hi, clip_actions);   // VecTask.step clamp + TA:1131, 729-733
         });
     }
     // the final phase only needs the new (q, qd): S.act_frc holds the drive torques by then
@@ -466,6 +500,8 @@ __device__ __forceinline__ void put_torso(Shared& S, int e, const Frame& f) {
     put3(S.torso, 9, e, f.pw); put3(S.torso, 12, e, f.w); put3(S.torso, 15, e, f.v);
 }
 
+// DR: the table-reading instantiation (domain randomisation on); DR = false is the kernel every reference yaml runs (randomize: False)
+template <bool DR>
 __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, const TAChainArgs a) {
     __shared__ Shared S;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -552,13 +588,16 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     }
     __syncthreads();
 
+    DrKeys dk{&a, env, n, (uint32_t)(a.p.env_id_offset + env), 0u, 0u};
+    if constexpr (DR) { dk.ep = a.episode[env]; dk.prog = (uint32_t)a.progress[env]; }   // the noise keys: episode / progress at the step's start
+
     CH_STAMP(1);
     // ---- physics: every wave runs its own role, start to finish (its limb's state lives in ITS registers only; the substep loop is
     // inside the role so that no other role's variables are live across it) -----------------------------------------------------
     auto no_geo = [](auto, const Frame&) {};
     auto leg_role = [&](auto limb_tag, const int leg) {
         typename decltype(limb_tag)::type L;
-        L.load(S, e, P.clip_actions);
+        L.load(S, e, P.clip_actions, dk);
         for (int sub = 0; sub < substeps; sub++) {
             if (sub > 0) TA_AWAIT(&S.f_base, sub);                  // the base state of this substep
             CH_STAMP(2 + 8 * (sub & 1));
@@ -578,7 +617,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     };
     auto arm_role = [&](auto limb_tag, const int arm, auto with_geo) {
         typename decltype(limb_tag)::type L;
-        L.load(S, e, P.clip_actions);
+        L.load(S, e, P.clip_actions, dk);
         for (int sub = 0; sub < substeps; sub++) {
             TA_AWAIT(&S.f_torso, sub + 1);
             CH_STAMP(2 + 8 * (sub & 1));
@@ -606,8 +645,10 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         L.store(S, e);
     };
     auto waist_role = [&]() {   // pelvis + waist: the two hubs, the base solve, the base integration
-        Limb<13, 3> WA;
-        WA.load(S, e, P.clip_actions);
+        Limb<13, 3, DR> WA;
+        WA.load(S, e, P.clip_actions, dk);
+        float ms0 = 1.f;                                            // the pelvis' mass scale
+        if constexpr (DR) ms0 = a.dr_ms ? a.dr_ms[env] : 1.f;
         BaseState base;
         base.p = row3(S.root, 0, e);
         for (int k = 0; k < 4; k++) base.quat[k] = S.root[3 + k][e];
@@ -637,7 +678,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             }
             publish(&S.f_geo_w, sub + 1);
             constexpr CPTable cp = cp_table();
-            constexpr LinkC L0 = T::link(0);
+            const LinkC L0 = dr_link<DR>(T::link(0), ms0, 1.f, 1.f);
             CH_STAMP(3 + 8 * (sub & 1));
             ArtI I0 = link_dynamics(P, L0, cp.p, f0.Rw, f0.pw, f0.w, f0.v);
             pin_art(I0);                                            // the pelvis' own dynamics: before the wait for the arms
@@ -684,6 +725,8 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         ball.w = row3(S.root, 36, e);
         S.pre_vx[e] = ball.v.x;                                                              // TA:1143
         if (live && a.pre_vx) a.pre_vx[e0 + e] = ball.v.x;
+        EnvDR bdr;
+        if constexpr (DR) { bdr.es = a.dr_es ? a.dr_es[env] : 1.f; bdr.fs = a.dr_fs ? a.dr_fs[env] : 1.f; }
         for (int sub = 0; sub < substeps; sub++) {
             TA_AWAIT(&S.f_geo_w, sub + 1);
             TA_AWAIT(&S.f_geo_ra, sub + 1);
@@ -703,7 +746,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                 g[0].vpc = row3(slot, gm.paddle_row + 6, e); g[0].pnd = row3(slot, gm.paddle_row + 9, e);
                 bound[0] = row3(S.u.hub.geo_w[sub & 1], gm.bound_row, e);
             }
-            ball_substep<ModelG1TA, 1>(*a.K, ball, g, bound);
+            ball_substep<ModelG1TA, 1, DR>(*a.K, ball, g, bound, &bdr);
             publish(&S.f_ball, sub + 1);
             CH_STAMP(6 + 8 * (sub & 1));
         }
@@ -711,11 +754,11 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         for (int k = 0; k < 4; k++) S.root[29 + k][e] = ball.quat[k];
         put3(S.root, 33, e, ball.v); put3(S.root, 36, e, ball.w);
     };
-    if (wave == W_LL) leg_role(std::common_type<Limb<1, 6>>{}, 0);
-    else if (wave == W_RL) leg_role(std::common_type<Limb<7, 6>>{}, 1);
+    if (wave == W_LL) leg_role(std::common_type<Limb<1, 6, DR>>{}, 0);
+    else if (wave == W_RL) leg_role(std::common_type<Limb<7, 6, DR>>{}, 1);
     else if (wave == W_WAIST) waist_role();
-    else if (wave == W_LA) arm_role(std::common_type<Limb<16, 7>>{}, 0, std::false_type{});
-    else if (wave == W_RA) arm_role(std::common_type<Limb<23, 5>>{}, 1, std::true_type{});
+    else if (wave == W_LA) arm_role(std::common_type<Limb<16, 7, DR>>{}, 0, std::false_type{});
+    else if (wave == W_RA) arm_role(std::common_type<Limb<23, 5, DR>>{}, 1, std::true_type{});
     else ball_role();
     CH_STAMP(20);
     __syncthreads();   // B1: the hubs are dead from here on (their memory becomes the observation tile)
@@ -726,7 +769,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     float* const orow = &S.u.obs[e * PPENV_TA_NUM_OBS];
     const ppenv_ta_params& p = a.p;
     float s22 = 0.f, s5 = 0.f, sv = 0.f, power = 0.f;      // ball wave: carried over B2
-    uint32_t f = 0, ep_in = 0;
+    uint32_t f = 0, ep_in = 0, dr_prog0 = 0;
     long long prog = 0;
     if (wave != W_BALL) {
         TaskCtx c{a, S, e, env, {0, 0, 0, 0}, mk(0, 0, 0), 0.f, 0.f, 0.f, {}};
@@ -760,6 +803,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         S.sums[wave][0][e] = c.pos_acc; S.sums[wave][1][e] = c.vel_acc; S.sums[wave][2][e] = c.norm_acc;
     } else {
         f = a.flags[env]; ep_in = a.episode[env]; prog = a.progress[env] + 1;                  // TA:1146 (loads in flight during the sums below)
+        dr_prog0 = (uint32_t)(prog - 1);
 #pragma unroll
         for (int d = 0; d < NDOF; d++) {
             const float qv = S.q[d][e], qdv = S.qd[d][e];
@@ -783,6 +827,9 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     bool any_here = false;
     if (wave == W_BALL) {
         const bool store = live && !S.dead;
+        if constexpr (DR) {   // the observation noise's keys — episode and progress at the step's START — in two rows of the torso hand-off, which is dead after B2
+            S.torso[0][e] = __uint_as_float(ep_in); S.torso[1][e] = __uint_as_float(dr_prog0);
+        }
         float pos_acc = 0.f, vel_acc = 0.f, norm_acc = 0.f;
 #pragma unroll
         for (int w = 0; w < 5; w++) { pos_acc += S.sums[w][0][e]; vel_acc += S.sums[w][1][e]; norm_acc += S.sums[w][2][e]; }
@@ -903,6 +950,17 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     if (!S.dead) {
         typedef float f4v __attribute__((ext_vector_type(4)));
         constexpr int kThreads = kWaves * 64;
+        if constexpr (DR) {
+            // observation noise (yaml: observations / gaussian / additive): on the finished tile, after the reward has been computed from the clean
+            // state and before the row leaves (and before the policy's copy of it is made) — index 32 + k, clear of the 27 action draws
+            if (a.dr_obs_sigma > 0.f) {
+                for (int t = tid; t < nvalid * PPENV_TA_NUM_OBS; t += kThreads) {
+                    const int ee = t / PPENV_TA_NUM_OBS, k = t - ee * PPENV_TA_NUM_OBS;
+                    S.u.obs[t] += a.dr_obs_sigma * ta_dr_gauss(a.p.seed, (uint32_t)(a.p.env_id_offset + e0 + ee), __float_as_uint(S.torso[0][ee]), __float_as_uint(S.torso[1][ee]), 32u + (uint32_t)k);
+                }
+            }
+            __syncthreads();       // (S.dead is the same for every thread of the workgroup after B3)
+        }
         float* dobs = a.obs + (size_t)e0 * PPENV_TA_NUM_OBS;                                           // 16-byte aligned: e0 is a multiple of 64
         if (nvalid == kE) {
             // constant trip counts: several LDS reads are in flight before the first store
@@ -1052,7 +1110,8 @@ bool ta_chain_model_matches(const TAConsts& C, char* why, size_t nwhy) {
 
 int ta_chain_launch(const TAScal& P, const TAChainArgs& a, void* stream) {
     const int n = a.p.num_envs;
-    hipLaunchKernelGGL(ta_chain_kernel, dim3((n + kE - 1) / kE), dim3(kWaves * 64), 0, (hipStream_t)stream, P, a);
+    if (a.dr_on()) hipLaunchKernelGGL(ta_chain_kernel<true>, dim3((n + kE - 1) / kE), dim3(kWaves * 64), 0, (hipStream_t)stream, P, a);
+    else hipLaunchKernelGGL(ta_chain_kernel<false>, dim3((n + kE - 1) / kE), dim3(kWaves * 64), 0, (hipStream_t)stream, P, a);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching the chain-wave 27-dof step failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }

@@ -541,6 +541,7 @@ struct ppenv_ta_sim {
     float pin_clip;
     unsigned short* pin_out;
     int pin_ld;
+    ppenv_ta_randomization dr;   // ppenv_ta_sim_set_randomization (chain-wave kernel only); all NULL / 0: off
 };
 
 namespace {
@@ -569,6 +570,15 @@ int ppenv_ta_sim_set_policy_input(ppenv_ta_sim* s, const float* mean_dev, const 
         return PPENV_EINVAL;
     }
     s->pin_mean = mean_dev; s->pin_inv_std = inv_std_dev; s->pin_clip = clip; s->pin_out = reinterpret_cast<unsigned short*>(out_f16_dev); s->pin_ld = ld_out;
+    return PPENV_OK;
+}
+/* domain randomisation tables of the 27-DoF step (chain-wave kernel): dr NULL switches it off */
+int ppenv_ta_sim_set_randomization(ppenv_ta_sim* s, const ppenv_ta_randomization* dr) {
+    if (!s) { ppenv_set_error("ppenv_ta_sim_set_randomization: NULL handle"); return PPENV_EINVAL; }
+    if (!dr) { s->dr = ppenv_ta_randomization{}; return PPENV_OK; }
+    if (!s->chain) { ppenv_set_error("ppenv_ta_sim_set_randomization: only the chain-wave kernel reads the tables (ppenv_ta_sim_kernel() == 2: the compiled G1 model)"); return PPENV_EINVAL; }
+    if (!(dr->action_noise_sigma >= 0.f) || !(dr->observation_noise_sigma >= 0.f)) { ppenv_set_error("ppenv_ta_sim_set_randomization: noise amplitudes must be >= 0"); return PPENV_EINVAL; }
+    s->dr = *dr;
     return PPENV_OK;
 }
 /* which kernel ppenv_ta_step launches: 2 chain-wave, 1 quad, 0 one lane per env */
@@ -620,6 +630,7 @@ int ppenv_ta_sim_create(const ppenv_config* scene, const ppenv_ta_model* model, 
     }
     s->status_host = s->status_dev = nullptr;
     s->pin_mean = s->pin_inv_std = nullptr; s->pin_out = nullptr; s->pin_clip = 0.f; s->pin_ld = 0;
+    s->dr = ppenv_ta_randomization{};
     // the handle lives on scene->device_id when that names a visible GPU (the caller's current device otherwise)
     int ndev = 0;
     s->device = -1;
@@ -669,6 +680,11 @@ int ppenv_ta_simulate(ppenv_ta_sim* s, int32_t n, const float* actions_dev, floa
         ppenv_set_error("ppenv_ta_simulate: NULL argument or num_envs <= 0");
         return PPENV_EINVAL;
     }
+    if (s->dr.dof_stiffness_scale || s->dr.dof_damping_scale || s->dr.link_mass_scale || s->dr.restitution_scale || s->dr.friction_scale ||
+        s->dr.action_noise_sigma > 0.f || s->dr.observation_noise_sigma > 0.f) {
+        ppenv_set_error("ppenv_ta_simulate: a randomisation is set; its tables are read by ppenv_ta_step (the chain-wave kernel) only");
+        return PPENV_EINVAL;
+    }
     if (int rc = ta_use_device(s)) return rc;
     if (s->quad)
         hipLaunchKernelGGL((ta_sim_quad_kernel<true, false>), dim3((n + kQuadEnvs - 1) / kQuadEnvs), dim3(64), 0, (hipStream_t)stream, s->dev, s->host.sc, s->devK, n, actions_dev,
@@ -698,7 +714,9 @@ int ppenv_ta_step(ppenv_ta_sim* s, const ppenv_ta_params* params, const float* a
     if (s->chain) {   // one lane per env, one wave per limb; rigid_body_states only on request
         TAChainArgs a{*params, s->devK, actions_dev, initial_rb_states_dev, root_states_dev, dof_states_dev, rb_states_dev, dof_force_dev, pre_ball_vx_dev,
                       reset_override_dev, flags_dev, episode_dev, (long long*)progress_dev, obs_dev, rew_dev, (long long*)reset_dev, scratch_any_reset_dev, s->status_dev,
-                      s->pin_mean, s->pin_inv_std, s->pin_clip, s->pin_out, s->pin_ld};
+                      s->pin_mean, s->pin_inv_std, s->pin_clip, s->pin_out, s->pin_ld,
+                      s->dr.dof_stiffness_scale, s->dr.dof_damping_scale, s->dr.link_mass_scale, s->dr.restitution_scale, s->dr.friction_scale,
+                      s->dr.action_noise_sigma, s->dr.observation_noise_sigma};
         return ta_chain_launch(s->host.sc, a, stream);
     }
     if (!rb_states_dev) { ppenv_set_error("ppenv_ta_step: rb_states may only be NULL with the chain-wave kernel (the compiled G1 model)"); return PPENV_EINVAL; }

@@ -137,6 +137,29 @@ class TASim:
         self._pin = (out, mean, inv_std)
         _lib.check(self.L.ppenv_ta_sim_set_policy_input(self.h, mean.data_ptr(), inv_std.data_ptr(), float(clip), out.data_ptr(), out.stride(0)))
 
+    def set_randomization(self, dof_stiffness_scale=None, dof_damping_scale=None, link_mass_scale=None, restitution_scale=None, friction_scale=None,
+                          action_noise_sigma=0.0, observation_noise_sigma=0.0):
+        """ppenv_ta_sim_set_randomization: per-env tables as float32 device tensors — drive stiffness / damping scales [27, N], link mass scales
+        [28, N] (link 0 = pelvis), restitution / friction scales [N]; None = not randomised — and the two noise amplitudes.  Read by every later
+        `step` (kept alive here); chain-wave kernel only."""
+        n = self.num_envs
+
+        def tab(t, rows):
+            if t is None:
+                return None
+            t = torch.as_tensor(t, dtype=torch.float32).to(self.device).contiguous()
+            assert tuple(t.shape) == ((rows, n) if rows else (n,)), tuple(t.shape)
+            return t
+        self._dr = [tab(dof_stiffness_scale, 27), tab(dof_damping_scale, 27), tab(link_mass_scale, 28), tab(restitution_scale, 0), tab(friction_scale, 0)]
+        r = scene.Randomization()      # ppenv_ta_randomization has the fields of ppenv_randomization
+        (r.dof_stiffness_scale, r.dof_damping_scale, r.link_mass_scale, r.restitution_scale, r.friction_scale) = [t.data_ptr() if t is not None else None for t in self._dr]
+        r.action_noise_sigma, r.observation_noise_sigma = float(action_noise_sigma), float(observation_noise_sigma)
+        _lib.check(self.L.ppenv_ta_sim_set_randomization(self.h, C.byref(r)))
+
+    def clear_randomization(self):
+        _lib.check(self.L.ppenv_ta_sim_set_randomization(self.h, None))
+        self._dr = None
+
     def pd_targets(self, actions):
         """pre_physics_step's PD targets (TA:1131) for actions [N,27]."""
         a = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, 27).contiguous()
@@ -226,6 +249,14 @@ class TAEnv:
     def set_policy_input(self, out=None, mean=None, inv_std=None, clip=5.0):
         """The step kernel writes the policy's first-layer input itself (TASim.set_policy_input; NativeMLP.attach_env wires it)."""
         self.sim.set_policy_input(out, mean, inv_std, clip)
+
+    def set_randomization(self, **kw):
+        """Domain-randomisation tables + noise amplitudes for every later step (TASim.set_randomization; fused step on the chain-wave kernel)."""
+        assert self.fused, "the randomisation tables are read by the fused step (ppenv_ta_step)"
+        self.sim.set_randomization(**kw)
+
+    def clear_randomization(self):
+        self.sim.clear_randomization()
 
     def reset_idx(self, env_ids=None):
         """_reset_idx (TA:965-1028) outside a step, for the listed env ids (None: all).  A rare host-driven path: plain torch

@@ -170,14 +170,14 @@ class VecTask:
         if obs:
             kw["observation_noise_sigma"] = float(obs["range"][1]) * sched(obs)
         g = (dr_params.get("sim_params") or {}).get("gravity")
-        if g:
+        if g and hasattr(self, "native_config"):      # (the 27-dof task keeps its gravity: its scene constants are uploaded once at create time)
             base = self.native_config.gravity_z
             dz = float(sample(g, (1,)).item()) if g.get("operation") == "additive" else 0.0
             self.env.set_gravity(min(base + dz, 0.0) if g.get("operation") == "additive" else base * float(sample(g, (1,)).item()))
         hum = ((dr_params.get("actor_params") or {}).get("humanoid") or {})
         mass = (hum.get("rigid_body_properties") or {}).get("mass")
         if mass:
-            kw["link_mass_scale"] = sample(mass, (scene.NUM_DOF, n))
+            kw["link_mass_scale"] = sample(mass, (getattr(self, "DR_MASS_ROWS", scene.NUM_DOF), n))
         shape = hum.get("rigid_shape_properties") or {}
         if shape.get("friction"):
             kw["friction_scale"] = sample(shape["friction"], (n,))
@@ -185,9 +185,9 @@ class VecTask:
             kw["restitution_scale"] = sample(shape["restitution"], (n,))
         dof = hum.get("dof_properties") or {}
         if dof.get("stiffness"):
-            kw["dof_stiffness_scale"] = sample(dof["stiffness"], (scene.NUM_DOF, n))
+            kw["dof_stiffness_scale"] = sample(dof["stiffness"], (getattr(self, "DR_DOF_ROWS", scene.NUM_DOF), n))
         if dof.get("damping"):
-            kw["dof_damping_scale"] = sample(dof["damping"], (scene.NUM_DOF, n))
+            kw["dof_damping_scale"] = sample(dof["damping"], (getattr(self, "DR_DOF_ROWS", scene.NUM_DOF), n))
         self.env.set_randomization(**kw)
         self.randomize_buf.zero_()
 
@@ -388,9 +388,6 @@ class HumanoidPingpongTiltNESSparse27DOF(VecTask):
         keys = ("episodeLength", "alphaVelocityReward", "powerCoefficient", "hitTableReward", "nothitTablePenalty", "crossNetRewardFloat",
                 "diePenaltyFloat", "hitPaddleReward", "missPaddlePenaltyCoefficient")
         env = {k: self.cfg["env"][k] for k in keys if k in self.cfg["env"]}
-        if self.randomize:
-            raise NotImplementedError("task.randomize = True: the randomisation tables are wired for the fused 7-dof step (ppenv_set_randomization); "
-                                      "the 27-dof task's yaml has randomize: False (cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml)")
         if self.control_freq_inv != 1:
             raise NotImplementedError("controlFrequencyInv != 1 is not wired for the 27-dof task (its yaml has none; "
                                       "cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml)")
@@ -411,9 +408,15 @@ class HumanoidPingpongTiltNESSparse27DOF(VecTask):
 
     vec_rb_states = body_states
 
+    # the 27-dof tree: 27 dofs, 28 links (link 0 = the pelvis) — the table shapes of ppenv_ta_randomization
+    DR_DOF_ROWS, DR_MASS_ROWS = scene.TA_NUM_DOF, scene.TA_NUM_LINKS
+
     def step(self, actions):
+        if self.randomize:                  # as the 7-dof tasks: once per step, gated by `frequency` (upstream: from _reset_idx, TA's reset path)
+            self.apply_randomizations(self.randomization_params)
         self.env.step(actions)              # the clipActions clamp happens inside the kernel
         self.control_steps += 1
+        self.last_step = self.control_steps
         if self.stats_every > 0 and self.control_steps % self.stats_every == 0:   # TA:860-866 prints the same two means every 40 steps
             self.extras["reward_mean"] = self.rew_buf.mean()
             self.extras["progress_mean"] = self.progress_buf.float().mean()

@@ -317,6 +317,37 @@ def ta_simulate(scene_cfg, model, actions, root, dof, threads=1):
     return rb, frc, pvx
 
 
+def ta_simulate_dr(scene_cfg, model, actions, root, dof, episode, progress, seed, env_id_offset=0, dof_stiffness_scale=None, dof_damping_scale=None,
+                   link_mass_scale=None, restitution_scale=None, friction_scale=None, action_noise_sigma=0.0, threads=1):
+    """ta_simulate with the domain-randomisation tables of ppenv_ta_randomization ([27, N] / [28, N] / [N] float32, None = not randomised) and the
+    action noise keyed by (seed, env id, episode, progress at the step's start)."""
+    L = lib()
+    n = root.shape[0]
+    for a in (actions, root, dof):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    tabs = [None if t is None else np.ascontiguousarray(t, np.float32) for t in (dof_stiffness_scale, dof_damping_scale, link_mass_scale, restitution_scale, friction_scale)]
+    for t, rows in zip(tabs, (27, 27, 28, 0, 0)):
+        assert t is None or t.shape == ((rows, n) if rows else (n,))
+    ep, pr = np.ascontiguousarray(episode, np.uint32), np.ascontiguousarray(progress, np.int64)
+    rb, frc, pvx = np.zeros((n, 42, 13), np.float32), np.zeros((n, 27), np.float32), np.zeros(n, np.float32)
+    L.ppo_ta_simulate_dr.argtypes = [C.POINTER(scene.Config), C.POINTER(scene.TAModel), C.c_int, C.c_int] + [C.c_void_p] * 11 + [C.c_float, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    L.ppo_ta_simulate_dr.restype = None
+    L.ppo_ta_simulate_dr(C.byref(scene_cfg), C.byref(model), n, threads, actions.ctypes.data, root.ctypes.data, dof.ctypes.data, rb.ctypes.data, frc.ctypes.data,
+                         pvx.ctypes.data, *[t.ctypes.data if t is not None else None for t in tabs], float(action_noise_sigma), int(seed), int(env_id_offset),
+                         ep.ctypes.data, pr.ctypes.data)
+    return rb, frc, pvx
+
+
+def ta_add_obs_noise(obs, sigma, seed, episode0, progress0, env_id_offset=0):
+    """The observation noise of the 27-dof task's randomisation, in place on obs [N, 313]: keys = episode / progress at the step's start."""
+    L = lib()
+    assert obs.dtype == np.float32 and obs.flags.c_contiguous
+    ep, pr = np.ascontiguousarray(episode0, np.uint32), np.ascontiguousarray(progress0, np.int64)
+    L.ppo_ta_add_obs_noise.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    L.ppo_ta_add_obs_noise.restype = None
+    L.ppo_ta_add_obs_noise(obs.ctypes.data, obs.shape[0], float(sigma), int(seed), int(env_id_offset), ep.ctypes.data, pr.ctypes.data)
+
+
 def ta_forward_kinematics(model, root, dof):
     L = lib()
     n = root.shape[0]

@@ -1775,6 +1775,54 @@ static void ta_simulate_env(const ppenv_config* c, const ppenv_ta_model* M, cons
     ta_body_states(M, &kf, root, rb);
 }
 
+/* Domain randomisation of the 27-DoF step (include/ppenv.h ppenv_ta_randomization; the yaml's randomization_params block, identical in every task
+ * yaml): as for the 3-actor step every env gets its OWN copy of the model and of the scene with its table entries applied — drive gains, link masses
+ * (inertia with them), restitution / friction of the humanoid's shapes and the paddle — and the action noise is added to the raw actions before the
+ * clamp.  The noise index space of this task is 512 wide (27 action draws, then 32 + k for observation value k < 313): folded into dr_gauss's
+ * 256-per-step keys as (2 progress + index / 256, index % 256); the kernel (ppenv_ta_chain.hip ta_dr_gauss) does the same. */
+static float ta_dr_gauss(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t progress, uint32_t index) {
+    return dr_gauss(seed, gid, episode, 2u * progress + (index >> 8), index & 255u);
+}
+void ppo_ta_simulate_dr(const ppenv_config* c, const ppenv_ta_model* M, int n, int threads, const float* actions, float* root_states,
+                        float* dof_states, float* rb_states, float* dof_force, float* pre_ball_vx, const float* kp_scale /*[27][n]*/,
+                        const float* kd_scale /*[27][n]*/, const float* mass_scale /*[28][n]*/, const float* e_scale /*[n]*/, const float* mu_scale /*[n]*/,
+                        float action_sigma, uint64_t seed, int env_id_offset, const uint32_t* episode, const int64_t* progress) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+#endif
+    for (int e = 0; e < n; e++) {
+        ppenv_ta_model Me = *M;
+        ppenv_config ce = *c;
+        for (int i = 0; i < PPENV_TA_NUM_LINKS; i++) {
+            ppenv_ta_link* L = &Me.link[i];
+            if (i > 0 && kp_scale) L->kp *= kp_scale[(size_t)(i - 1) * n + e];
+            if (i > 0 && kd_scale) L->kd *= kd_scale[(size_t)(i - 1) * n + e];
+            if (mass_scale) {
+                float sc = mass_scale[(size_t)i * n + e];
+                L->mass *= sc;
+                for (int k = 0; k < 6; k++) L->inertia[k] *= sc;
+            }
+        }
+        float es = e_scale ? e_scale[e] : 1.f, fs = mu_scale ? mu_scale[e] : 1.f;
+        ce.paddle_restitution = fminf(ce.paddle_restitution * es, ce.restitution_max); ce.paddle_friction *= fs;
+        for (int sh = 0; sh < ce.num_shapes; sh++) { ce.shape[sh].restitution = fminf(ce.shape[sh].restitution * es, ce.restitution_max); ce.shape[sh].friction *= fs; }
+        float act[PPENV_TA_NUM_DOF];
+        for (int d = 0; d < PPENV_TA_NUM_DOF; d++) {
+            act[d] = actions[(size_t)e * PPENV_TA_NUM_DOF + d];
+            if (action_sigma > 0.f) act[d] += action_sigma * ta_dr_gauss(seed, (uint32_t)(env_id_offset + e), episode[e], (uint32_t)progress[e], (uint32_t)d);
+        }
+        ta_simulate_env(&ce, &Me, act, &root_states[(size_t)e * 39], &dof_states[(size_t)e * 54],
+                        &rb_states[(size_t)e * 42 * 13], &dof_force[(size_t)e * PPENV_TA_NUM_DOF], &pre_ball_vx[e]);
+    }
+}
+/* observation noise: added to the finished rows, keyed by the episode / progress the step STARTED with */
+void ppo_ta_add_obs_noise(float* obs /*[n,313]*/, int n, float sigma, uint64_t seed, int env_id_offset, const uint32_t* episode0, const int64_t* progress0) {
+    if (!(sigma > 0.f)) return;
+    for (int e = 0; e < n; e++)
+        for (int k = 0; k < PPENV_TA_NUM_OBS; k++)
+            obs[(size_t)e * PPENV_TA_NUM_OBS + k] += sigma * ta_dr_gauss(seed, (uint32_t)(env_id_offset + e), episode0[e], (uint32_t)progress0[e], 32u + (uint32_t)k);
+}
+
 void ppo_ta_simulate(const ppenv_config* c, const ppenv_ta_model* M, int n, int threads, const float* actions, float* root_states,
                      float* dof_states, float* rb_states, float* dof_force, float* pre_ball_vx) {
 #ifdef _OPENMP

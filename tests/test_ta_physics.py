@@ -379,3 +379,146 @@ def test_ta_chain_kernel_clears_count_flags_across_workgroups_and_skips_rb(monke
     torch.cuda.synchronize()
     assert int(env.reset_buf.sum()) == 0 and int(env.state._any_reset.item()) == 0
     env.close()
+
+
+# ------------------------------------------------------------------------------------------- domain randomisation (round 3)
+def _ta_dr_tables(n, rng):
+    u = lambda lo, hi, shape: rng.uniform(lo, hi, shape).astype(np.float32)
+    return dict(dof_stiffness_scale=u(0.6, 1.4, (27, n)), dof_damping_scale=u(0.6, 1.4, (27, n)), link_mass_scale=u(0.7, 1.3, (28, n)),
+                restitution_scale=u(0.0, 0.7, n), friction_scale=u(0.7, 1.3, n))
+
+
+def test_ta_oracle_randomisation_with_unit_tables_is_the_plain_step(oracle_lib):
+    n = 24
+    cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
+    root, dof = initial_tensors(n, seed=4)
+    rng = np.random.default_rng(1)
+    act = rng.uniform(-1, 1, (n, 27)).astype(np.float32)
+    r2, d2 = root.copy(), dof.copy()
+    rb, frc, _ = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=4)
+    ones = {k: np.ones_like(v) for k, v in _ta_dr_tables(n, rng).items()}
+    rb2, frc2, _ = oracle_lib.ta_simulate_dr(cfg, m, act, r2, d2, np.zeros(n, np.uint32), np.zeros(n, np.int64), seed=5, threads=4, **ones)
+    np.testing.assert_array_equal(rb, rb2)
+    np.testing.assert_array_equal(frc, frc2)
+    # ... and real tables / action noise move it
+    r3, d3 = root.copy(), dof.copy()
+    oracle_lib.ta_simulate_dr(cfg, m, act, r3, d3, np.zeros(n, np.uint32), np.zeros(n, np.int64), seed=5, threads=4, action_noise_sigma=0.05, **_ta_dr_tables(n, rng))
+    r4, d4 = root.copy(), dof.copy()
+    oracle_lib.ta_simulate(cfg, m, act, r4, d4, threads=4)
+    assert np.abs(d3 - d4).max() > 1e-3
+    obs = np.zeros((n, 313), np.float32)
+    oracle_lib.ta_add_obs_noise(obs, 0.01, 5, np.zeros(n, np.uint32), np.arange(n, dtype=np.int64))
+    assert 0.008 < obs.std() < 0.012 and abs(obs.mean()) < 1e-3
+    assert len(np.unique(obs)) > 0.99 * obs.size                     # no index collisions inside a row or between consecutive steps
+    both = np.concatenate([obs[3], obs[4]])                          # progress 3 and 4 of (the same seed, different env ids)
+    assert len(np.unique(both)) == both.size
+
+
+@pytest.mark.gpu
+def test_ta_chain_kernel_with_randomisation_matches_oracle(oracle_lib, monkeypatch):
+    """The table-reading instantiation of the chain-wave kernel (per-env drive gains, link masses, materials, action and observation noise)
+    against the oracle with the same tables (every env its own scaled copy of the model), restarted from the oracle's tensors every step; with
+    the randomisation cleared the plain kernel runs again, bit for bit."""
+    import torch
+    from isaacgym_amd.tensor_api import TAEnv
+    monkeypatch.setenv("PPENV_TA_KERNEL", "chain")
+    n = 640
+    cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
+    env = TAEnv(n, device="cuda:0", seed=11, env={"episodeLength": 40}, materialize_rb=True)
+    ref = TAEnv(n, device="cuda:0", seed=11, env={"episodeLength": 40}, materialize_rb=True)
+    p = env.params
+    rng = np.random.default_rng(21)
+    tabs = _ta_dr_tables(n, rng)
+    kw = dict(action_noise_sigma=0.02, observation_noise_sigma=0.002)
+    env.set_randomization(**tabs, **kw)
+    root, dof = env.root_states.cpu().numpy().copy(), env.dof_states.cpu().numpy().copy()
+    irb = np.broadcast_to(env.initial_rb_states.cpu().numpy(), (1, 42, 13)).copy()
+    flags, episode, progress = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64)
+    oa = _ta_obs_atol() + 2e-6
+    log = ExclusionLog(f"gpu 27-dof chain-wave step with domain randomisation vs oracle [n={n}]", bound=0.005)
+    resets, moved = 0, 0.0
+    act = None
+
+    def load(e):
+        e.root_states.copy_(torch.from_numpy(root)); e.dof_states.copy_(torch.from_numpy(dof))
+        e.state.flags.copy_(torch.from_numpy(flags.view(np.int32))); e.state.episode.copy_(torch.from_numpy(episode.view(np.int32)))
+        e.state.progress_buf.copy_(torch.from_numpy(progress))
+    for t in range(70):
+        if t % 4 == 0:
+            act = rng.uniform(-1.2, 1.2, (n, 27)).astype(np.float32)
+            act[: n // 3] *= 0.1
+        load(env)
+        env.step(torch.from_numpy(act).cuda())
+        if t == 10:                                                   # the plain kernel from the same state: the tables do something
+            load(ref)
+            ref.step(torch.from_numpy(act).cuda())
+            moved = float((ref.dof_states - env.dof_states).abs().max())
+        root0, dof0, ep0, prog0 = root.copy(), dof.copy(), episode.copy(), progress.copy()
+        rb, frc, pvx = oracle_lib.ta_simulate_dr(cfg, m, act, root, dof, ep0, prog0, seed=p.seed, env_id_offset=p.env_id_offset, threads=8,
+                                                 action_noise_sigma=kw["action_noise_sigma"], **tabs)
+        # the ball's discrete contact decisions, by the ORACLE's own sensitivity (with this env's tables: a jittered second oracle step)
+        rng2 = np.random.default_rng(500 + t)
+        switch = np.zeros(n, bool)
+        for _ in range(2):
+            rj = (root0 * (1.0 + 1e-6 * rng2.uniform(-1, 1, root0.shape))).astype(np.float32)
+            dj = (dof0 * (1.0 + 1e-6 * rng2.uniform(-1, 1, dof0.shape))).astype(np.float32)
+            oracle_lib.ta_simulate_dr(cfg, m, act, rj, dj, ep0, prog0, seed=p.seed, env_id_offset=p.env_id_offset, threads=8,
+                                      action_noise_sigma=kw["action_noise_sigma"], **tabs)
+            switch |= np.abs(rj[:, 2, 7:10] - root[:, 2, 7:10]).max(axis=1) > 1e-3
+        obs, rew, reset = oracle_lib.ta_post_physics_step(p, rb, irb, root, dof, frc, pvx, None, flags, episode, progress)
+        oracle_lib.ta_add_obs_noise(obs, kw["observation_noise_sigma"], p.seed, ep0, prog0, env_id_offset=p.env_id_offset)
+        keep = ~switch
+        log.add(keep)
+        g_rb = env._rb_states.cpu().numpy()
+        g_root, g_dof, g_frc = env.root_states.cpu().numpy(), env.dof_states.cpu().numpy(), env.dof_force_tensor.cpu().numpy()
+        np.testing.assert_array_equal(env.reset_buf.cpu().numpy(), reset)
+        np.testing.assert_array_equal(env.progress_buf.cpu().numpy(), progress)
+        np.testing.assert_array_equal(env.state.flags.cpu().numpy().view(np.uint32)[keep], flags[keep])
+        check_step((g_root[keep], g_dof[keep], g_rb[keep][:, :40], g_frc[keep]), (root[keep], dof[keep], rb[keep][:, :40], frc[keep]), f"DR step {t}")
+        g_obs = env.obs_buf.cpu().numpy()
+        assert_close(np.delete(g_obs, 120, axis=1)[keep], np.delete(obs, 120, axis=1)[keep], f"DR step {t}: obs", atol=np.delete(oa, 120))
+        assert_close(env.rew_buf.cpu().numpy()[keep], rew[keep], f"DR step {t}: rew", atol=1e-4 * 3000.0 * 0.5)
+        resets += int(reset.sum())
+        flags[~keep] = env.state.flags.cpu().numpy().view(np.uint32)[~keep]
+    log.close()
+    assert resets >= n and moved > 1e-2
+    # cleared: the plain kernel again, bit for bit
+    env.clear_randomization()
+    load(env); load(ref)
+    a = torch.from_numpy(act).cuda()
+    env.step(a); ref.step(a)
+    for name in ("root_states", "dof_states", "dof_force_tensor", "obs_buf", "rew_buf"):
+        assert torch.equal(getattr(env, name), getattr(ref, name)), name
+    assert env.sim.status == 0
+    env.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_ta_vec_task_randomize_true_draws_tables_of_the_tree(monkeypatch):
+    """task.randomize = True on the 27-dof VecTask: apply_randomizations fills tables shaped for the tree ([27, N] gains, [28, N] masses) and the
+    steps stay finite; a table-driven kernel refuses the randomisation."""
+    import torch
+    from isaacgym_amd import _lib
+    from isaacgym_amd.tasks import isaacgym_task_map
+    from isaacgym_amd.tensor_api import TASim
+    cfg = scene.default_task_cfg("TA")
+    cfg["env"]["numEnvs"] = 256
+    cfg["task"] = {"randomize": True, "randomization_params": {
+        "frequency": 8, "observations": {"range": [0, 0.002], "operation": "additive", "distribution": "gaussian"},
+        "actions": {"range": [0.0, 0.02], "operation": "additive", "distribution": "gaussian"},
+        "actor_params": {"humanoid": {"rigid_body_properties": {"mass": {"range": [0.8, 1.2], "operation": "scaling", "distribution": "uniform"}},
+                                      "rigid_shape_properties": {"restitution": {"range": [0.0, 0.7], "operation": "scaling", "distribution": "uniform"}},
+                                      "dof_properties": {"stiffness": {"range": [0.8, 1.2], "operation": "scaling", "distribution": "uniform"},
+                                                         "damping": {"range": [0.8, 1.2], "operation": "scaling", "distribution": "uniform"}}}}}}
+    task = isaacgym_task_map["HumanoidPingpongTiltNESSparse27DOFG1"](cfg, "cuda:0", "cuda:0", -1, True, False, False)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(20):
+        obs, rew, done, _ = task.step(torch.rand(256, 27, device="cuda", generator=gen) * 2 - 1)
+    dr = task.env.sim._dr
+    assert tuple(dr[0].shape) == (27, 256) and tuple(dr[2].shape) == (28, 256) and dr[3].shape == (256,) and dr[4] is None
+    assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all() and task.env.sim.status == 0
+    monkeypatch.setenv("PPENV_TA_KERNEL", "quad")
+    sim = TASim(64, device="cuda:0")
+    with pytest.raises(_lib.PPEnvError, match="chain-wave"):
+        sim.set_randomization(action_noise_sigma=0.1)
+    sim.close()
