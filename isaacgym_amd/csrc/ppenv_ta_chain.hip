@@ -43,7 +43,15 @@ void ppenv_set_error(const char* msg);   // ppenv.hip
 
 namespace {
 using T = ModelG1Tree;
-constexpr int kE = 64;                 // envs per workgroup = lanes per wave
+constexpr int kE = 64;                 // lanes per wave = rows of every LDS tile
+// Envs per workgroup.  64 in the product.  Diagnostic builds (tools/gpu_ta_narrow.sh, round 3) set 32 or 16: the upper lanes of every wave idle (they chew on
+// a copy of the workgroup's last env, like the lanes of a ragged last workgroup) and the grid has 2x / 4x the workgroups — at 4096 envs 128 / 256 CUs get one
+// instead of 64.  Measured: the chain does not get shorter (a wave issues an instruction in four passes whatever its EXEC mask), see DESIGN.md §9.
+#ifndef TA_ENVS_PER_WG
+#define TA_ENVS_PER_WG 64
+#endif
+constexpr int kEPW = TA_ENVS_PER_WG;
+static_assert(kEPW == 64 || kEPW == 32 || kEPW == 16, "envs per workgroup");
 constexpr int kWaves = 6;
 // Role -> wave index.  A workgroup's waves are dealt round-robin over the CU's four SIMDs (wave i on SIMD i & 3), so six waves
 // leave two SIMDs with two waves each.  The critical path is waist -> arms -> waist; the legs finish early and the ball wave is
@@ -506,12 +514,12 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     __shared__ Shared S;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int e0 = blockIdx.x * kE;
+    const int e0 = blockIdx.x * kEPW;
     const int n = a.p.num_envs;
-    const int nvalid = min(kE, n - e0);
+    const int nvalid = min(kEPW, n - e0);
     const int e = lane;
-    const int env = min(e0 + e, n - 1);           // lanes past the last env compute on a copy of it and store nothing
-    const bool live = e0 + e < n;
+    const int env = e0 + min(e, nvalid - 1);      // lanes past the workgroup's last env compute on a copy of it and store nothing (or the same values to its rows)
+    const bool live = e < nvalid;
     bool dead = false;                            // a hand-off timed out: finish without storing (TA_AWAIT)
     const int substeps = P.substeps;
 
@@ -1110,8 +1118,8 @@ bool ta_chain_model_matches(const TAConsts& C, char* why, size_t nwhy) {
 
 int ta_chain_launch(const TAScal& P, const TAChainArgs& a, void* stream) {
     const int n = a.p.num_envs;
-    if (a.dr_on()) hipLaunchKernelGGL(ta_chain_kernel<true>, dim3((n + kE - 1) / kE), dim3(kWaves * 64), 0, (hipStream_t)stream, P, a);
-    else hipLaunchKernelGGL(ta_chain_kernel<false>, dim3((n + kE - 1) / kE), dim3(kWaves * 64), 0, (hipStream_t)stream, P, a);
+    if (a.dr_on()) hipLaunchKernelGGL(ta_chain_kernel<true>, dim3((n + kEPW - 1) / kEPW), dim3(kWaves * 64), 0, (hipStream_t)stream, P, a);
+    else hipLaunchKernelGGL(ta_chain_kernel<false>, dim3((n + kEPW - 1) / kEPW), dim3(kWaves * 64), 0, (hipStream_t)stream, P, a);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching the chain-wave 27-dof step failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }
