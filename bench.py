@@ -548,39 +548,53 @@ def secondary_configs(device, only=None, cpu=True):
     for name, cfg_no, variant, n, rollout in plan:
         if only and name not in only:
             continue
-        w = Workload(variant, n, device, rollout=rollout)
-        w.capture([HORIZON])
-        us, regions = w.kernel_region_us(128, 320, 3)
-        row = {"name": name, "baseline_config": f"BASELINE.json configs[{cfg_no - 1}]", "variant": variant, "num_envs": n,
-               "workload": WORKLOAD_NAMES[variant] + (", rollout step = normalise + actor/critic forward + action draw + env step" if rollout else ""),
-               "launch": f"HIP graph of {HORIZON} steps, replayed", "dtype": "f32" if not rollout else "f32 env step, f16 operands / f32 accumulation in the policy",
-               "region": "3 x 320 launches after 128 (median)"}
-        if not rollout:
-            row.update({"avg_kernel_us": us, "env_steps_per_s": n / (us * 1e-6), "agent_steps_per_s": w.rows / (us * 1e-6),
-                        "roofline": hbm_roofline(variant, n, us, regions)})
-        else:
-            fwd_us, _ = w.kernel_region_us(16, 64, 3, fn=w.forward)            # the eight launches of one forward, eager, back to back
-            tf = w.policy_flops / (fwd_us * 1e-6) / 1e12
-            step_us = rows[-1]["avg_kernel_us"] if rows and rows[-1]["name"] == "c5_TA_4096_step" else None
-            row.update({"us_per_rollout_step": us, "env_steps_per_s": n / (us * 1e-6), "us_policy_forward": fwd_us,
-                        "us_env_step_alone": step_us, "policy_gflop_per_step": w.policy_flops / 1e9,
-                        "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
-                                     "traffic": None, "kernel": "mlp_layer_pp_kernel / mlp_layer_pp1_kernel (policy forward: 8 launches)",
-                                     "avg_kernel_us": fwd_us, "flops_per_launch_sequence": w.policy_flops}})
-        w.close()
-        del w
-        torch.cuda.empty_cache()
-        if cpu:
-            try:
-                row["cpu_baseline"] = cpu_baseline_rollout(256, cores) if rollout else cpu_baseline(n, target_seconds=2.5, variant=variant)
-            except Exception as e:   # noqa: BLE001 - a CPU row must not cost the GPU rows
-                row["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-        rows.append(row)
+        try:
+            rows.append(_secondary_row(device, name, cfg_no, variant, n, rollout, rows, cores, cpu))
+        except Exception as e:   # noqa: BLE001 - a secondary row must never cost the headline line
+            rows.append({"name": name, "error": f"{type(e).__name__}: {e}"})
+            torch.cuda.empty_cache()
     for m in (8192, 32768):
         if only and f"c5_TA_learner_minibatch_{m}" not in only:
             continue
-        rows.append(learner_config(device, m, cores, cpu=cpu))
+        try:
+            rows.append(learner_config(device, m, cores, cpu=cpu))
+        except Exception as e:   # noqa: BLE001
+            rows.append({"name": f"c5_TA_learner_minibatch_{m}", "error": f"{type(e).__name__}: {e}"})
+            torch.cuda.empty_cache()
     return rows
+
+
+def _secondary_row(device, name, cfg_no, variant, n, rollout, rows, cores, cpu):
+    """One row of secondary_configs: an env-step config (HBM roofline) or the rollout config (MFMA roofline of its policy forward)."""
+    import torch
+    w = Workload(variant, n, device, rollout=rollout)
+    w.capture([HORIZON])
+    us, regions = w.kernel_region_us(128, 320, 3)
+    row = {"name": name, "baseline_config": f"BASELINE.json configs[{cfg_no - 1}]", "variant": variant, "num_envs": n,
+           "workload": WORKLOAD_NAMES[variant] + (", rollout step = normalise + actor/critic forward + action draw + env step" if rollout else ""),
+           "launch": f"HIP graph of {HORIZON} steps, replayed", "dtype": "f32" if not rollout else "f32 env step, f16 operands / f32 accumulation in the policy",
+           "region": "3 x 320 launches after 128 (median)"}
+    if not rollout:
+        row.update({"avg_kernel_us": us, "env_steps_per_s": n / (us * 1e-6), "agent_steps_per_s": w.rows / (us * 1e-6),
+                    "roofline": hbm_roofline(variant, n, us, regions)})
+    else:
+        fwd_us, _ = w.kernel_region_us(16, 64, 3, fn=w.forward)            # the eight launches of one forward, eager, back to back
+        tf = w.policy_flops / (fwd_us * 1e-6) / 1e12
+        step_us = rows[-1].get("avg_kernel_us") if rows and rows[-1]["name"] == "c5_TA_4096_step" else None
+        row.update({"us_per_rollout_step": us, "env_steps_per_s": n / (us * 1e-6), "us_policy_forward": fwd_us,
+                    "us_env_step_alone": step_us, "policy_gflop_per_step": w.policy_flops / 1e9,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+                                 "traffic": None, "kernel": "mlp_layer_pp_kernel / mlp_layer_pp1_kernel (policy forward: 8 launches)",
+                                 "avg_kernel_us": fwd_us, "flops_per_launch_sequence": w.policy_flops}})
+    w.close()
+    del w
+    torch.cuda.empty_cache()
+    if cpu:
+        try:
+            row["cpu_baseline"] = cpu_baseline_rollout(256, cores) if rollout else cpu_baseline(n, target_seconds=2.5, variant=variant)
+        except Exception as e:   # noqa: BLE001 - a CPU row must not cost the GPU rows
+            row["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    return row
 
 
 def main():
@@ -848,7 +862,10 @@ def main():
             if args.variant == VARIANT and not rollout:
                 out["cpu_baseline_rows"] = cpu_baseline_rows(out["cpu_baseline"]["cores"])
         if world == 1 and not args.no_configs and not rollout and args.variant == VARIANT and not gather and dist is None:
-            out["configs"] = secondary_configs(device, cpu=not args.no_cpu_baseline)
+            try:
+                out["configs"] = secondary_configs(device, cpu=not args.no_cpu_baseline)
+            except Exception as e:   # noqa: BLE001 - the headline line is printed whatever happens to the secondary rows
+                out["configs"] = [{"error": f"{type(e).__name__}: {e}"}]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

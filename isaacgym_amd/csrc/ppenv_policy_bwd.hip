@@ -223,6 +223,18 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
+// the same for a destination [n, ld_dst] with ld_dst > k (a padded weight-gradient image): src rows are [n, k] contiguous
+__global__ __launch_bounds__(256) void reduce_rows_2d_kernel(const float* __restrict__ src, int rows, long long row_stride, int n, int k, float* __restrict__ dst,
+                                                             int ld_dst, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n * k) return;
+    const int r = (int)(i / k), c = (int)(i - (long long)r * k);
+    float* d = dst + (size_t)r * ld_dst + c;
+    float s = accumulate ? *d : 0.f;
+    for (int p = 0; p < rows; p++) s += src[(size_t)p * row_stride + i];
+    *d = s;
+}
+
 // the same sum for MANY rows of a narrow matrix (the 512 per-block column sums behind a bias gradient at M = 32768): one thread walking all the
 // rows would be 512 dependent round trips to memory.  A workgroup owns 64 columns: thread -> float4 column tid & 15, row class tid >> 4 (rows
 // rc, rc + 16, ... four loads in flight), then the 16 classes are added through LDS in class order — a fixed order, so still deterministic.
@@ -429,12 +441,11 @@ extern "C" int ppenv_mlp_layer_backward_weight(const ppenv_mlp_dw* d, void* stre
             const long long tot = nk * d->batch;
             hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((tot / 4 + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
                                reinterpret_cast<const float*>(d->workspace), s, nk * d->batch, tot, d->dw, d->accumulate);
-        } else {
+        } else {                                     // a padded leading dimension or batch stride: one launch per batch entry, (row, column) addressing
             for (int b = 0; b < d->batch; b++)
-                for (int r = 0; r < d->n; r++)       // ragged leading dimension: row by row (not a path the policy takes)
-                    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((d->k / 4 + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
-                                       reinterpret_cast<const float*>(d->workspace) + (size_t)b * nk + (size_t)r * d->k, s, nk * d->batch, (long long)d->k,
-                                       d->dw + (size_t)b * d->dw_stride + (size_t)r * d->lddw, d->accumulate);
+                hipLaunchKernelGGL(reduce_rows_2d_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                   reinterpret_cast<const float*>(d->workspace) + (size_t)b * nk, s, nk * d->batch, d->n, d->k,
+                                   d->dw + (size_t)b * d->dw_stride, d->lddw, d->accumulate);
         }
         if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching reduce_rows_kernel failed"); return PPENV_EHIP; }
     }

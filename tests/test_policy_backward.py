@@ -68,6 +68,10 @@ def test_weight_gradient_kernel_exact_on_integer_data(m, n, k, batch, splits):
     dw = base.cuda()
     layer_backward_weight(dw, dzd, xd, batch=batch, dz_stride=n, x_stride=k, dw_stride=n * k, n=n, k=k, splits=splits, accumulate=True)
     assert torch.equal(dw.cpu(), want + base)
+    # a padded gradient image (lddw > k, a batch stride that is not n k): the columns beyond k are left alone
+    pad = torch.full((batch, n + 3, k + 8), 7.0, device="cuda")
+    layer_backward_weight(pad[:, :n, :k], dzd, xd, batch=batch, dz_stride=n, x_stride=k, dw_stride=(n + 3) * (k + 8), n=n, k=k, splits=splits)
+    assert torch.equal(pad[:, :n, :k].cpu(), want) and bool((pad[:, n:, :] == 7.0).all()) and bool((pad[:, :, k:] == 7.0).all())
 
 
 @pytest.mark.gpu
