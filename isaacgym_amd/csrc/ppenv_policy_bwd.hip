@@ -392,13 +392,23 @@ __global__ __launch_bounds__(256) void rms_update_kernel(const float* __restrict
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-// splits: enough workgroups for two rounds of the 256 CUs, a power of two (XCD placement), at least 8 contraction tiles each
+// splits: the power of two that minimises a small cost model fitted to measurements (tools/gpu_mlp_bwd_layers.py --splits, M = 8192 and 32768):
+//   rounds of 256 workgroups x contraction tiles per workgroup x time per 256 x 256 x 64 tile (1.25 us on a lightly used chip, 1.9 us when every CU
+//   has a workgroup and the clock sags) + the partial images' round trip through memory (written once, read once; ~60 % of it hidden behind other
+//   workgroups' compute at ~4 TB/s).  More splits fill the chip and shorten each workgroup's loop, but the partials grow with them while the GEMM
+//   shrinks with M: at M = 8192 the widest layer wants 2 splits, the narrowest 16; at M = 32768 they want 8 and 32.
 int choose_splits(const ppenv_mlp_dw* d) {
-    const long long tiles = (long long)((d->n + 255) / 256) * ((d->k + 255) / 256) * d->batch;
+    const double tiles = (double)((d->n + 255) / 256) * ((d->k + 255) / 256) * d->batch;
     const int ktiles = d->m / 64;
-    int s = 1;
-    while (tiles * s < 512 && s * 2 * 8 <= ktiles && s < 64) s *= 2;
-    return s;
+    const double image_mb = (double)d->n * d->k * d->batch * 4.0 / 1e6;
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= 64 && s * 2 <= ktiles; s *= 2) {
+        const double wgs = tiles * s, busy = wgs < 256.0 ? wgs / 256.0 : 1.0, rounds = (double)(((long long)wgs + 255) / 256);
+        const double t = rounds * ((double)ktiles / s) * (1.25 + 0.65 * busy) + (s > 1 ? 0.3 * s * image_mb : 0.0);
+        if (t < best_t) { best_t = t; best = s; }
+    }
+    return best;
 }
 }  // namespace
 
