@@ -53,12 +53,23 @@ constexpr int kE = 64;                 // lanes per wave = rows of every LDS til
 constexpr int kEPW = TA_ENVS_PER_WG;
 static_assert(kEPW == 64 || kEPW == 32 || kEPW == 16, "envs per workgroup");
 constexpr int kWaves = 6;
-// Role -> wave index.  A workgroup's waves are dealt round-robin over the CU's four SIMDs (wave i on SIMD i & 3), so six waves
-// leave two SIMDs with two waves each.  The critical path is waist -> arms -> waist; the legs finish early and the ball wave is
-// short.  The arms therefore get SIMDs 2 and 3 to themselves, the waist shares SIMD 0 with the left leg (it waits for the arms
-// while the leg works) and the right leg shares SIMD 1 with the ball.  (Measured with the first numbering — right arm on the
-// left leg's SIMD: the right arm's five links took 15.7k cycles against 11k for the left arm's seven.)
+// Role -> wave index.  A workgroup's waves are dealt round-robin over the CU's four SIMDs (wave i on SIMD i & 3), so six waves leave two SIMDs with two waves
+// each.  The critical path is waist -> arms -> waist, with the legs close behind.  Round 3 (tools/gpu_ta_rolemap.sh, profiles/r03_d_ta_rolemap.txt): the waist
+// shares SIMD 0 with the RIGHT ARM — the two take turns by construction (the arm waits for the torso's pose, the waist for the arms' inertias, the arm for the
+// torso's acceleration), so they hardly ever want the same issue slot — the right leg shares SIMD 1 with the (short) ball wave, and the left leg and the left arm
+// (seven links) get SIMDs 2 and 3 to themselves: 30.6 us at 4096 envs.  Round 2's placement (TA_ROLE_MAP=0: the waist with the LEFT LEG, both arms alone) made
+// the left leg the last to deliver its inertia (24.2k cycles into the step against 20.8k for the right leg): 31.4 us.  The waist with the left arm
+// (TA_ROLE_MAP=2): 32.5 us.  (Round 2, first numbering — right arm on the left leg's SIMD: the right arm's five links took 15.7k cycles against 11k for the left's seven.)
+#ifndef TA_ROLE_MAP
+#define TA_ROLE_MAP 1
+#endif
+#if TA_ROLE_MAP == 1
+enum { W_WAIST = 0, W_RL = 1, W_LL = 2, W_LA = 3, W_RA = 4, W_BALL = 5 };
+#elif TA_ROLE_MAP == 2
+enum { W_WAIST = 0, W_RL = 1, W_LL = 2, W_RA = 3, W_LA = 4, W_BALL = 5 };
+#else
 enum { W_WAIST = 0, W_RL = 1, W_LA = 2, W_RA = 3, W_LL = 4, W_BALL = 5 };
+#endif
 constexpr int kTorso = 15;
 constexpr int kGeoW = 39, kGeoRA = 48; // floats of collision geometry the waist / right-arm wave hand to the ball wave
 

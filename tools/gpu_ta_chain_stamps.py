@@ -34,7 +34,8 @@ assert L.ppenv_ta_chain_debug_read_stamps(buf.ctypes.data, buf.size) == 0
 t = buf.reshape(1024, 6, 32)[:nb].astype(np.int64)
 t0 = t[:, :, 0].min(axis=1, keepdims=True)[:, :, None]
 rel = t - t0
-names = ["waist", "right leg", "left arm", "right arm", "left leg", "ball"]   # wave index order (ppenv_ta_chain.hip W_*)
+names = {"0": ["waist", "right leg", "left arm", "right arm", "left leg", "ball"], "1": ["waist", "right leg", "left leg", "left arm", "right arm", "ball"],
+         "2": ["waist", "right leg", "left leg", "right arm", "left arm", "ball"]}[os.environ.get("TA_ROLE_MAP", "1")]   # wave index order (ppenv_ta_chain.hip W_*, per TA_ROLE_MAP)
 pts = {0: "start", 1: "inputs staged", 2: "s1 begin", 3: "s1 pass1 done", 7: "s1 (waist) pelvis dyn", 4: "s1 pass2 done / arms in", 8: "s1 (waist) waist pass2", 9: "s1 (waist) legs in",
        5: "s1 accel in/out", 6: "s1 end", 10: "s2 begin", 11: "s2 pass1 done", 15: "s2 (waist) pelvis dyn", 12: "s2 pass2 done / arms in", 16: "s2 (waist) waist pass2",
        17: "s2 (waist) legs in", 13: "s2 accel in/out", 14: "s2 end", 20: "B1 arrive", 21: "B1 leave", 22: "B2 arrive", 23: "B2 leave", 24: "B3 arrive", 25: "B3 leave", 26: "end"}
