@@ -166,10 +166,11 @@ def pmc_traffic(num_envs, variant=VARIANT):
     bench.py cannot collect counters itself; null when no profile of this kernel at this workload size is committed."""
     import glob
     best = None
-    kernel = kernel_name(variant).replace(" ", "")
+    kernel = kernel_name(variant).replace(" ", "").rstrip(">")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
         d = json.load(open(f))
-        if d.get("num_envs") == num_envs and d.get("kernel", "").replace(" ", "") == kernel:
+        k = d.get("kernel", "").replace(" ", "").rstrip(">")      # a profile may name the kernel with fewer template arguments (defaults added later)
+        if d.get("num_envs") == num_envs and k and (kernel.startswith(k) or k.startswith(kernel)):
             best = d["hbm_bytes_per_launch"]
     return best
 
