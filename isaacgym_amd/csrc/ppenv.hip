@@ -1329,6 +1329,7 @@ int ppenv_create(const ppenv_config* cfg, void* arena_dev, size_t arena_bytes, v
         const char* k = getenv("PPENV_STEP_KERNEL");
         e->split = k ? (strcmp(k, "fused") != 0) : 1;
         if (k && strcmp(k, "quad") == 0) e->split = 3;          // four waves per 64 envs (single-humanoid variants)
+        if (k && strcmp(k, "split_g1") == 0) e->split = 4;      // two waves, the ARM wave sweeps the collision geometry (round-3 experiment, single-humanoid variants)
         if (cfg->substeps > kMaxSplitSubsteps) e->split = 0;   // one LDS hand-off slot per substep boundary
         if (e->agents == 2) e->split = (k && strcmp(k, "split3") == 0) ? 1 : 2;
         else if (e->split == 3 && cfg->substeps > kMaxSplitSubsteps) e->split = 0;   // 4-actor: arm waves sweep the geometry (default), or the ball wave
@@ -1436,6 +1437,9 @@ static int launch_step(ppenv* e, const DevBuffers& buf, const float* actions_dev
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->agents == 2)
         hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, buf,
+                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+    else if (e->split == 4)
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, buf,
                            actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
     else if (e->split == 3)
         hipLaunchKernelGGL((step_kernel_quad<ModelG1>), dim3(grid_for(e->cfg.num_envs)), dim3(4 * kBlock), 0, (hipStream_t)stream, e->K, buf,
