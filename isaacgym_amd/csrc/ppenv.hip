@@ -353,7 +353,10 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
     // Who writes dof_pos / dof_vel / dof_force.  With one humanoid the arm wave is the critical path and would sit waiting
     // for the ball wave's reset decision just to pick between q and the initial pose: the ball wave, which has both, stores
     // them instead.  With two humanoids the ball wave is the critical path and the arm waves keep the stores.
-    constexpr bool kBallStoresDofs = A == 1;
+#ifndef PP_BALL_STORES_DOFS
+#define PP_BALL_STORES_DOFS 1      // profiling builds: 0 = the arm wave stores the dof state of the one-humanoid variants too (it waits for the reset decision)
+#endif
+    constexpr bool kBallStoresDofs = A == 1 && PP_BALL_STORES_DOFS;
     __shared__ float s_geom[G ? 2 : 1][G ? A : 1][G ? kGeo : 1][G ? kBlock : 1];   // geometry of boundary s in slot s & 1
     __shared__ int s_gflag[A];                         // arm -> ball: boundaries whose geometry is in LDS
     __shared__ int s_bflag;                            // ball -> arm: substeps the ball has finished (slot reuse)
