@@ -13,6 +13,8 @@ reward and mean progress — plus the episode count: three scalars, one all-redu
 (backend "nccl" on ROCm) or gloo in the CPU tests.  `gather_rollout` is the optional
 obs/reward/done all-gather for a single central learner; DESIGN.md explains why it cannot be the
 default (the env emits more obs bytes per second than one GPU's xGMI links can absorb).
+`GradientBuckets` is the learners' side of that mode: the gradient all-reduce, one bucket per layer, issued while the
+backward of the layers below is still running.
 """
 import os
 
@@ -177,3 +179,34 @@ class RolloutGather:
         if ed == 0 and not self.ragged:
             return recv.reshape((self.world * self.m,) + tuple(recv.shape[2:]))
         return torch.cat(parts, dim=ed)
+
+
+class GradientBuckets:
+    """Data-parallel learners (the reference's multi-GPU mode: one env shard + one learner per rank, `train.py:117-120`; rl_games averages the
+    gradients over the ranks before every optimizer step).  A callable for `NativeMLPLearner.backward(on_grads=...)`: each layer's gradient tensors
+    are all-reduced as soon as the backward has ENQUEUED the kernels that produce them — asynchronously, so the collective of layer l runs on RCCL's
+    stream beside the dX / dW kernels of the layers below it (a layer's dW of both networks is 0.5–25 MB: a bucket by itself; xGMI is point to point,
+    large buckets keep its per-link rings busy).  `wait()` joins them (the compute stream then waits for the collectives) and turns the sums into means;
+    call it before the optimizer step.  force: issue the collectives even in a one-rank group (the RCCL path on a one-GPU box)."""
+
+    def __init__(self, group=None, force=False):
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.works, self.tensors, self.names, self.bytes = [], [], [], 0
+
+    def __call__(self, name, tensors):
+        self.names.append(name)
+        for t in tensors:
+            self.tensors.append(t)
+            self.bytes += t.numel() * t.element_size()
+            if self.active:
+                self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        if self.world > 1:
+            for t in self.tensors:
+                t.div_(self.world)
+        self.works, self.tensors = [], []

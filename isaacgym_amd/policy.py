@@ -409,8 +409,10 @@ class NativeMLPLearner:
             self.rms.update(obs)
         return self.net.forward(obs)
 
-    def backward(self, d_head, accumulate=False):
-        """d_head [M, A + 1] fp32 = d loss / d [mu | value] of the rows of the last forward (M a multiple of 64)."""
+    def backward(self, d_head, accumulate=False, on_grads=None):
+        """d_head [M, A + 1] fp32 = d loss / d [mu | value] of the rows of the last forward (M a multiple of 64).
+        on_grads(name, tensors): called once per layer — heads first, layer 1 last — right after the launches that produce that layer's weight and
+        bias gradients have been enqueued (distributed.GradientBuckets: the gradient all-reduce of a layer overlaps the backward of the layers below)."""
         net, u, na = self.net, self.net.units, self.net.num_actions
         m = d_head.shape[0]
         assert m == net._rows and m % 64 == 0 and d_head.dtype == torch.float32 and d_head.shape[1] == na + 1 and d_head.stride(1) == 1
@@ -420,6 +422,8 @@ class NativeMLPLearner:
         prepare_input(self.dhead16, d_head)                                # cast + pad to whole chunks (no statistics)
         bias_grad_f32(g["head_b"], d_head, accumulate, self.ws_b)
         layer_backward_weight(g["head_w"], self.dhead16, net.h[-1], accumulate=accumulate, workspace=self.ws)
+        if on_grads is not None:
+            on_grads("heads", [g["head_w"], g["head_b"]])
         cur = self.dz[(nl - 1) & 1][:, :2 * u[-1]]
         layer_backward_input(cur, self.dhead16, self.head_wt, elu_out=net.h[-1], colsum_partial=self.colsum)
         for i in range(nl - 1, -1, -1):
@@ -427,10 +431,14 @@ class NativeMLPLearner:
             reduce_rows(g["b"][i].view(-1), self.colsum, rows=blocks, n=2 * n, accumulate=accumulate)
             if i == 0:                                                     # both networks read the same rows: one problem over the stacked weights
                 layer_backward_weight(g["w"][0].view(2 * n, -1), cur, net.x16, accumulate=accumulate, workspace=self.ws)
+                if on_grads is not None:
+                    on_grads("layer1", [g["w"][0], g["b"][0]])
                 break
             k = u[i - 1]
             layer_backward_weight(g["w"][i], cur, net.h[i - 1], batch=2, dz_stride=n, x_stride=k, dw_stride=n * k, m=m, n=n, k=k,
                                   accumulate=accumulate, workspace=self.ws)
+            if on_grads is not None:
+                on_grads(f"layer{i + 1}", [g["w"][i], g["b"][i]])
             nxt = self.dz[(i - 1) & 1][:, :2 * k]
             layer_backward_input(nxt, cur, self.wt[i], elu_out=net.h[i - 1], colsum_partial=self.colsum, batch=2, dz_stride=n, wt_stride=k * n,
                                  dx_stride=k, elu_out_stride=k, colsum_stride=k, m=m, n=k, k=n)
@@ -456,7 +464,11 @@ class _ActorCriticFn(torch.autograd.Function):
             d_head[:, :na] = d_mu
         if d_value is not None:
             d_head[:, na:] = d_value
-        return (None, None) + tuple(g.clone() for g in lr.backward(d_head))
+        sync = ctx.module.grad_sync                   # distributed.GradientBuckets (or None): per-layer all-reduce beside the rest of the backward
+        grads = lr.backward(d_head, on_grads=sync)
+        if sync is not None:
+            sync.wait()                              # the clones below are ordered after the collectives
+        return (None, None) + tuple(g.clone() for g in grads)
 
 
 class NativeActorCritic(torch.nn.Module):
@@ -480,6 +492,7 @@ class NativeActorCritic(torch.nn.Module):
         self.hidden_b = torch.nn.ParameterList([P(b) for b in lr.b32])
         self.mu_w, self.mu_b, self.value_w, self.value_b = P(lr.mu_w), P(lr.mu_b), P(lr.value_w), P(lr.value_b)
         self.sigma = P(torch.zeros(lr.net.num_actions, device=lr.device), requires_grad=False)   # fixed_sigma: log-std, const 0 (yaml:21-27)
+        self.grad_sync = None                        # set to a distributed.GradientBuckets for data-parallel learners (multi_gpu: True)
         self._seen = self._versions()
 
     @classmethod

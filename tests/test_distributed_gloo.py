@@ -218,3 +218,38 @@ def test_rollout_gather_single_process_is_a_local_copy_and_pads():
     g.push(1, [x], env_dims=[1])
     assert torch.equal(g.result(1, 0), x)
     assert g.bytes_sent == 3 * 8 * 4
+
+
+def _grad_bucket_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from isaacgym_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = D.GradientBuckets()
+    assert b.active and b.world == world
+    layers = {"heads": [torch.full((8, 64), float(rank + 1)), torch.full((8,), 10.0 * (rank + 1))], "layer2": [torch.arange(12.0).view(2, 2, 3) * (rank + 1), torch.ones(2, 2) * rank]}
+    for name, ts in layers.items():          # the learner's backward calls it layer by layer; the collectives are in flight until wait()
+        b(name, ts)
+    assert b.names == ["heads", "layer2"] and b.bytes == (8 * 64 + 8 + 12 + 4) * 4
+    b.wait()
+    if rank == 0:
+        torch.save(layers, os.path.join(out_dir, "buckets.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_average_over_two_ranks(tmp_path):
+    """distributed.GradientBuckets (the data-parallel learners' per-layer gradient all-reduce): sums over the ranks, then the mean, in place."""
+    mp.spawn(_grad_bucket_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "buckets.pt")
+    assert torch.equal(got["heads"][0], torch.full((8, 64), 1.5)) and torch.equal(got["heads"][1], torch.full((8,), 15.0))
+    assert torch.equal(got["layer2"][0], torch.arange(12.0).view(2, 2, 3) * 1.5) and torch.equal(got["layer2"][1], torch.full((2, 2), 0.5))
+
+
+def test_gradient_buckets_without_a_process_group_leave_the_gradients_alone():
+    from isaacgym_amd import distributed as D
+    b = D.GradientBuckets()
+    t = torch.arange(6.0)
+    b("layer1", [t])
+    b.wait()
+    assert not b.active and torch.equal(t, torch.arange(6.0)) and b.names == ["layer1"]

@@ -336,3 +336,42 @@ def test_learner_forward_backward_is_graph_capturable():
         torch.cuda.synchronize()
     for a, b in zip(eager, learner.gradients()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_learner_backward_all_reduces_each_layer_on_rccl_with_one_rank():
+    """The data-parallel learners' collective on the real transport, as far as a one-GPU box allows: NativeActorCritic with
+    grad_sync = GradientBuckets(force=True) in a one-rank nccl group — every layer's gradients go through an asynchronous all_reduce issued right after
+    the launches that produce them (heads first, layer 1 last), and come out as they went in (a mean over one rank)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from isaacgym_amd import distributed as D
+from isaacgym_amd.policy import NativeActorCritic
+from test_policy_mlp import _mlp
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+gen = torch.Generator().manual_seed(4)
+actor, critic = _mlp(torch, 80, (256, 128), 7, gen), _mlp(torch, 80, (256, 128), 1, gen)
+obs, w = torch.randn(512, 80, generator=gen).cuda(), torch.randn(512, 8, generator=gen).cuda()
+grads = []
+for sync in (None, D.GradientBuckets(force=True)):
+    net = NativeActorCritic(actor, critic, 80, dev, normalize_input=False)
+    net.grad_sync = sync
+    mu, value = net(obs)
+    (torch.cat([mu, value], dim=1) * w).sum().backward()
+    torch.cuda.synchronize()
+    grads.append([p.grad.clone() for p in net.parameters() if p.requires_grad])
+assert sync.active and sync.names == ["heads", "layer2", "layer1"], sync.names
+assert sync.bytes == sum(t.numel() * 4 for t in net.learner.grads["w"] + net.learner.grads["b"]) + net.learner.grads["head_w"].numel() * 4 + net.learner.grads["head_b"].numel() * 4
+for a, b in zip(*grads):
+    assert torch.equal(a, b)
+dist.barrier(); dist.destroy_process_group(); print("ok")
+''' % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]

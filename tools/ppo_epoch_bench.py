@@ -31,8 +31,19 @@ ap.add_argument("--learner", default="native", choices=["native", "torch"])
 ap.add_argument("--num-envs", type=int, default=4096)
 ap.add_argument("--minibatch", type=int, default=32768)
 ap.add_argument("--epochs", type=int, default=3)
+ap.add_argument("--force-dist", action="store_true", help="create the nccl group and all-reduce the gradients even with ONE rank (the RCCL path on a one-GPU box)")
 args = ap.parse_args()
-dev = torch.device("cuda", 0)
+# data-parallel learners, one rank per GPU (the reference's multi_gpu mode, train.py:117-120): launched by torch.distributed.run, each rank owns num_envs envs
+# and its own learner; the gradients are averaged over the ranks before every optimizer step (native learner: one all-reduce per layer beside the backward)
+import torch.distributed as dist  # noqa: E402
+from isaacgym_amd import distributed as D  # noqa: E402
+rank, local_rank, world = D.rank_info()
+dev = torch.device("cuda", local_rank)
+torch.cuda.set_device(dev)
+use_dist = world > 1 or args.force_dist
+if use_dist:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 n, H, A, NOBS = args.num_envs, 32, 27, 313
 MINI_EPOCHS, E_CLIP, CRITIC_COEF, BOUNDS_COEF, GRAD_NORM, LR = 5, 0.2, 4.0, 1e-4, 10.0, 2e-5     # yaml:60-85
 torch.manual_seed(0)
@@ -48,7 +59,7 @@ def mlp(n_out):
 
 
 actor, critic = mlp(A), mlp(1)
-env = TAEnv(n, device=dev, seed=0)
+env = TAEnv(n, device=dev, seed=0, env_id_offset=rank * n)
 native = NativeActorCritic(actor, critic, NOBS, dev, normalize_input=True)          # serves the rollout in both modes
 logstd = torch.nn.Parameter(torch.zeros(A, device=dev))                             # fixed_sigma: a learnable, observation-independent log-std (yaml:21-27)
 col = RolloutCollector(env, native.learner.net, horizon=H, sigma=torch.exp(logstd.detach()))
@@ -74,6 +85,8 @@ else:
     params = list(native.parameters()) + [logstd]
     params = [p for p in params if p.requires_grad]
     net_forward = native
+    if use_dist:
+        native.grad_sync = D.GradientBuckets(force=args.force_dist)
 opt = torch.optim.Adam(params, lr=LR, eps=1e-8, fused=True)
 scale = 1024.0          # a constant loss scale (GradScaler's job in rl_games): fp16 gradients inside the network either way
 
@@ -105,6 +118,14 @@ def learn():
             loss = a_loss.mean() + 0.5 * CRITIC_COEF * c_loss.mean() + BOUNDS_COEF * b_loss.mean()
             opt.zero_grad(set_to_none=True)
             (loss * scale).backward()
+            if use_dist:          # what the native learner has not already averaged inside its backward: everything (torch learner) or the log-std alone
+                rest = [p.grad for p in params if p.grad is not None] if args.learner == "torch" else [logstd.grad]
+                flat = torch.cat([g.reshape(-1) for g in rest])
+                dist.all_reduce(flat)
+                flat.div_(world)
+                off = 0
+                for g in rest:
+                    g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
             for p in params:
                 if p.grad is not None:
                     p.grad.div_(scale)
@@ -142,9 +163,18 @@ for _ in range(args.epochs):
     dt, (steps, last_loss) = timed(learn)
     learn_s += dt
 roll_ms, learn_ms = roll_s / args.epochs * 1e3, learn_s / args.epochs * 1e3
-print(json.dumps({
+if use_dist:
+    t = torch.tensor([roll_ms, learn_ms], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    roll_ms, learn_ms = float(t[0]), float(t[1])
+if rank == 0:
+  print(json.dumps({
     "what": "one PPO epoch of BASELINE config 5's per-GPU slice (27-dof task, rl_games a2c_continuous settings of cfg/train/HumanoidPingpongTiltG1PPO.yaml), context only",
     "learner": args.learner, "num_envs": n, "horizon": H, "minibatch_rows": args.minibatch, "mini_epochs": MINI_EPOCHS, "minibatch_steps_per_epoch": steps,
     "ms_rollout_per_epoch": roll_ms, "ms_learning_per_epoch": learn_ms, "ms_per_minibatch_step": learn_ms / steps,
-    "env_steps_per_s_end_to_end": n * H / ((roll_ms + learn_ms) * 1e-3), "last_loss": last_loss,
+    "ranks": world, "gradient_all_reduce": ("RCCL, one bucket per layer beside the backward" if args.learner == "native" else "RCCL, one flat bucket after the backward") if use_dist else "none (one rank)",
+    "env_steps_per_s_end_to_end": world * n * H / ((roll_ms + learn_ms) * 1e-3), "last_loss": last_loss,
     "finite": bool(all(torch.isfinite(p).all() for p in params))}))
+if use_dist:
+    dist.barrier()
+    dist.destroy_process_group()
