@@ -121,6 +121,14 @@ int ppenv_mlp_bias_grad_f32(const float* dz, int32_t m, int32_t n, int32_t ld, v
 int ppenv_mlp_cast_weights(const float* w32, int32_t n, int32_t k, int32_t ldw32, uint16_t* w16, int32_t ldw16, uint16_t* wt16, int32_t ldwt16,
                            int32_t wt_rows, void* stream);
 
+/* The same for up to 32 matrices in ONE launch (a whole network: its weight matrices, and its bias vectors as 1-row matrices). */
+typedef struct ppenv_mlp_cast {
+    const float* w32;   int32_t n, k, ldw32;
+    uint16_t* w16;      int32_t ldw16;            /* NULL: not wanted */
+    uint16_t* wt16;     int32_t ldwt16, wt_rows;  /* NULL: not wanted */
+} ppenv_mlp_cast;
+int ppenv_mlp_cast_weights_batch(const ppenv_mlp_cast* items, int32_t count, void* stream);
+
 /* rl_games' RunningMeanStd in training mode (normalize_input, yaml:51) on one batch obs [m, k] fp32: batch mean and unbiased batch
  * variance per column merged into the running float64 (mean, var, count) by the parallel-moments rule; also writes the fp32 mean and
  * 1 / sqrt(var + eps) that ppenv_mlp_prepare_input reads (either may be NULL).  One launch, one pass over obs.  workspace:

@@ -295,10 +295,9 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
 
 // fp32 master weights [n, k] -> the two fp16 operand images: w16 [n, ldw] (the forward's and dW's layout, rows zero-padded to ldw) and
 // wt16 [k_pad, ldwt] = its transpose (dX's operand: K-contiguous for the product over n), zero beyond n / k.  32 x 32 tiles through LDS.
-__global__ __launch_bounds__(256) void cast_weights_kernel(const float* __restrict__ w32, int n, int k, int ldw32, _Float16* __restrict__ w16, int ldw,
-                                                           _Float16* __restrict__ wt16, int ldwt, int kpad, int npad) {
-    __shared__ float t[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+__device__ __forceinline__ void cast_tile(const float* __restrict__ w32, int n, int k, int ldw32, _Float16* __restrict__ w16, int ldw, _Float16* __restrict__ wt16, int ldwt,
+                                          int kpad, int npad, int bx, int by, float (*t)[33]) {
+    const int c0 = bx * 32, r0 = by * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
@@ -314,6 +313,29 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(const float* __restri
             if (kk < kpad && nn < npad && nn < ldwt) wt16[(size_t)kk * ldwt + nn] = (_Float16)t[tx][ty + 8 * i];
         }
     }
+}
+__global__ __launch_bounds__(256) void cast_weights_kernel(const float* __restrict__ w32, int n, int k, int ldw32, _Float16* __restrict__ w16, int ldw,
+                                                           _Float16* __restrict__ wt16, int ldwt, int kpad, int npad) {
+    __shared__ float t[32][33];
+    cast_tile(w32, n, k, ldw32, w16, ldw, wt16, ldwt, kpad, npad, blockIdx.x, blockIdx.y, t);
+}
+// every matrix of the network in ONE launch (the per-optimizer-step cast: 13 weight matrices and 7 bias vectors were 13 launches + 9 copies): the items and the
+// prefix sums of their 32 x 32 tile counts travel by value in the kernel argument; a workgroup finds its item by a scan of at most 32 entries
+constexpr int kCastMax = 32;
+struct CastBatch {
+    int count;
+    int tile_off[kCastMax + 1];
+    int tiles_x[kCastMax];
+    ppenv_mlp_cast it[kCastMax];
+};
+__global__ __launch_bounds__(256) void cast_weights_batch_kernel(const CastBatch b) {
+    __shared__ float t[32][33];
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.tile_off[i + 1]) i++;
+    const ppenv_mlp_cast& c = b.it[i];
+    const int local = (int)blockIdx.x - b.tile_off[i];
+    cast_tile(c.w32, c.n, c.k, c.ldw32, reinterpret_cast<_Float16*>(c.w16), c.ldw16, reinterpret_cast<_Float16*>(c.wt16), c.ldwt16, c.wt_rows, c.ldwt16,
+              local % b.tiles_x[i], local / b.tiles_x[i], t);
 }
 
 // rl_games' RunningMeanStd in training mode on one batch of observations [m, k] (fp32): per column the batch mean and the UNBIASED batch
@@ -359,8 +381,17 @@ __global__ __launch_bounds__(256) void rms_update_kernel(const float* __restrict
     __threadfence();
     // this chunk's row blocks, rows rc, rc + 4, ... per thread, then the four classes in order
     s = 0.0; s2 = 0.0;
-    if (col)
-        for (int b = rc; b < nrb; b += 4) { s += partial[((size_t)b * 2 + 0) * k + c]; s2 += partial[((size_t)b * 2 + 1) * k + c]; }
+    if (col) {
+        int b = rc;
+        for (; b + 28 < nrb; b += 32) {                 // eight row blocks' partials in flight (a plain loop is one dependent round trip per block)
+            double v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { v[u] = partial[((size_t)(b + 4 * u) * 2 + 0) * k + c]; w[u] = partial[((size_t)(b + 4 * u) * 2 + 1) * k + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { s += v[u]; s2 += w[u]; }
+        }
+        for (; b < nrb; b += 4) { s += partial[((size_t)b * 2 + 0) * k + c]; s2 += partial[((size_t)b * 2 + 1) * k + c]; }
+    }
     __syncthreads();
     red[0][rc][cx] = s; red[1][rc][cx] = s2;
     __syncthreads();
@@ -495,6 +526,30 @@ extern "C" int ppenv_mlp_cast_weights(const float* w32, int32_t n, int32_t k, in
     hipLaunchKernelGGL(cast_weights_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, w32, n, k, ldw32,
                        reinterpret_cast<_Float16*>(w16), ldw16, reinterpret_cast<_Float16*>(wt16), ldwt16, wt_rows, ldwt16);
     if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching cast_weights_kernel failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
+
+extern "C" int ppenv_mlp_cast_weights_batch(const ppenv_mlp_cast* items, int32_t count, void* stream) {
+    if (!items || count <= 0 || count > kCastMax) { ppenv_set_error("ppenv_mlp_cast_weights_batch: NULL items or count outside 1 .. 32"); return PPENV_EINVAL; }
+    CastBatch b;
+    b.count = count;
+    int off = 0;
+    for (int i = 0; i < count; i++) {
+        const ppenv_mlp_cast& c = items[i];
+        if (!c.w32 || (!c.w16 && !c.wt16) || c.n <= 0 || c.k <= 0 || c.ldw32 < c.k || (c.w16 && c.ldw16 < c.k) || (c.wt16 && (c.ldwt16 < c.n || c.wt_rows < c.k))) {
+            ppenv_set_error("ppenv_mlp_cast_weights_batch: an item has a NULL pointer or inconsistent sizes (as ppenv_mlp_cast_weights)");
+            return PPENV_EINVAL;
+        }
+        const int cols = c.w16 ? (c.ldw16 > c.wt_rows ? c.ldw16 : c.wt_rows) : c.wt_rows, rows = c.wt16 ? (c.ldwt16 > c.n ? c.ldwt16 : c.n) : c.n;
+        b.it[i] = c;
+        if (!c.wt16) { b.it[i].wt_rows = 0; b.it[i].ldwt16 = 0; }
+        b.tiles_x[i] = (cols + 31) / 32;
+        b.tile_off[i] = off;
+        off += b.tiles_x[i] * ((rows + 31) / 32);
+    }
+    b.tile_off[count] = off;
+    hipLaunchKernelGGL(cast_weights_batch_kernel, dim3(off), dim3(256), 0, (hipStream_t)stream, b);
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching cast_weights_batch_kernel failed"); return PPENV_EHIP; }
     return PPENV_OK;
 }
 

@@ -41,6 +41,13 @@ class MLPDw(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class MLPCast(C.Structure):
+    """ctypes mirror of ppenv_mlp_cast (include/ppenv_policy.h)."""
+    _fields_ = [("w32", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32), ("ldw32", C.c_int32),
+                ("w16", C.c_void_p), ("ldw16", C.c_int32),
+                ("wt16", C.c_void_p), ("ldwt16", C.c_int32), ("wt_rows", C.c_int32)]
+
+
 def _lib_policy():
     L = _lib.lib()
     if getattr(L, "_policy_bound", False):
@@ -55,6 +62,7 @@ def _lib_policy():
     L.ppenv_mlp_bias_grad_workspace_bytes.argtypes = [i32, i32]
     L.ppenv_mlp_bias_grad_f32.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp]
     L.ppenv_mlp_cast_weights.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, vp]
+    L.ppenv_mlp_cast_weights_batch.argtypes = [C.POINTER(MLPCast), i32, vp]
     L.ppenv_running_mean_std_workspace_bytes.restype = C.c_size_t
     L.ppenv_running_mean_std_workspace_bytes.argtypes = [i32, i32]
     L.ppenv_running_mean_std_update.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.c_float, vp, vp]
@@ -187,6 +195,21 @@ def cast_weights(w32, w16=None, wt16=None):
     n, k = w32.shape
     _lib.check(_lib_policy().ppenv_mlp_cast_weights(w32.data_ptr(), n, k, w32.stride(0), _ptr(w16), w16.stride(0) if w16 is not None else 0,
                                                     _ptr(wt16), wt16.stride(0) if wt16 is not None else 0, wt16.shape[0] if wt16 is not None else 0, _stream(w32)))
+
+
+def cast_item(w32, w16=None, wt16=None):
+    """One entry of a cast_weights_batch list (the tensors must stay alive and in place: the entry holds their addresses)."""
+    it = MLPCast()
+    it.w32, it.n, it.k, it.ldw32 = w32.data_ptr(), w32.shape[0], w32.shape[1], w32.stride(0)
+    it.w16, it.ldw16 = _ptr(w16), (w16.stride(0) if w16 is not None else 0)
+    it.wt16, it.ldwt16, it.wt_rows = _ptr(wt16), (wt16.stride(0) if wt16 is not None else 0), (wt16.shape[0] if wt16 is not None else 0)
+    return it
+
+
+def cast_weights_batch(items, stream_of):
+    """ppenv_mlp_cast_weights_batch: every matrix in `items` (cast_item entries, at most 32) in one launch."""
+    arr = (MLPCast * len(items))(*items)
+    _lib.check(_lib_policy().ppenv_mlp_cast_weights_batch(arr, len(items), _stream(stream_of)))
 
 
 class RunningMeanStd:
@@ -363,6 +386,7 @@ class NativeMLPLearner:
         self.grads = dict(w=[z32(*w.shape) for w in net.w], b=[z32(2, n) for n in u], head_w=z32(self.nh, 2 * u[-1]), head_b=z32(na + 1))
         self._rows = 0
         self.rms = None
+        self._cast_items = None
         self.sync_weights()
 
     def parameters(self):
@@ -375,16 +399,22 @@ class NativeMLPLearner:
                 [g["head_w"][:na, :u[-1]], g["head_b"][:na], g["head_w"][na:na + 1, u[-1]:], g["head_b"][na:]])
 
     def sync_weights(self):
-        """fp32 masters -> the fp16 operand images of the forward (w, zero-padded rows) and of dX (wt, transposed)."""
+        """fp32 masters -> the fp16 operand images of the forward (w, zero-padded rows) and of dX (wt, transposed), and the fp16 biases: ONE launch for the
+        whole network (ppenv_mlp_cast_weights_batch; the heads' block-diagonal master image is refreshed by two small copies first)."""
         net, u, na = self.net, self.net.units, self.net.num_actions
-        for i in range(len(u)):
-            for j in range(2):
-                cast_weights(self.w32[i][j], net.w[i][j], self.wt[i][j] if i else None)
-            net.b[i].copy_(self.b32[i])
+        if getattr(self, "_cast_items", None) is None:
+            items = []
+            for i in range(len(u)):
+                for j in range(2):
+                    items.append(cast_item(self.w32[i][j], net.w[i][j], self.wt[i][j] if i else None))
+                items.append(cast_item(self.b32[i].view(1, -1), net.b[i].view(1, -1)))          # a bias vector = a one-row matrix
+            items.append(cast_item(self.head_w32, net.head_w, self.head_wt))
+            items.append(cast_item(self.mu_b.view(1, -1), net.head_b[:na].view(1, -1)))
+            items.append(cast_item(self.value_b.view(1, -1), net.head_b[na:].view(1, -1)))
+            self._cast_items = items
         self.head_w32[:na, :u[-1]] = self.mu_w
         self.head_w32[na:, u[-1]:] = self.value_w
-        cast_weights(self.head_w32, net.head_w, self.head_wt)
-        net.head_b.copy_(torch.cat([self.mu_b, self.value_b]))
+        cast_weights_batch(self._cast_items, self.head_w32)
 
     def _alloc(self, m):
         u, dev = self.net.units, self.device

@@ -39,6 +39,7 @@ def test_backward_entry_points_reject_bad_arguments_before_any_device_call():
     assert L.ppenv_mlp_layer_backward_input(C.byref(g), None, 0, 0, None, 0, 0, None) == -1 and b"bias NULL, elu 0" in L.ppenv_last_error()
     assert L.ppenv_mlp_reduce_rows(None, 1, 1, 1, None, 0, None) == -1
     assert L.ppenv_mlp_cast_weights(None, 1, 1, 1, None, 0, None, 0, 0, None) == -1
+    assert L.ppenv_mlp_cast_weights_batch(None, 0, None) == -1
     assert L.ppenv_running_mean_std_update(None, 1, 1, 1, None, None, None, None, None, 1e-5, None, None) == -1
     assert L.ppenv_running_mean_std_workspace_bytes(1000, 313) == 1024 + 8 * 2 * 313 * 8
     with pytest.raises(_lib.PPEnvError):
@@ -127,6 +128,15 @@ def test_cast_weights_bias_grad_and_reduce_rows():
     assert torch.equal(wt16.cpu(), want_t)
     cast_weights(w.cuda(), None, wt16)                            # either image alone
     assert torch.equal(wt16.cpu(), want_t)
+    # the whole-network form: several matrices (and a bias as a one-row matrix) in one launch
+    from isaacgym_amd.policy import cast_item, cast_weights_batch
+    w2, bias = torch.randn(70, 64, generator=gen).cuda(), torch.randn(1, 300, generator=gen).cuda()
+    wd = w.cuda()
+    o16, ot16 = torch.full((150, 320), float("nan"), dtype=torch.float16, device="cuda"), torch.full((320, 152), float("nan"), dtype=torch.float16, device="cuda")
+    o2, b16 = torch.full((70, 64), float("nan"), dtype=torch.float16, device="cuda"), torch.full((1, 300), float("nan"), dtype=torch.float16, device="cuda")
+    cast_weights_batch([cast_item(wd, o16, ot16), cast_item(w2, o2), cast_item(bias, b16)], wd)
+    assert torch.equal(o16.cpu(), want) and torch.equal(ot16.cpu(), want_t)
+    assert torch.equal(o2, w2.to(torch.float16)) and torch.equal(b16, bias.to(torch.float16))
     d = torch.randint(-8, 9, (5000, 28), generator=gen).float()
     out = torch.full((28,), 3.0, device="cuda")
     bias_grad_f32(out, d.cuda())
