@@ -495,6 +495,18 @@ constexpr bool geo_owners_ok() {   // every shape, the paddle and the bound cent
 }
 static_assert(geo_owners_ok(), "collision shapes must ride on the pelvis, the waist chain or the right arm");
 
+// How the full-workgroup flush leaves the CU (profiling builds: -DTA_FLUSH_MODE=0 plain stores; 1 = non-temporal, the default)
+#ifndef TA_FLUSH_MODE
+#define TA_FLUSH_MODE 1
+#endif
+template <class V>
+__device__ __forceinline__ void flush_store(V v, V* p) {
+#if TA_FLUSH_MODE == 1
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 // flat copies between an [rows][64] SoA tile and the workgroup's contiguous block of a row-major [N, W] tensor
 template <int W>
 __device__ __forceinline__ void tile_in(float (*tile)[kE], const float* __restrict__ src, int nvalid, int tid) {
@@ -555,14 +567,16 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         for (int it = 0; it < tA; it++) { const int i = it * kThreads + tid; va[it] = i < nA ? sa[i] : f4v{0, 0, 0, 0}; }
 #pragma unroll
         for (int it = 0; it < tR; it++) { const int i = it * kThreads + tid; vr[it] = i < nR ? sr[i] : f4v{0, 0, 0, 0}; }
+        // (one division per float4, then a running (env, column) pair: the four divisions per vector were a third of the staging's instructions)
 #pragma unroll
         for (int it = 0; it < tD; it++) {
             const int i = it * kThreads + tid;
             if (i < nD) {
+                int ee = (4 * i) / (2 * NDOF), c = 4 * i - ee * 2 * NDOF;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int t = 4 * i + k, ee = t / (2 * NDOF), c = t - ee * 2 * NDOF;
                     if (c & 1) S.qd[c >> 1][ee] = vd[it][k]; else S.q[c >> 1][ee] = vd[it][k];
+                    if (++c == 2 * NDOF) { c = 0; ee++; }
                 }
             }
         }
@@ -570,10 +584,11 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         for (int it = 0; it < tA; it++) {
             const int i = it * kThreads + tid;
             if (i < nA) {
+                int ee = (4 * i) / NDOF, d = 4 * i - ee * NDOF;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int t = 4 * i + k, ee = t / NDOF, d = t - ee * NDOF;
                     S.act_frc[d][ee] = va[it][k];   // raw: Limb::load maps it to the PD target
+                    if (++d == NDOF) { d = 0; ee++; }
                 }
             }
         }
@@ -581,8 +596,12 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         for (int it = 0; it < tR; it++) {
             const int i = it * kThreads + tid;
             if (i < nR) {
+                int ee = (4 * i) / 39, c = 4 * i - ee * 39;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { const int t = 4 * i + k, ee = t / 39, c = t - ee * 39; S.root[c][ee] = vr[it][k]; }
+                for (int k = 0; k < 4; k++) {
+                    S.root[c][ee] = vr[it][k];
+                    if (++c == 39) { c = 0; ee++; }
+                }
             }
         }
     } else {
@@ -988,7 +1007,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
 #pragma unroll 7
             for (int it = 0; it < tO; it++) {
                 const int i = it * kThreads + tid;
-                if (i < nO) __builtin_nontemporal_store(reinterpret_cast<const f4v*>(S.u.obs)[i], reinterpret_cast<f4v*>(dobs) + i);
+                if (i < nO) flush_store(reinterpret_cast<const f4v*>(S.u.obs)[i], reinterpret_cast<f4v*>(dobs) + i);
             }
             f4v* dd = reinterpret_cast<f4v*>(a.dof_states + (size_t)e0 * 2 * NDOF);
 #pragma unroll
@@ -996,9 +1015,10 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                 const int i = it * kThreads + tid;
                 if (i < nD) {
                     f4v v;
+                    int ee = (4 * i) / (2 * NDOF), c = 4 * i - ee * 2 * NDOF;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { const int t = 4 * i + k, ee = t / (2 * NDOF), c = t - ee * 2 * NDOF; v[k] = (c & 1) ? S.qd[c >> 1][ee] : S.q[c >> 1][ee]; }
-                    __builtin_nontemporal_store(v, dd + i);
+                    for (int k = 0; k < 4; k++) { v[k] = (c & 1) ? S.qd[c >> 1][ee] : S.q[c >> 1][ee]; if (++c == 2 * NDOF) { c = 0; ee++; } }
+                    flush_store(v, dd + i);
                 }
             }
             f4v* df = reinterpret_cast<f4v*>(a.dof_force + (size_t)e0 * NDOF);
@@ -1007,9 +1027,10 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                 const int i = it * kThreads + tid;
                 if (i < nF) {
                     f4v v;
+                    int ee = (4 * i) / NDOF, d = 4 * i - ee * NDOF;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { const int t = 4 * i + k, ee = t / NDOF, d = t - ee * NDOF; v[k] = S.act_frc[d][ee]; }
-                    __builtin_nontemporal_store(v, df + i);
+                    for (int k = 0; k < 4; k++) { v[k] = S.act_frc[d][ee]; if (++d == NDOF) { d = 0; ee++; } }
+                    flush_store(v, df + i);
                 }
             }
             f4v* dr = reinterpret_cast<f4v*>(a.root_states + (size_t)e0 * 39);
@@ -1018,9 +1039,10 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                 const int i = it * kThreads + tid;
                 if (i < nR) {
                     f4v v;
+                    int ee = (4 * i) / 39, c = 4 * i - ee * 39;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { const int t = 4 * i + k, ee = t / 39, c = t - ee * 39; v[k] = S.root[c][ee]; }
-                    __builtin_nontemporal_store(v, dr + i);
+                    for (int k = 0; k < 4; k++) { v[k] = S.root[c][ee]; if (++c == 39) { c = 0; ee++; } }
+                    flush_store(v, dr + i);
                 }
             }
             if (a.pin_out) {
