@@ -299,7 +299,8 @@ typedef struct ppenv_randomization {
     float observation_noise_sigma;      /* 0 = off */
 } ppenv_randomization;
 /* The tables are NOT copied: they must stay valid (and may be rewritten in place between steps) until the randomisation is replaced or
- * cleared.  3-actor variants only. */
+ * cleared.  The 4-actor variant takes the same [7][N] tables: an env's entries apply to both of its humanoids (two instances of the yaml's one
+ * "humanoid" actor); its 14 action draws and its two agents' observation rows have noise indices of their own. */
 int ppenv_set_randomization(struct ppenv* env, const ppenv_randomization* dr /* NULL: off */);
 /* sim_params.gravity of the whole simulation (yaml:83,114-120; the task's own override is -9.8, TT:329-331). */
 int ppenv_set_gravity(struct ppenv* env, float gravity_z);

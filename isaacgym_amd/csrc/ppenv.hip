@@ -130,7 +130,8 @@ struct NoisyRowStore {
     float sigma;
     uint64_t seed;
     uint32_t gid, episode, progress;
-    __device__ __forceinline__ void operator()(int k, float v) { row[k] = v + sigma * dr_gauss(seed, gid, episode, progress, 16u + (uint32_t)k); }
+    uint32_t base = 16u;      // first noise index of this row: 16 for the one agent of the 3-actor variants, 16 + 80 a for agent a of the 4-actor one
+    __device__ __forceinline__ void operator()(int k, float v) { row[k] = v + sigma * dr_gauss(seed, gid, episode, progress, base + (uint32_t)k); }
 };
 // device pointers of the randomisation tables (ppenv_randomization), by value in the kernel argument
 struct DRTables {
@@ -348,7 +349,7 @@ template <class T, int A, int G, int BW = 1, bool DR = false>
 __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const StepConsts K, DevBuffers b, const float* __restrict__ actions, int serve_on,
                                                                        uint32_t* status, int dbg_drop_handoff, const DRTables drt = DRTables{}) {
     static_assert(BW == 1 || G == 0, "narrow ball waves: each sweeps its own geometry (the s_bflag slot protocol has one consumer)");
-    static_assert(!DR || A == 1, "the randomisation tables are [7][N]: one humanoid");
+    // (DR with two humanoids: both are instances of the yaml's one "humanoid" actor — an env's [7][N] table entries apply to both arms)
     constexpr int kGeo = MovingGeom<T>::count();
     // Who writes dof_pos / dof_vel / dof_force.  With one humanoid the arm wave is the critical path and would sit waiting
     // for the ball wave's reset decision just to pick between q and the initial pose: the ball wave, which has both, stores
@@ -406,7 +407,7 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
                 qd[d] = b.dof_vel[(size_t)(arm * ND + d) * n + i];
                 tau[d] = 0.f;
                 float act = actions[((size_t)i * A + arm) * ND + d];
-                if (DR) { if (dr.act_sigma > 0.f) act += dr.act_sigma * dr_gauss(K.seed, (uint32_t)(K.env_id_offset + i), dr_ep0, dr.key_progress, (uint32_t)d); }   // as simulate_env: before the clamp
+                if (DR) { if (dr.act_sigma > 0.f) act += dr.act_sigma * dr_gauss(K.seed, (uint32_t)(K.env_id_offset + i), dr_ep0, dr.key_progress, (uint32_t)(arm * ND + d)); }   // as simulate_env: before the clamp
                 target[d] = pd_target(act, T::drive(d).lower, T::drive(d).upper, K.clip_actions);   // VecTask.step clamp + TT:1008
             }
         }
@@ -465,7 +466,8 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
 #pragma unroll
             for (int j = 0; j < NB; j++) { bpos[j] = bodies[j].pos; bvel[j] = bodies[j].lin; }
             LdsRowStore store{&s_obs[(arm * kBlock + lane) * kObsStride]};
-            NoisyRowStore nstore{&s_obs[(arm * kBlock + lane) * kObsStride], dr.obs_sigma, K.seed, (uint32_t)(K.env_id_offset + i), dr_ep0, dr.key_progress};
+            NoisyRowStore nstore{&s_obs[(arm * kBlock + lane) * kObsStride], dr.obs_sigma, K.seed, (uint32_t)(K.env_id_offset + i), dr_ep0, dr.key_progress,
+                                 16u + (uint32_t)(arm * PPENV_NUM_OBS)};
             if (DR && drt.obs_sigma > 0.f) write_obs_bodies(bpos, bvel, S.hinv, nstore);
             else write_obs_bodies(bpos, bvel, S.hinv, store);
         }
@@ -587,7 +589,8 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
         if (DR && drt.obs_sigma > 0.f) {
             NoisyRowStore nstores[A];
 #pragma unroll
-            for (int a = 0; a < A; a++) nstores[a] = NoisyRowStore{stores[a].row, bdr.obs_sigma, K.seed, (uint32_t)(K.env_id_offset + bi), bdr_ep0, bdr.key_progress};
+            for (int a = 0; a < A; a++)
+                nstores[a] = NoisyRowStore{stores[a].row, bdr.obs_sigma, K.seed, (uint32_t)(K.env_id_offset + bi), bdr_ep0, bdr.key_progress, 16u + (uint32_t)(a * PPENV_NUM_OBS)};
             post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + bi), st, bodies, pre_vx, &next_serve, rew, reset, nstores);
         } else
             post_physics_env<A, false>(K, (uint32_t)(K.env_id_offset + bi), st, bodies, pre_vx, &next_serve, rew, reset, stores);
@@ -1426,7 +1429,10 @@ static int launch_step(ppenv* e, const DevBuffers& buf, const float* actions_dev
     if (int rc = check_status(e)) return rc;
     if (int rc = use_device(e)) return rc;
     if (e->dr_on) {   // domain randomisation: the table-reading instantiation — of the two-wave schedule (default) or of the one-wave kernel (PPENV_STEP_KERNEL=fused)
-        if (e->split)
+        if (e->agents == 2)
+            hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1, 1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, buf,
+                               actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff, e->dr);
+        else if (e->split)
             hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, buf,
                                actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff, e->dr);
         else
@@ -1491,7 +1497,6 @@ uint32_t ppenv_status(ppenv* e) { return e ? *(volatile uint32_t*)e->status_host
 int ppenv_set_randomization(ppenv* e, const ppenv_randomization* dr) {
     if (!e) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (!dr) { e->dr_on = 0; e->dr = DRTables{}; return PPENV_OK; }
-    if (e->agents != 1) { set_err("domain randomisation is wired for the 3-actor variants (no reference yaml randomises the 4-actor task)"); return PPENV_EINVAL; }
     if (!(dr->action_noise_sigma >= 0.f) || !(dr->observation_noise_sigma >= 0.f)) { set_err("noise amplitudes must be >= 0"); return PPENV_EINVAL; }
     e->dr = DRTables{dr->dof_stiffness_scale, dr->dof_damping_scale, dr->link_mass_scale, dr->restitution_scale, dr->friction_scale,
                      dr->action_noise_sigma, dr->observation_noise_sigma};

@@ -738,7 +738,8 @@ int ppo_set_randomization(ppo_env* e, const float* kp_scale, const float* kd_sca
     e->cfg_env = NULL;
     e->dr_action_sigma = e->dr_obs_sigma = 0.f;
     if (!on) return 0;
-    if (e->A != 1) return -1;
+    /* two humanoids (the 4-actor variant): both are instances of the one "humanoid" actor of the yaml's randomization_params, so an env's table entries
+     * apply to both of its arms and to both shape sets */
     e->dr_action_sigma = action_sigma; e->dr_obs_sigma = obs_sigma;
     if (!kp_scale && !kd_scale && !mass_scale && !e_scale && !mu_scale) return 0;
     int n = e->n;
@@ -759,6 +760,8 @@ int ppo_set_randomization(ppo_env* e, const float* kp_scale, const float* kd_sca
         float es = e_scale ? e_scale[i] : 1.f, fs = mu_scale ? mu_scale[i] : 1.f;
         c->paddle_restitution = fminf(c->paddle_restitution * es, c->restitution_max); c->paddle_friction *= fs;
         for (int s = 0; s < c->num_shapes; s++) { c->shape[s].restitution = fminf(c->shape[s].restitution * es, c->restitution_max); c->shape[s].friction *= fs; }
+        if (e->A == 2)
+            for (int s = 0; s < c->num_shapes; s++) { c->shape2[s].restitution = fminf(c->shape2[s].restitution * es, c->restitution_max); c->shape2[s].friction *= fs; }
     }
     return 0;
 }
@@ -1301,15 +1304,18 @@ void ppo_t4_rewards(const ppenv_t4_params* p, const float* rb_states, const floa
  * build's completion (include/ppenv.h, PPENV_VARIANT_T4).  Like the class's call site (T4:746-747), both reward
  * functions receive the whole 14-dof force / velocity tensors. */
 static void step_env_t4(ppo_env* e, int i, const float* actions) {
-    const ppenv_config* c = &e->cfg;
+    const ppenv_config* c = e->cfg_env ? &e->cfg_env[i] : &e->cfg;      /* domain randomisation: this env's own scaled model (both humanoids) */
     const int n = e->n;
     float qf[2 * ND], qdf[2 * ND], ballf[13];
     gather_env(e, i, qf, qdf, ballf);
+    const uint32_t dr_gid = (uint32_t)(c->env_id_offset + i), dr_ep = e->episode[i], dr_prog = (uint32_t)e->progress[(size_t)i * 2];
 
     double target[2][ND], q[2][ND], qd[2][ND], tau_drive[2][ND] = {{0}};
     for (int a = 0; a < 2; a++)
         for (int d = 0; d < ND; d++) {
-            target[a][d] = pd_target(actions[((size_t)i * 2 + a) * ND + d], c->joint[d].lower, c->joint[d].upper, c->clip_actions);   /* T4:1014 */
+            float act = actions[((size_t)i * 2 + a) * ND + d];
+            if (e->dr_action_sigma > 0.f) act += e->dr_action_sigma * dr_gauss(c->seed, dr_gid, dr_ep, dr_prog, (uint32_t)(a * ND + d));   /* indices 0 .. 13 */
+            target[a][d] = pd_target(act, c->joint[d].lower, c->joint[d].upper, c->clip_actions);   /* T4:1014 */
             q[a][d] = qf[a * ND + d]; qd[a][d] = qdf[a * ND + d];
         }
     float pre_vx = ballf[7];                                        /* T4:1026 */
@@ -1388,6 +1394,9 @@ static void step_env_t4(ppo_env* e, int i, const float* actions) {
     for (int a = 0; a < 2; a++) {
         e->progress[(size_t)i * 2 + a] = progress; e->flags[(size_t)a * n + i] = flags[a]; e->reset[(size_t)i * 2 + a] = reset;
         compute_obs(bs[a], &qf[a * ND], &qdf[a * ND], ballf, &e->obs[((size_t)i * 2 + a) * PPENV_NUM_OBS]);
+        if (e->dr_obs_sigma > 0.f)       /* agent a's row: indices 16 + 80 a + k (clear of the 14 action draws, < 256) */
+            for (int k = 0; k < PPENV_NUM_OBS; k++)
+                e->obs[((size_t)i * 2 + a) * PPENV_NUM_OBS + k] += e->dr_obs_sigma * dr_gauss(c->seed, dr_gid, dr_ep, dr_prog, 16u + (uint32_t)(a * PPENV_NUM_OBS + k));
     }
     e->rew[(size_t)i * 2] = rew1; e->rew[(size_t)i * 2 + 1] = rew2;
 }

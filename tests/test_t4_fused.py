@@ -248,3 +248,56 @@ def test_t4_vec_task_surface(torch_cuda):
     assert task.body_states.shape == (n, 82, 13) and task.humanoid2_paddle_rb_states.shape == (n, 13)
     assert task.reward_calculated.shape == (2, n)
     assert torch.equal(task.progress_buf[0::2], task.progress_buf[1::2])
+
+
+@pytest.mark.gpu
+def test_t4_fused_step_with_randomisation_matches_oracle(torch_cuda, oracle_lib):
+    """Domain randomisation on the 4-actor task (round 3): an env's [7][N] table entries apply to both humanoids (two instances of the yaml's one "humanoid"
+    actor), the 14 action draws and the two agents' observation rows have their own noise indices — the three-wave table-reading kernel against the oracle,
+    restarted from the oracle's state every step; cleared, the plain kernel runs again bit for bit."""
+    torch = torch_cuda
+    from isaacgym_amd.env import PPEnv
+    n = 512
+    cfg = scene.build_config("T4", num_envs=n, seed=9)
+    o = oracle_lib.OracleEnv(cfg, threads=8)
+    env = PPEnv(scene.build_config("T4", num_envs=n, seed=9), device="cuda:0")
+    ref = PPEnv(scene.build_config("T4", num_envs=n, seed=9), device="cuda:0")
+    rng = np.random.default_rng(3)
+    u = lambda lo, hi, shape: rng.uniform(lo, hi, shape).astype(np.float32)
+    tabs = dict(dof_stiffness_scale=u(0.5, 1.5, (7, n)), dof_damping_scale=u(0.5, 1.5, (7, n)), link_mass_scale=u(0.5, 1.5, (7, n)),
+                restitution_scale=u(0.0, 0.7, n), friction_scale=u(0.7, 1.3, n))
+    kw = dict(action_noise_sigma=0.02, observation_noise_sigma=0.002)
+    probe = SensitivityProbe(oracle_lib, cfg)
+    for x in (o, probe.o2, env):
+        x.set_randomization(**tabs, **kw)
+    oa, ra = obs_atol() + 2e-6, 2 * reward_atol(cfg)
+    log = ExclusionLog("gpu 4-actor step with domain randomisation vs oracle", bound=0.01)
+    resets, moved = 0, 0.0
+    for t in range(120):
+        actions = rng.uniform(-1.2, 1.2, (2 * n, 7)).astype(np.float32)
+        st = o.get_state()
+        env.set_state(st)
+        if t == 5:
+            ref.set_state(st)
+            ref.step(torch.from_numpy(actions).cuda())
+        o.step(actions)
+        env.step(torch.from_numpy(actions).cuda())
+        if t == 5:
+            moved = float((ref.dof_vel - env.dof_vel).abs().max())
+        keep = ~probe.sensitive(st, actions, o)
+        log.add(keep)
+        _check_step(mask_envs(DevView(env), keep, 2), mask_envs(o, keep, 2), t, oa, ra)
+        resets += int(o.reset_buf.sum())
+    log.close()
+    assert resets > 30 and moved > 1e-2
+    # the two agents of an env do not share their observation noise
+    g = env.obs_buf.cpu().numpy().reshape(n, 2, 80)
+    assert np.abs(g[:, 0, 60:67] - g[:, 1, 60:67]).max() > 1e-4
+    env.clear_randomization()
+    st = o.get_state()
+    env.set_state(st); ref.set_state(st)
+    a = torch.from_numpy(actions).cuda()
+    env.step(a); ref.step(a)
+    for name in ("obs_buf", "rew_buf", "dof_pos", "dof_vel", "ball"):
+        assert torch.equal(getattr(env, name), getattr(ref, name)), name
+    env.close(); ref.close()
