@@ -175,8 +175,51 @@ def pmc_traffic(num_envs, variant=VARIANT):
     return best
 
 
+VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 4    # 256 CUs x 4 SIMDs, one wave-instruction per SIMD every 4 cycles, 2.4 GHz max clock (MI355X_MICROARCH.md)
+
+
+def _pmc_profile(num_envs, variant):
+    """(counters, file) of the newest committed profiles/*_pmc_summary.csv of this variant's step kernel taken at num_envs (the
+    companion *_pmc_traffic.json names the size and the kernel), or (None, None)."""
+    import csv
+    import glob
+    tag = {"T4": "_T4", "TA": "_TA"}.get(variant, "")
+    best = (None, None)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_?{tag}_pmc_traffic.json"))):
+        d = json.load(open(f))
+        summ = f.replace("_pmc_traffic.json", "_pmc_summary.csv")
+        if d.get("num_envs") != num_envs or not os.path.exists(summ):
+            continue
+        if variant not in ("T4", "TA") and ("_T4_" in f or "_TA_" in f):
+            continue
+        c = {row["counter"]: float(row["mean_per_dispatch"]) for row in csv.DictReader(open(summ))}
+        best = (c, os.path.basename(summ))
+    return best
+
+
+def valu_roofline(variant, n, kernel_us):
+    """The ceiling that actually binds these kernels ("dependency-depth bound", not HBM): VALU issue.
+    achieved = SQ_INSTS_VALU per launch (wave-instructions, from the committed rocprofv3 PMC pass of this kernel at this size; bench.py
+    cannot collect counters itself) / the kernel's launch duration measured live here; peak = 1024 SIMDs x one wave-instruction per
+    4 cycles x 2.4 GHz.  wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES of the same pass: the share of a wave's lifetime spent waiting (on a
+    hand-off, a barrier, memory) — the dependency chain.  None when no profile of this kernel at this size is committed."""
+    c, src = _pmc_profile(n, variant)
+    if not c or "SQ_INSTS_VALU" not in c:
+        return None
+    achieved = c["SQ_INSTS_VALU"] / (kernel_us * 1e-6)
+    out = {"bound": "valu_issue", "achieved": achieved / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9, "unit": "G wave-instructions/s",
+           "frac": achieved / VALU_PEAK_WAVE_INSTS_PER_S, "valu_insts_per_launch": c["SQ_INSTS_VALU"], "source": f"profiles/{src}"}
+    if c.get("SQ_WAVE_CYCLES"):
+        out["wait_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        out["valu_busy_frac"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"]
+    if c.get("SQ_WAVES"):
+        out["waves_per_launch"] = c["SQ_WAVES"]
+        out["simd_slots_occupied_frac"] = min(1.0, c["SQ_WAVES"] / 1024.0)
+    return out
+
+
 def kernel_name(variant):
-    """The schedule ppenv_create picks (isaacgym_amd/csrc/ppenv.hip): two waves per 64 envs unless the one-wave kernel is
+    """FALLBACK only (pmc_traffic's file matching, and rows whose handle is gone): the schedule ppenv_create picks (isaacgym_amd/csrc/ppenv.hip): two waves per 64 envs unless the one-wave kernel is
     forced; three waves (two arm waves + the ball wave) for the 4-actor variant."""
     if variant == "T4":
         return "step_kernel_split<ModelG1, 2, 0, 1, false>" if os.environ.get("PPENV_STEP_KERNEL") == "split3" else "step_kernel_split<ModelG1, 2, 1, 1, false>"
@@ -280,6 +323,7 @@ class Workload:
             self.rows, self.num_act, self.num_obs = cnt * self.env.num_agents, 7, 80
         self.pool = [(torch.rand(self.rows, self.num_act, device=device, generator=gen) * 2 - 1).contiguous() for _ in range(8)]
         self.obs_buf = self.env.obs_buf
+        self.kernel = self.env.sim.kernel_name if variant == "TA" else self.env.step_kernel_name    # asked of the handle, not guessed
         self.graphs = {}
         # horizon-major output slices for the gather modes: [depth, HORIZON, rows(, num_obs)]
         self.into = None
@@ -391,14 +435,19 @@ class Workload:
         self.env.close()
 
 
-def hbm_roofline(variant, n, kernel_us, region_us=None, region=None):
+def hbm_roofline(variant, n, kernel_us, region_us=None, region=None, observed_kernel=None):
+    """observed_kernel: what the handle says it launches (ppenv_step_kernel_name / ppenv_ta_sim_kernel_name)."""
     algo = ALGO_BYTES[variant]
     achieved = algo * n / (kernel_us * 1e-6) / 1e9
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "traffic": pmc_traffic(n, variant), "kernel": kernel_name(variant), "avg_kernel_us": kernel_us,
-         "algorithmic_bytes_per_launch": algo * n}
+         "traffic": pmc_traffic(n, variant), "kernel": observed_kernel or kernel_name(variant), "avg_kernel_us": kernel_us,
+         "algorithmic_bytes_per_launch": algo * n,
+         "traffic_source": "committed rocprofv3 --pmc passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE), not a counter read in this run"}
     if region_us is not None:
         r["region_us"], r["region"] = region_us, region
+    sec = valu_roofline(variant, n, kernel_us)
+    if sec is not None:
+        r["secondary"] = sec        # the binding ceiling (VALU issue) beside the formal one (HBM): DESIGN.md §6
     return r
 
 
@@ -565,6 +614,53 @@ def secondary_configs(device, only=None, cpu=True):
     return rows
 
 
+def run_secondary_child(args, timeout_s=420):
+    """secondary_configs() in a child process: `python bench.py --only-config ALL` -> its `configs` list (or one error row)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--only-config", "ALL"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=dict(os.environ))
+        try:
+            stdout, _ = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            proc.kill()                      # exactly the process started above
+            proc.communicate()
+            return [{"error": f"secondary configs: the child process exceeded {timeout_s} s and was killed"}]
+        for line in reversed(stdout.decode(errors="replace").splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)["configs"]
+        return [{"error": f"secondary configs: the child process ended with code {proc.returncode} and no JSON line"}]
+    except Exception as e:   # noqa: BLE001 - the headline line is printed whatever happens to the secondary rows
+        return [{"error": f"{type(e).__name__}: {e}"}]
+
+
+def configs_summary(rows):
+    """name -> the few scalars of each secondary row (flat and short: what the driver's record and a reader's eye keep)."""
+    out = {}
+    for r in rows:
+        name = r.get("name", "error")
+        if "error" in r:
+            out[name] = {"error": r["error"][:120]}
+            continue
+        roof = r.get("roofline", {})
+        e = {"frac": round(roof.get("frac", 0.0), 4), "bound": roof.get("bound")}
+        for k_out, k_in in (("env_steps_per_s", "env_steps_per_s"), ("avg_kernel_us", "avg_kernel_us"), ("us_per_rollout_step", "us_per_rollout_step"),
+                            ("us_policy_forward", "us_policy_forward"), ("us_forward", "us_forward_incl_stats_update"), ("us_backward", "us_backward"),
+                            ("rows_per_s", "rows_per_s_forward_backward")):
+            if r.get(k_in) is not None:
+                e[k_out] = round(r[k_in], 3 if "us" in k_out else 0)
+        sec = roof.get("secondary")
+        if sec:
+            e["valu_issue_frac"], e["wait_frac"] = round(sec["frac"], 4), round(sec.get("wait_frac", 0.0), 3)
+        if roof.get("traffic"):
+            e["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 3)
+        cb = r.get("cpu_baseline", {})
+        if "value" in cb:
+            e["cpu_baseline"] = round(cb["value"], 0)
+        out[name] = e
+    return out
+
+
 def _secondary_row(device, name, cfg_no, variant, n, rollout, rows, cores, cpu):
     """One row of secondary_configs: an env-step config (HBM roofline) or the rollout config (MFMA roofline of its policy forward)."""
     import torch
@@ -577,7 +673,7 @@ def _secondary_row(device, name, cfg_no, variant, n, rollout, rows, cores, cpu):
            "region": "3 x 320 launches after 128 (median)"}
     if not rollout:
         row.update({"avg_kernel_us": us, "env_steps_per_s": n / (us * 1e-6), "agent_steps_per_s": w.rows / (us * 1e-6),
-                    "roofline": hbm_roofline(variant, n, us, regions)})
+                    "roofline": hbm_roofline(variant, n, us, regions, observed_kernel=w.kernel)})
     else:
         fwd_us, _ = w.kernel_region_us(16, 64, 3, fn=w.forward)            # the eight launches of one forward, eager, back to back
         tf = w.policy_flops / (fwd_us * 1e-6) / 1e12
@@ -592,7 +688,7 @@ def _secondary_row(device, name, cfg_no, variant, n, rollout, rows, cores, cpu):
     torch.cuda.empty_cache()
     if cpu:
         try:
-            row["cpu_baseline"] = cpu_baseline_rollout(256, cores) if rollout else cpu_baseline(n, target_seconds=2.5, variant=variant)
+            row["cpu_baseline"] = cpu_baseline_rollout(n, cores, seconds=6.0) if rollout else cpu_baseline(n, target_seconds=2.5, variant=variant)
         except Exception as e:   # noqa: BLE001 - a CPU row must not cost the GPU rows
             row["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     return row
@@ -675,7 +771,7 @@ def main():
     torch.cuda.set_device(device)
 
     if args.only_config:
-        rows = secondary_configs(device, only=set(args.only_config), cpu=not args.no_cpu_baseline)
+        rows = secondary_configs(device, only=None if args.only_config == ["ALL"] else set(args.only_config), cpu=not args.no_cpu_baseline)
         print(json.dumps({"configs": rows}), flush=True)
         return
 
@@ -817,7 +913,8 @@ def main():
     if rank == 0:
         total_env_steps = n * world * args.steps
         if not rollout:
-            roof = hbm_roofline(args.variant, n, kernel_us, region_us, f"{ROOFLINE_REGIONS} x {ROOFLINE_LAUNCHES} launches after {ROOFLINE_WARM} (median)")
+            roof = hbm_roofline(args.variant, n, kernel_us, region_us, f"{ROOFLINE_REGIONS} x {ROOFLINE_LAUNCHES} launches after {ROOFLINE_WARM} (median)",
+                                observed_kernel=w.kernel)
             roof["timed_region_us_per_step"] = dev_ms * 1e3 / args.steps
             metric = "env-steps/sec at N_envs=16384 (1/2/4/8 GPUs) + achieved HBM GB/s vs roofline"
             what = "random U(-1,1) actions, 2 physics substeps per step, fused step kernel"
@@ -859,14 +956,21 @@ def main():
         dist.barrier()
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_rollout(256, usable_cores()) if rollout else cpu_baseline(n, variant=args.variant)
+            out["cpu_baseline"] = cpu_baseline_rollout(n, usable_cores(), seconds=10.0) if rollout else cpu_baseline(n, variant=args.variant)
             if args.variant == VARIANT and not rollout:
                 out["cpu_baseline_rows"] = cpu_baseline_rows(out["cpu_baseline"]["cores"])
         if world == 1 and not args.no_configs and not rollout and args.variant == VARIANT and not gather and dist is None:
-            try:
-                out["configs"] = secondary_configs(device, cpu=not args.no_cpu_baseline)
-            except Exception as e:   # noqa: BLE001 - the headline line is printed whatever happens to the secondary rows
-                out["configs"] = [{"error": f"{type(e).__name__}: {e}"}]
+            # The secondary rows run in a freshly started CHILD process (this script with --only-config), after the headline has been
+            # measured and its env closed: a device fault, abort or hang in one of them (each touches other kernels) can then cost
+            # only that child — it is killed by exact PID at its time limit — never the headline line printed below.
+            out["configs"] = run_secondary_child(args)
+            summary = configs_summary(out["configs"])
+            out["config"]["configs_summary"] = summary          # inside `config`: the driver's record keeps that object's values
+        out["config"]["episode_stats"] = out["episode_stats"]
+        if "secondary" in out["roofline"]:
+            out["roofline_secondary"] = out["roofline"]["secondary"]
+        if "configs" in out:
+            out["configs_summary"] = out["config"]["configs_summary"]     # ... and LAST on the line, so a tail of the output ends with it
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -310,6 +310,11 @@ int ppenv_set_gravity(struct ppenv* env, float gravity_z);
  * PPENV_EDEVICE once it is non-zero. */
 uint32_t ppenv_status(struct ppenv* env);
 
+/* The kernel ppenv_step launches for this handle as it is configured NOW (schedule chosen at create, randomisation state), by the
+ * demangled name rocprofv3's kernel trace prints, e.g. "step_kernel_split<pp::ModelG1, 1, 0, 1, false>".  Host-only, no GPU call; the
+ * string is static.  (No reference counterpart: measurement plumbing — bench.py reports it as roofline.kernel.) */
+const char* ppenv_step_kernel_name(struct ppenv* env);
+
 /* What the reference prints every 40 steps (mean reward, mean progress: TT:763-766) plus the number of
  * finished episodes, as sums over this handle's envs: out_dev[4] (f64) = { sum rew_buf, sum progress_buf,
  * sum episode, num_envs }.  One small reduction launch; the caller all-reduces it across ranks. */
@@ -482,6 +487,8 @@ int ppenv_ta_sim_device(const ppenv_ta_sim* sim);
  * 0 = one lane per env (any tree).  PPENV_TA_KERNEL=chain|quad|lane forces one. */
 uint32_t ppenv_ta_sim_status(const ppenv_ta_sim* sim);
 int ppenv_ta_sim_kernel(const ppenv_ta_sim* sim);
+/* ... and by name, as rocprofv3 prints it ("ta_chain_kernel<false>", "ta_chain_kernel<true>" with a randomisation set, ...). */
+const char* ppenv_ta_sim_kernel_name(const ppenv_ta_sim* sim);
 /* Domain randomisation of the 27-DoF task (cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml carries the same task.randomization_params block as the
  * 7-dof yamls; TA's apply_randomizations call sits in its reset path as TT:849-850's does): per-env tables in device memory, SoA, NULL = not
  * randomised — drive stiffness / damping scales [27][N], link mass scales [28][N] (link 0 = pelvis; mass and inertia together), restitution and

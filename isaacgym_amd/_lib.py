@@ -88,6 +88,24 @@ def build_for_arm_model(config, out_dir, force=False):
     return build(force=force, out=os.path.join(out_dir, "libppenv.so"), extra_flags=[f'-DPPENV_MODEL_HEADER="{header}"'], extra_deps=[header])
 
 
+def build_for_ta_model(model, out_dir, scene_cfg=None, force=False):
+    """The library with ANOTHER 27-dof tree compiled into the chain-wave kernel (TA:470 `g1_27dof.urdf`): `model` is a
+    scene.TAModel (isaacgym_amd.urdf.ta_model of the asset), `scene_cfg` the scene whose collision shapes ride on it (default
+    scene.build_ta_scene).  modelgen_ta writes the tree's header into out_dir and the same sources are built against it
+    (-DPPENV_TA_MODEL_HEADER=...): ppenv_ta_sim_create of THAT library then selects ta_chain_kernel for the model — the default
+    library keeps its table-driven kernels for it (and refuses PPENV_TA_KERNEL=chain).  The tree must have the G1's topology: limbs of
+    6 + 6 + 3 + 7 + 5 links on the pelvis / torso; anything else fails the kernel's static_asserts at compile time, not at run time.
+    -> path of out_dir/libppenv.so (load()).  The 7-dof kernels of that library carry the stock arm."""
+    from . import modelgen_ta
+    os.makedirs(out_dir, exist_ok=True)
+    header = os.path.join(out_dir, "ppenv_model_ta.h")
+    text = modelgen_ta.generate(scene_cfg if scene_cfg is not None else scene.build_ta_scene(1), model)
+    if not os.path.exists(header) or open(header).read() != text:
+        with open(header, "w") as fh:
+            fh.write(text)
+    return build(force=force, out=os.path.join(out_dir, "libppenv.so"), extra_flags=[f'-DPPENV_TA_MODEL_HEADER="{header}"'], extra_deps=[header])
+
+
 def lib():
     """The loaded library with argtypes set.  Raises PPEnvError when it is not built."""
     global _lib
@@ -130,6 +148,10 @@ def load(path):
     L.ppenv_set_gravity.argtypes = [vp, C.c_float]
     L.ppenv_status.restype = C.c_uint32
     L.ppenv_status.argtypes = [vp]
+    L.ppenv_step_kernel_name.restype = C.c_char_p
+    L.ppenv_step_kernel_name.argtypes = [vp]
+    L.ppenv_ta_sim_kernel_name.restype = C.c_char_p
+    L.ppenv_ta_sim_kernel_name.argtypes = [vp]
     L.ppenv_ta_pd_targets.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.ppenv_ta_serve_from_draws.argtypes = [vp, vp, C.c_int32, vp, vp]
     L.ppenv_ta_sim_device.argtypes = [vp]

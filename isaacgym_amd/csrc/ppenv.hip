@@ -1424,50 +1424,72 @@ int ppenv_config_of(ppenv* e, ppenv_config* out) {
     return PPENV_OK;
 }
 
+// Which kernel ppenv_step launches for this handle NOW (the randomisation state included).  One decision, two readers: launch_step
+// switches on it, ppenv_step_kernel_name reports it — so what bench.py prints as `roofline.kernel` is what ran, not a guess from the
+// environment.  The names are the demangled ones rocprofv3's kernel trace shows (default template arguments written out).
+enum StepSchedule { SCH_DR_T4, SCH_DR_SPLIT, SCH_DR_FUSED, SCH_T4_ARMS_SWEEP, SCH_T4_BALL_SWEEPS, SCH_SPLIT_ARM_SWEEPS, SCH_QUAD, SCH_SPLIT_BW4, SCH_SPLIT_BW2,
+                    SCH_SPLIT, SCH_FUSED };
+static const char* const kScheduleNames[] = {
+    "step_kernel_split<pp::ModelG1, 2, 1, 1, true>", "step_kernel_split<pp::ModelG1, 1, 0, 1, true>", "step_kernel<pp::ModelG1, true>",
+    "step_kernel_split<pp::ModelG1, 2, 1, 1, false>", "step_kernel_split<pp::ModelG1, 2, 0, 1, false>", "step_kernel_split<pp::ModelG1, 1, 1, 1, false>",
+    "step_kernel_quad<pp::ModelG1>", "step_kernel_split<pp::ModelG1, 1, 0, 4, false>", "step_kernel_split<pp::ModelG1, 1, 0, 2, false>",
+    "step_kernel_split<pp::ModelG1, 1, 0, 1, false>", "step_kernel<pp::ModelG1, false>"};
+static StepSchedule schedule_of(const ppenv* e) {
+    if (e->dr_on)   // domain randomisation: the table-reading instantiation — of the two-wave schedule (default) or of the one-wave kernel (PPENV_STEP_KERNEL=fused)
+        return e->agents == 2 ? SCH_DR_T4 : e->split ? SCH_DR_SPLIT : SCH_DR_FUSED;
+    if (e->agents == 2) return e->split == 2 ? SCH_T4_ARMS_SWEEP : SCH_T4_BALL_SWEEPS;
+    if (e->split == 4) return SCH_SPLIT_ARM_SWEEPS;
+    if (e->split == 3) return SCH_QUAD;
+    if (e->split) return e->ball_waves == 4 ? SCH_SPLIT_BW4 : e->ball_waves == 2 ? SCH_SPLIT_BW2 : SCH_SPLIT;
+    return SCH_FUSED;
+}
+
 static int launch_step(ppenv* e, const DevBuffers& buf, const float* actions_dev, void* stream) {
     if (!e || !actions_dev) { set_err("NULL argument"); return PPENV_EINVAL; }
     if (int rc = check_status(e)) return rc;
     if (int rc = use_device(e)) return rc;
-    if (e->dr_on) {   // domain randomisation: the table-reading instantiation — of the two-wave schedule (default) or of the one-wave kernel (PPENV_STEP_KERNEL=fused)
-        if (e->agents == 2)
-            hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1, 1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, buf,
-                               actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff, e->dr);
-        else if (e->split)
-            hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, buf,
-                               actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff, e->dr);
-        else
-            hipLaunchKernelGGL((step_kernel<ModelG1, true>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, buf, actions_dev,
-                               e->serve_on, e->dr);
-        PP_HIP(hipGetLastError());
-        return PPENV_OK;
+    const dim3 grid(grid_for(e->cfg.num_envs));
+    hipStream_t st = (hipStream_t)stream;
+    switch (schedule_of(e)) {
+    case SCH_DR_T4:
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1, 1, true>), grid, dim3(3 * kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff, e->dr);
+        break;
+    case SCH_DR_SPLIT:
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 1, true>), grid, dim3(2 * kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff, e->dr);
+        break;
+    case SCH_DR_FUSED:
+        hipLaunchKernelGGL((step_kernel<ModelG1, true>), grid, dim3(kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->dr);
+        break;
+    case SCH_T4_ARMS_SWEEP:
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1>), grid, dim3(3 * kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+        break;
+    case SCH_T4_BALL_SWEEPS:
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 0>), grid, dim3(3 * kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+        break;
+    case SCH_SPLIT_ARM_SWEEPS:
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 1>), grid, dim3(2 * kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+        break;
+    case SCH_QUAD:
+        hipLaunchKernelGGL((step_kernel_quad<ModelG1>), grid, dim3(4 * kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+        break;
+    case SCH_SPLIT_BW4:
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 4>), grid, dim3(5 * kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+        break;
+    case SCH_SPLIT_BW2:
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 2>), grid, dim3(3 * kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+        break;
+    case SCH_SPLIT:
+        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0>), grid, dim3(2 * kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
+        break;
+    case SCH_FUSED:
+        hipLaunchKernelGGL((step_kernel<ModelG1, false>), grid, dim3(kBlock), 0, st, e->K, buf, actions_dev, e->serve_on, DRTables{});
+        break;
     }
-    if (e->agents == 2 && e->split == 2)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, buf,
-                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
-    else if (e->agents == 2)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 2, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, buf,
-                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
-    else if (e->split == 4)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 1>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, buf,
-                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
-    else if (e->split == 3)
-        hipLaunchKernelGGL((step_kernel_quad<ModelG1>), dim3(grid_for(e->cfg.num_envs)), dim3(4 * kBlock), 0, (hipStream_t)stream, e->K, buf,
-                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
-    else if (e->split && e->ball_waves == 4)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 4>), dim3(grid_for(e->cfg.num_envs)), dim3(5 * kBlock), 0, (hipStream_t)stream, e->K, buf,
-                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
-    else if (e->split && e->ball_waves == 2)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0, 2>), dim3(grid_for(e->cfg.num_envs)), dim3(3 * kBlock), 0, (hipStream_t)stream, e->K, buf,
-                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
-    else if (e->split)
-        hipLaunchKernelGGL((step_kernel_split<ModelG1, 1, 0>), dim3(grid_for(e->cfg.num_envs)), dim3(2 * kBlock), 0, (hipStream_t)stream, e->K, buf,
-                           actions_dev, e->serve_on, e->status_dev, e->dbg_drop_handoff);
-    else
-        hipLaunchKernelGGL((step_kernel<ModelG1, false>), dim3(grid_for(e->cfg.num_envs)), dim3(kBlock), 0, (hipStream_t)stream, e->K, buf, actions_dev,
-                           e->serve_on, DRTables{});
     PP_HIP(hipGetLastError());
     return PPENV_OK;
 }
+
+const char* ppenv_step_kernel_name(ppenv* e) { return e ? kScheduleNames[schedule_of(e)] : ""; }
 
 int ppenv_step(ppenv* e, const float* actions_dev, void* stream) { return launch_step(e, e ? e->buf : DevBuffers{}, actions_dev, stream); }
 

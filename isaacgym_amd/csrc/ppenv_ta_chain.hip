@@ -33,7 +33,12 @@
 
 #include "ppenv_ta_device.h"
 #include "ppenv_ta_task.h"
-#include "ppenv_model_g1_ta.h"
+// PPENV_TA_MODEL_HEADER: a build for another 27-dof asset names the header isaacgym_amd/modelgen_ta.py generated from ITS tree
+// (isaacgym_amd/_lib.py build_for_ta_model); the struct keeps its name, the static_asserts below hold it to the G1's topology.
+#ifndef PPENV_TA_MODEL_HEADER
+#define PPENV_TA_MODEL_HEADER "ppenv_model_g1_ta.h"
+#endif
+#include PPENV_TA_MODEL_HEADER
 #include "ppenv_ta_chain.h"
 
 using namespace pp;

@@ -674,6 +674,15 @@ void ppenv_ta_sim_destroy(ppenv_ta_sim* s) {
     delete s;
 }
 
+// The kernel ppenv_ta_step launches for this handle now (demangled, as rocprofv3's kernel trace shows it).
+const char* ppenv_ta_sim_kernel_name(const ppenv_ta_sim* s) {
+    if (!s) return "";
+    const bool dr = s->dr.dof_stiffness_scale || s->dr.dof_damping_scale || s->dr.link_mass_scale || s->dr.restitution_scale || s->dr.friction_scale ||
+                    s->dr.action_noise_sigma > 0.f || s->dr.observation_noise_sigma > 0.f;
+    if (s->chain) return dr ? "ta_chain_kernel<true>" : "ta_chain_kernel<false>";
+    return s->quad ? "ta_sim_quad_kernel<true, true>" : "ta_sim_kernel<true> + ta_post_physics_kernel";
+}
+
 int ppenv_ta_simulate(ppenv_ta_sim* s, int32_t n, const float* actions_dev, float* root_states_dev, float* dof_states_dev, float* rb_states_dev,
                       float* dof_force_dev, float* pre_ball_vx_dev, void* stream) {
     if (!s || n <= 0 || !actions_dev || !root_states_dev || !dof_states_dev || !rb_states_dev || !dof_force_dev || !pre_ball_vx_dev) {

@@ -194,8 +194,14 @@ class GradientBuckets:
         self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.active else 1
         self.works, self.tensors, self.names, self.bytes = [], [], [], 0
+        self._joined = True                     # wait() has run since the last bucket: the next bucket starts a new backward
 
     def __call__(self, name, tensors):
+        """Not for `backward(accumulate=True)`: the gradient buffers then hold sums that earlier backward passes already reduced, and reducing
+        them again would count those once more — accumulate locally (on_grads=None) and pass this callable to the LAST micro-batch's backward only
+        (NativeMLPLearner.backward refuses the combination)."""
+        if self._joined:                        # `names` / `bytes` describe ONE backward: they start over here instead of growing for ever
+            self.names, self.bytes, self._joined = [], 0, False
         self.names.append(name)
         for t in tensors:
             self.tensors.append(t)
@@ -210,3 +216,4 @@ class GradientBuckets:
             for t in self.tensors:
                 t.div_(self.world)
         self.works, self.tensors = [], []
+        self._joined = True

@@ -144,6 +144,11 @@ class PPEnv:
         """PPENV_STATUS_* bits reported by the kernels (0 = healthy); read without synchronising."""
         return int(self.L.ppenv_status(self.h))
 
+    @property
+    def step_kernel_name(self):
+        """The kernel ppenv_step launches for this handle now, as rocprofv3's kernel trace names it (ppenv_step_kernel_name)."""
+        return self.L.ppenv_step_kernel_name(self.h).decode()
+
     def reduce_stats(self, out=None):
         """float64[4] on the device: sum rew_buf, sum progress_buf, sum episode, num_envs (one reduction launch)."""
         if out is None:

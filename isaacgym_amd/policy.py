@@ -212,20 +212,32 @@ def cast_weights_batch(items, stream_of):
     _lib.check(_lib_policy().ppenv_mlp_cast_weights_batch(arr, len(items), _stream(stream_of)))
 
 
-class RunningMeanStd:
+class RunningMeanStd(torch.nn.Module):
     """rl_games' RunningMeanStd (normalize_input: True, cfg/train/HumanoidPingpongTiltG1PPO.yaml:51) with the training-mode update as
     one launch (ppenv_running_mean_std_update): float64 running mean / var / count as rl_games keeps them, plus the fp32 mean and
     1 / sqrt(var + eps) the policy's normaliser reads.  rl_games itself is absent from the reference: restated from its published
-    running_mean_std.py (unbiased batch variance, parallel-moments merge) — parity unpinned."""
+    running_mean_std.py (unbiased batch variance, parallel-moments merge) — parity unpinned.
+    A torch module with rl_games' own buffer names (`running_mean`, `running_var`, `count`), so that a module holding it as
+    `running_mean_std` saves and restores the statistics under rl_games' checkpoint keys; the two fp32 tensors the kernels read are
+    derived (non-persistent) and are refreshed in place after every load, so whoever holds them (NativeMLP.set_normalization_tensors)
+    keeps seeing the current statistics."""
 
     def __init__(self, num_obs, device, eps=1e-5):
+        super().__init__()
         self.device, self.eps, self.num_obs = torch.device(device), float(eps), int(num_obs)
-        self.running_mean = torch.zeros(num_obs, dtype=torch.float64, device=self.device)
-        self.running_var = torch.ones(num_obs, dtype=torch.float64, device=self.device)
-        self.count = torch.ones((), dtype=torch.float64, device=self.device)
-        self.mean = torch.zeros(num_obs, dtype=torch.float32, device=self.device)
-        self.inv_std = torch.rsqrt(torch.ones(num_obs, dtype=torch.float32, device=self.device) + eps)
+        self.register_buffer("running_mean", torch.zeros(num_obs, dtype=torch.float64, device=self.device))
+        self.register_buffer("running_var", torch.ones(num_obs, dtype=torch.float64, device=self.device))
+        self.register_buffer("count", torch.ones((), dtype=torch.float64, device=self.device))
+        self.register_buffer("mean", torch.zeros(num_obs, dtype=torch.float32, device=self.device), persistent=False)
+        self.register_buffer("inv_std", torch.rsqrt(torch.ones(num_obs, dtype=torch.float32, device=self.device) + eps), persistent=False)
         self._ws, self._ws_rows = None, 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh())
+
+    def refresh(self):
+        """mean / inv_std (fp32, what the normaliser reads) from the float64 running statistics, IN PLACE."""
+        with torch.no_grad():
+            self.mean.copy_(self.running_mean.float())
+            self.inv_std.copy_(torch.rsqrt(self.running_var.float() + self.eps))
 
     def update(self, obs):
         """obs [M, num_obs] fp32 on the device: one pass; mean / inv_std are refreshed in place (a NativeMLP given these tensors by
@@ -387,6 +399,7 @@ class NativeMLPLearner:
         self._rows = 0
         self.rms = None
         self._cast_items = None
+        self.generation = 0                 # forward passes so far: backward() differentiates the LAST one (the activation buffers are shared)
         self.sync_weights()
 
     def parameters(self):
@@ -437,14 +450,21 @@ class NativeMLPLearner:
     def forward(self, obs, update_stats=False):
         if update_stats:
             self.rms.update(obs)
+        self.generation += 1
         return self.net.forward(obs)
 
-    def backward(self, d_head, accumulate=False, on_grads=None):
+    def backward(self, d_head, accumulate=False, on_grads=None, generation=None):
         """d_head [M, A + 1] fp32 = d loss / d [mu | value] of the rows of the last forward (M a multiple of 64).
         on_grads(name, tensors): called once per layer — heads first, layer 1 last — right after the launches that produce that layer's weight and
         bias gradients have been enqueued (distributed.GradientBuckets: the gradient all-reduce of a layer overlaps the backward of the layers below)."""
         net, u, na = self.net, self.net.units, self.net.num_actions
         m = d_head.shape[0]
+        if generation is not None and generation != self.generation:
+            raise RuntimeError(f"NativeMLPLearner.backward: the gradient belongs to forward #{generation}, but the activation buffers hold forward "
+                               f"#{self.generation} — one forward, then its backward (a second forward in between overwrites what the backward reads)")
+        if accumulate and on_grads is not None:
+            raise ValueError("backward(accumulate=True, on_grads=...): the buffers would hold sums an earlier collective already reduced; accumulate "
+                             "locally and hand on_grads the totals once (distributed.GradientBuckets)")
         assert m == net._rows and m % 64 == 0 and d_head.dtype == torch.float32 and d_head.shape[1] == na + 1 and d_head.stride(1) == 1
         if m != self._rows:
             self._alloc(m)
@@ -483,6 +503,7 @@ class _ActorCriticFn(torch.autograd.Function):
     def forward(ctx, module, obs, *params):          # params: only so that autograd routes their gradients here
         mu, value = module.learner.forward(obs, update_stats=module.training and module.learner.rms is not None)
         ctx.module = module
+        ctx.generation = module.learner.generation   # the activation buffers are the learner's own: backward checks nobody forwarded since
         return mu.clone(), value.clone()             # the network's own buffers are reused by the next forward
 
     @staticmethod
@@ -495,7 +516,7 @@ class _ActorCriticFn(torch.autograd.Function):
         if d_value is not None:
             d_head[:, na:] = d_value
         sync = ctx.module.grad_sync                   # distributed.GradientBuckets (or None): per-layer all-reduce beside the rest of the backward
-        grads = lr.backward(d_head, on_grads=sync)
+        grads = lr.backward(d_head, on_grads=sync, generation=ctx.generation)
         if sync is not None:
             sync.wait()                              # the clones below are ordered after the collectives
         return (None, None) + tuple(g.clone() for g in grads)
@@ -515,7 +536,10 @@ class NativeActorCritic(torch.nn.Module):
         self.learner = NativeMLPLearner(actor, critic, num_obs, device, eps=eps, clip=clip)
         self.learner.rms = None
         if normalize_input:
-            self.learner.attach_running_mean_std(RunningMeanStd(num_obs, device, eps=eps))
+            # a SUBMODULE under rl_games' own name: state_dict() / load_state_dict() carry `running_mean_std.running_mean | running_var | count`
+            # (the statistics are part of a trained policy: without them a restored network would normalise with mean 0 / var 1)
+            self.running_mean_std = RunningMeanStd(num_obs, device, eps=eps)
+            self.learner.attach_running_mean_std(self.running_mean_std)
         lr = self.learner
         P = torch.nn.Parameter
         self.hidden_w = torch.nn.ParameterList([P(w) for w in lr.w32])       # the same storage as the learner's masters
@@ -531,29 +555,25 @@ class NativeActorCritic(torch.nn.Module):
         net = cls(actor, critic, actor[0][0].shape[1], device, normalize_input="running_mean_std.running_mean" in state_dict, **kw)
         if net.learner.rms is not None:
             rms = net.learner.rms
-            rms.running_mean.copy_(state_dict["running_mean_std.running_mean"])
-            rms.running_var.copy_(state_dict["running_mean_std.running_var"])
-            rms.count.copy_(state_dict["running_mean_std.count"])
-            rms.mean.copy_(rms.running_mean.float())
-            rms.inv_std.copy_(torch.rsqrt(rms.running_var.float() + rms.eps))
+            with torch.no_grad():
+                rms.running_mean.copy_(state_dict["running_mean_std.running_mean"])
+                rms.running_var.copy_(state_dict["running_mean_std.running_var"])
+                rms.count.copy_(state_dict["running_mean_std.count"])
+            rms.refresh()
         if "a2c_network.sigma" in state_dict:
             net.sigma.data.copy_(state_dict["a2c_network.sigma"])
         return net
 
-    def _ordered(self):
-        return list(self.hidden_w) + list(self.hidden_b) + [self.mu_w, self.mu_b, self.value_w, self.value_b]
-
-    def _versions(self):
-        return tuple(p._version for p in self._ordered())
-
-    def forward(self, obs):
-        if obs.shape[0] % 64:
-            raise ValueError(f"NativeActorCritic: {obs.shape[0]} rows; the minibatch must be a multiple of 64")
-        v = self._versions()
-        if v != self._seen:                          # an optimizer stepped (or a state dict was loaded): recast the operand images
-            self.learner.sync_weights()
-            self._seen = v
-        return _ActorCriticFn.apply(self, obs, *self._ordered())
+    def to_rlgames_state_dict(self):
+        """The inverse of from_rlgames: rl_games' key layout for this network (what `torch.save({"model": ...})` of its a2c_continuous_logstd
+        model holds — `a2c_network.{actor,critic}_mlp.<2 i>.{weight,bias}`, `a2c_network.mu.*`, `a2c_network.value.*`, `a2c_network.sigma`,
+        `running_mean_std.{running_mean,running_var,count}`), so that a policy trained here plays under rl_games' player or
+        RLGamesPolicy.  Detached clones on the module's device.  (`value_mean_std.*` — normalize_value — belongs to the agent, not to
+        this network; rl_games is absent offline: the layout is its published one, not pinned to a file.)"""
+        lr = self.learner
+        actor = [(self.hidden_w[i][0], self.hidden_b[i][0]) for i in range(len(lr.net.units))] + [(self.mu_w, self.mu_b)]
+        critic = [(self.hidden_w[i][1], self.hidden_b[i][1]) for i in range(len(lr.net.units))] + [(self.value_w, self.value_b)]
+        return rlgames_state_dict_from_layers(actor, critic, sigma=self.sigma, rms=lr.rms)
 
 
 # ---- a trained rl_games checkpoint on the native forward (the reference's `train.py test=True checkpoint=...` play mode) ---------------
@@ -575,6 +595,23 @@ def layers_from_rlgames_state_dict(sd):
     actor = mlp("actor") + [(sd["a2c_network.mu.weight"], sd["a2c_network.mu.bias"])]
     critic = mlp("critic") + [(sd["a2c_network.value.weight"], sd["a2c_network.value.bias"])]
     return actor, critic
+
+
+def rlgames_state_dict_from_layers(actor, critic, sigma=None, rms=None):
+    """The inverse of layers_from_rlgames_state_dict: (weight, bias) lists, head last -> rl_games' keys (hidden layer i sits at index 2 i of
+    its nn.Sequential: Linear, activation, Linear, ...), plus `a2c_network.sigma` and `running_mean_std.*` when given.  Detached clones."""
+    c = lambda t: t.detach().clone()
+    sd = {}
+    for which, layers, head in (("actor", actor, "mu"), ("critic", critic, "value")):
+        for i, (w, b) in enumerate(layers[:-1]):
+            sd[f"a2c_network.{which}_mlp.{2 * i}.weight"], sd[f"a2c_network.{which}_mlp.{2 * i}.bias"] = c(w), c(b)
+        sd[f"a2c_network.{head}.weight"], sd[f"a2c_network.{head}.bias"] = c(layers[-1][0]), c(layers[-1][1])
+    if sigma is not None:
+        sd["a2c_network.sigma"] = c(sigma)
+    if rms is not None:
+        for k in ("running_mean", "running_var", "count"):
+            sd[f"running_mean_std.{k}"] = c(getattr(rms, k))
+    return sd
 
 
 class RLGamesPolicy:

@@ -358,12 +358,61 @@ def _set(arr, values):
         arr[i] = float(v)
 
 
+def _table_geom(table):
+    """TABLE_GEOM overridden by `table` (isaacgym_amd.urdf.table_scene of a table asset, or a hand-written dict of the same keys)."""
+    g = dict(TABLE_GEOM, offset_xy=(0.0, 0.0), net_offset_xy=None, net_bottom_z=None)
+    if table is not None:
+        unknown = sorted(set(table) - set(g) - {"ignored"})
+        if unknown:
+            raise ValueError(f"table geometry has unknown keys {unknown}")
+        g.update({k: v for k, v in table.items() if k != "ignored"})
+    if g["net_offset_xy"] is None:
+        g["net_offset_xy"] = g["offset_xy"]
+    if g["net_bottom_z"] is None:
+        g["net_bottom_z"] = g["top_z"]
+    for k in ("length", "width", "slab", "net_height", "net_half_thickness"):
+        if not g[k] > 0.0:
+            raise ValueError(f"table geometry: {k} must be positive")
+    return g
+
+
+def _ball_geom(ball):
+    """BALL_GEOM overridden by `ball` (isaacgym_amd.urdf.ball_params of a ball asset, or a dict of the same keys)."""
+    g = dict(BALL_GEOM)
+    if ball is not None:
+        unknown = sorted(set(ball) - set(g))
+        if unknown:
+            raise ValueError(f"ball parameters have unknown keys {unknown}")
+        g.update(ball)
+    if not (g["radius"] > 0.0 and g["mass"] > 0.0 and g["inertia_factor"] > 0.0 and g["angular_damping"] >= 0.0):
+        raise ValueError("ball parameters: radius, mass and inertia_factor must be positive")
+    return g
+
+
+def asset_geometry(scene_cfg):
+    """(table, ball) for build_config from the optional asset entries of a task cfg's `scene` block: `table_urdf` / `ball_urdf` name the
+    files the reference loads as pingpong_table.urdf / small_ball.urdf (TT:496,502 — absolute paths on its author's machine, not
+    yaml keys, hence entries of this build's own block); `table_geom` / `ball_geom` give the same dicts directly.  Absent: (None, None),
+    i.e. the UNVERIFIED placeholders."""
+    from . import urdf
+    table, ball = scene_cfg.get("table_geom"), scene_cfg.get("ball_geom")
+    if scene_cfg.get("table_urdf"):
+        table = urdf.table_scene(urdf.load(scene_cfg["table_urdf"]))
+    if scene_cfg.get("ball_urdf"):
+        ball = urdf.ball_params(urdf.load(scene_cfg["ball_urdf"]))
+    return table, ball
+
+
 def build_config(variant, cfg=None, num_envs=None, seed=0, device_id=0, env_id_offset=0, ball_substeps=4,
-                 restitution_max=1.0):
-    """Build the C config for variant 'T3' | 'TT' | 'TN' from a task cfg dict (default: the yaml defaults)."""
+                 restitution_max=1.0, table=None, ball=None):
+    """Build the C config for variant 'T3' | 'TT' | 'TN' | 'T4' from a task cfg dict (default: the yaml defaults).
+    table / ball: the geometry of the other two assets of the scene (TT:496,502) when it comes from their URDFs
+    (isaacgym_amd.urdf.table_scene / ball_params) instead of the UNVERIFIED placeholders TABLE_GEOM / BALL_GEOM; both are run-time
+    constants of the step kernels, so no rebuild is involved."""
     if cfg is None:
         cfg = default_task_cfg(variant)
     env, sim, scene = cfg["env"], cfg["sim"], cfg["scene"]
+    bg = _ball_geom(ball)
     c = Config()
     c.abi_version = ABI_VERSION
     c.variant = VARIANT_IDS[variant]
@@ -453,12 +502,12 @@ def build_config(variant, cfg=None, num_envs=None, seed=0, device_id=0, env_id_o
 
     # --- ball + materials (combined coefficients are precomputed here)
     ball_mat = scene["ball_material"]
-    c.ball_radius = BALL_GEOM["radius"]
-    c.ball_mass = BALL_GEOM["mass"]
-    c.ball_inertia_factor = BALL_GEOM["inertia_factor"]
+    c.ball_radius = bg["radius"]
+    c.ball_mass = bg["mass"]
+    c.ball_inertia_factor = bg["inertia_factor"]
     c.ball_restitution = ball_mat["restitution"]
     c.ball_friction = ball_mat["friction"]
-    c.ball_angular_damping = BALL_GEOM["angular_damping"]
+    c.ball_angular_damping = bg["angular_damping"]
     c.restitution_max = restitution_max
 
     plane = env["plane"]
@@ -467,11 +516,11 @@ def build_config(variant, cfg=None, num_envs=None, seed=0, device_id=0, env_id_o
         ball_mat, dict(restitution=plane["restitution"], friction=plane["dynamicFriction"]), restitution_max)
 
     tp = np.asarray(scene["table_pos"], dtype=np.float64)
-    g = TABLE_GEOM
-    _set(c.table.center, (tp[0], tp[1], tp[2] + g["top_z"] - 0.5 * g["slab"]))
+    g = _table_geom(table)
+    _set(c.table.center, (tp[0] + g["offset_xy"][0], tp[1] + g["offset_xy"][1], tp[2] + g["top_z"] - 0.5 * g["slab"]))
     _set(c.table.half, (0.5 * g["length"], 0.5 * g["width"], 0.5 * g["slab"]))
     c.table.restitution, c.table.friction = _combine(ball_mat, scene["table_material"], restitution_max)
-    _set(c.net.center, (tp[0], tp[1], tp[2] + g["top_z"] + 0.5 * g["net_height"]))
+    _set(c.net.center, (tp[0] + g["net_offset_xy"][0], tp[1] + g["net_offset_xy"][1], tp[2] + g["net_bottom_z"] + 0.5 * g["net_height"]))
     _set(c.net.half, (g["net_half_thickness"], 0.5 * g["width"] + g["net_overhang"], 0.5 * g["net_height"]))
     # only table_shape_props[0] is given the table material (TT:580-582); the net keeps the default
     c.net.restitution, c.net.friction = _combine(ball_mat, DEFAULT_SHAPE_MATERIAL, restitution_max)
@@ -806,10 +855,10 @@ TASK_CFGS["TA"] = dict(
 )
 
 
-def build_ta_scene(num_envs, device_id=0):
+def build_ta_scene(num_envs, device_id=0, table=None, ball=None):
     """The ppenv_config part of the 27-DoF scene (ball, table, net, contact scalars, dt ...) with the humanoid's ball-collision
-    shapes re-attached to links of the 28-link tree (ppenv_ta_model)."""
-    c = build_config("TN", cfg=default_task_cfg("TA"), num_envs=num_envs, device_id=device_id)
+    shapes re-attached to links of the 28-link tree (ppenv_ta_model).  table / ball: as in build_config (TA:551,557)."""
+    c = build_config("TN", cfg=default_task_cfg("TA"), num_envs=num_envs, device_id=device_id, table=table, ball=ball)
     ra = G1_RIGHT_ARM
     yaw_o = np.asarray(ra[2]["xyz"])
     elbow_o = yaw_o + np.asarray(ra[3]["xyz"])

@@ -16,8 +16,8 @@ from . import _lib, scene
 class TAState:
     """Per-env buffers the reference keeps across steps (progress, sticky/count flags) plus the outputs."""
 
-    def __init__(self, params, device="cuda:0"):
-        self.L = _lib.lib()
+    def __init__(self, params, device="cuda:0", library=None):
+        self.L = library if library is not None else _lib.lib()
         self.params = params
         self.device = torch.device(device)
         n = self.num_envs = params.num_envs
@@ -30,6 +30,9 @@ class TAState:
         self.episode = z((n,), torch.int32)
         self._any_reset = z((1,), torch.int32)
 
+    def _ck(self, rc):
+        _lib.check(rc, self.L)          # the message is the thread-local one of THIS library instance
+
     def post_physics_step(self, rb_states, initial_rb_states, root_states, dof_states, dof_force, pre_ball_vx, reset_override=None):
         n = self.num_envs
         irb_n = 1 if self.params.initial_rb_shared else n
@@ -41,7 +44,7 @@ class TAState:
             ov = reset_override.to(self.device, torch.float32).reshape(n, 5).contiguous()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         # (the library launches on the device that owns obs_buf, whatever the caller's current device is)
-        _lib.check(self.L.ppenv_ta_post_physics_step(
+        self._ck(self.L.ppenv_ta_post_physics_step(
             C.byref(self.params), rb_states.data_ptr(), initial_rb_states.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(),
             dof_force.data_ptr(), pre_ball_vx.data_ptr(), ov.data_ptr() if ov is not None else None, self.flags.data_ptr(),
             self.episode.data_ptr(), self.progress_buf.data_ptr(), self.obs_buf.data_ptr(), self.rew_buf.data_ptr(),
@@ -53,16 +56,21 @@ class TAState:
 class TASim:
     """pre_physics_step + gym.simulate + refresh for the 27-DoF task (TA:1124-1143, 1150) on Isaac-Gym-layout tensors."""
 
-    def __init__(self, num_envs, device="cuda:0", scene_cfg=None, model=None):
-        self.L = _lib.lib()
+    def __init__(self, num_envs, device="cuda:0", scene_cfg=None, model=None, library=None):
+        """model: another 28-link tree (isaacgym_amd.urdf.ta_model of an asset).  library: a libppenv built with THAT tree compiled into
+        the chain-wave kernel (_lib.load(_lib.build_for_ta_model(...))); the default library steps such a model on its table-driven kernels."""
+        self.L = library if library is not None else _lib.lib()
         self.device = torch.device(device)
         self.num_envs = int(num_envs)
         self.scene = scene_cfg if scene_cfg is not None else scene.build_ta_scene(self.num_envs, device_id=self.device.index or 0)
         self.model = model if model is not None else scene.build_ta_model()
         self.h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.L.ppenv_ta_sim_create(C.byref(self.scene), C.byref(self.model), self._stream(), C.byref(self.h)))
+            self._ck(self.L.ppenv_ta_sim_create(C.byref(self.scene), C.byref(self.model), self._stream(), C.byref(self.h)))
             torch.cuda.current_stream(self.device).synchronize()
+
+    def _ck(self, rc):
+        _lib.check(rc, self.L)
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -86,13 +94,18 @@ class TASim:
         n = self.num_envs
         for t, k in ((actions, n * 27), (root_states, n * 39), (dof_states, n * 54), (rb_states, n * 42 * 13), (dof_force, n * 27), (pre_ball_vx, n)):
             self._check(t, k)
-        _lib.check(self.L.ppenv_ta_simulate(self.h, n, actions.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(), rb_states.data_ptr(),
+        self._ck(self.L.ppenv_ta_simulate(self.h, n, actions.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(), rb_states.data_ptr(),
                                             dof_force.data_ptr(), pre_ball_vx.data_ptr(), self._stream()))
 
     @property
     def kernel(self):
         """Which kernel ppenv_ta_step launches: 'chain' (one lane per env, one wave per limb), 'quad' or 'lane'."""
         return {2: "chain", 1: "quad", 0: "lane"}[int(self.L.ppenv_ta_sim_kernel(self.h))]
+
+    @property
+    def kernel_name(self):
+        """... by the name rocprofv3's kernel trace shows (ppenv_ta_sim_kernel_name; 'ta_chain_kernel<true>' while a randomisation is set)."""
+        return self.L.ppenv_ta_sim_kernel_name(self.h).decode()
 
     @property
     def status(self):
@@ -117,7 +130,7 @@ class TASim:
         ov = None
         if reset_override is not None:
             ov = reset_override.to(self.device, torch.float32).reshape(n, 5).contiguous()
-        _lib.check(self.L.ppenv_ta_step(
+        self._ck(self.L.ppenv_ta_step(
             self.h, C.byref(state.params), actions.data_ptr(), initial_rb_states.data_ptr(), root_states.data_ptr(), dof_states.data_ptr(),
             rb_states.data_ptr() if rb_states is not None else None, dof_force.data_ptr(), pre_ball_vx.data_ptr(), ov.data_ptr() if ov is not None else None, state.flags.data_ptr(),
             state.episode.data_ptr(), state.progress_buf.data_ptr(), obs.data_ptr(), rew.data_ptr(), reset.data_ptr(),
@@ -130,12 +143,12 @@ class TASim:
         clamp((obs - mean) * inv_std, +-clip), zero beyond column 312 (what policy.prepare_input makes of obs_buf).  out None: off.
         The tensors are read / written by every later step: the caller keeps them alive."""
         if out is None:
-            _lib.check(self.L.ppenv_ta_sim_set_policy_input(self.h, None, None, 0.0, None, 0))
+            self._ck(self.L.ppenv_ta_sim_set_policy_input(self.h, None, None, 0.0, None, 0))
             self._pin = None
             return
         assert out.dtype == torch.float16 and out.shape[0] == self.num_envs and out.stride(1) == 1 and mean.dtype == inv_std.dtype == torch.float32
         self._pin = (out, mean, inv_std)
-        _lib.check(self.L.ppenv_ta_sim_set_policy_input(self.h, mean.data_ptr(), inv_std.data_ptr(), float(clip), out.data_ptr(), out.stride(0)))
+        self._ck(self.L.ppenv_ta_sim_set_policy_input(self.h, mean.data_ptr(), inv_std.data_ptr(), float(clip), out.data_ptr(), out.stride(0)))
 
     def set_randomization(self, dof_stiffness_scale=None, dof_damping_scale=None, link_mass_scale=None, restitution_scale=None, friction_scale=None,
                           action_noise_sigma=0.0, observation_noise_sigma=0.0):
@@ -154,31 +167,31 @@ class TASim:
         r = scene.Randomization()      # ppenv_ta_randomization has the fields of ppenv_randomization
         (r.dof_stiffness_scale, r.dof_damping_scale, r.link_mass_scale, r.restitution_scale, r.friction_scale) = [t.data_ptr() if t is not None else None for t in self._dr]
         r.action_noise_sigma, r.observation_noise_sigma = float(action_noise_sigma), float(observation_noise_sigma)
-        _lib.check(self.L.ppenv_ta_sim_set_randomization(self.h, C.byref(r)))
+        self._ck(self.L.ppenv_ta_sim_set_randomization(self.h, C.byref(r)))
 
     def clear_randomization(self):
-        _lib.check(self.L.ppenv_ta_sim_set_randomization(self.h, None))
+        self._ck(self.L.ppenv_ta_sim_set_randomization(self.h, None))
         self._dr = None
 
     def pd_targets(self, actions):
         """pre_physics_step's PD targets (TA:1131) for actions [N,27]."""
         a = actions.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, 27).contiguous()
         out = torch.empty_like(a)
-        _lib.check(self.L.ppenv_ta_pd_targets(self.h, self.num_envs, a.data_ptr(), out.data_ptr(), self._stream()))
+        self._ck(self.L.ppenv_ta_pd_targets(self.h, self.num_envs, a.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
     def serve_from_draws(self, draws):
         """TA's generate_random_speed_for_ball (TA:346-377) on [M,3] draws (speed, tilt deg, tilt_z deg)."""
         d = torch.as_tensor(draws, dtype=torch.float32).to(self.device).reshape(-1, 3).contiguous()
         out = torch.empty_like(d)
-        _lib.check(self.L.ppenv_ta_serve_from_draws(self.h, d.data_ptr(), d.shape[0], out.data_ptr(), self._stream()))
+        self._ck(self.L.ppenv_ta_serve_from_draws(self.h, d.data_ptr(), d.shape[0], out.data_ptr(), self._stream()))
         return out
 
     def forward_kinematics(self, root_states, dof_states, rb_states):
         n = self.num_envs
         for t, k in ((root_states, n * 39), (dof_states, n * 54), (rb_states, n * 42 * 13)):
             self._check(t, k)
-        _lib.check(self.L.ppenv_ta_forward_kinematics(self.h, n, root_states.data_ptr(), dof_states.data_ptr(), rb_states.data_ptr(), self._stream()))
+        self._ck(self.L.ppenv_ta_forward_kinematics(self.h, n, root_states.data_ptr(), dof_states.data_ptr(), rb_states.data_ptr(), self._stream()))
 
 
 class TAEnv:
@@ -187,7 +200,8 @@ class TAEnv:
     (ppenv_ta_step) plus the tiny count-flag clear; `fused=False` keeps the two launches (ppenv_ta_simulate +
     ppenv_ta_post_physics_step).  Surface: obs_buf [N,313], rew_buf, reset_buf, progress_buf, 27 actions."""
 
-    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_offset=0, env=None, fused=True, materialize_rb=None, share_initial_rb=True):
+    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_offset=0, env=None, fused=True, materialize_rb=None, share_initial_rb=True,
+                 scene_cfg=None, model=None, library=None):
         """materialize_rb: write rigid_body_states [N,42,13] in every step (the reference's refresh_rigid_body_state_tensor, pre-reset
         body states).  Default: only where the kernel needs the tensor itself (the two-launch path and the table-driven kernels);
         the chain-wave kernel keeps the body states in registers and `rb_states` is then produced on demand by forward kinematics
@@ -197,8 +211,8 @@ class TAEnv:
         n = self.num_envs = int(num_envs)
         self.num_obs, self.num_actions, self.num_agents = scene.TA_NUM_OBS, scene.TA_NUM_DOF, 1
         self.params = scene.build_ta_params(n, env=env, seed=seed, env_id_offset=env_id_offset)
-        self.sim = TASim(n, device=self.device)
-        self.state = TAState(self.params, device=self.device)
+        self.sim = TASim(n, device=self.device, scene_cfg=scene_cfg, model=model, library=library)
+        self.state = TAState(self.params, device=self.device, library=library)
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
         self.root_states, self.dof_states = z(n, 3, 13), z(n, 27, 2)          # TA:187-193, 237-240
         self._rb_states, self.dof_force_tensor, self.pre_ball_vx = z(n, 42, 13), z(n, 27), z(n)

@@ -8,7 +8,10 @@ inertials, revolute / fixed joints with origins, axes and limits) and produces
   * `arm_specs(robot, joint_names)`: the 7-dof chain tables in the format of `scene.G1_RIGHT_ARM` (feed `scene.use_arm_tables`,
     then regenerate the compiled-in model with `python -m isaacgym_amd.modelgen` and rebuild),
   * `ta_model(robot, dof_joint_names, body_names, ...)`: the 28-link tree of the 27-dof task as a `scene.TAModel` — welded
-    bodies (fixed joints) are merged into the link that carries them, exactly what `scene.build_ta_model` does by hand.
+    bodies (fixed joints) are merged into the link that carries them, exactly what `scene.build_ta_model` does by hand
+    (`_lib.build_for_ta_model` compiles the chain-wave kernel for it),
+  * `table_scene(robot)` / `ball_params(robot)`: the scene's other two assets — `pingpong_table.urdf` -> slab and net boxes,
+    `small_ball.urdf` -> radius, mass, inertia factor (TT:496,502) — in the format `scene.build_config(table=, ball=)` takes.
 
 `<collision>` geometry (box / sphere / cylinder / capsule with its origin) is read too and turned into the tables that are not
 inertial data: `ball_shapes` (the capsule / sphere shapes the ball collides with, link-attached end points + radius),
@@ -431,6 +434,111 @@ def ground_contacts(robot, movable_links, link_names, down=(0.0, 0.0, -1.0), max
     if len(out) > max_points:
         raise ValueError(f"{len(out)} ground-contact points, the model holds {max_points}")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The other two assets of the scene (TT:496 `pingpong_table.urdf`, TT:502 `small_ball.urdf`; T3:480,486, TN:501,507, T4:505,511, TA:551,557)
+def _static_frames(robot):
+    """{link: (offset, rotation)} of every link in the root link's frame for an asset without movable joints (the table: loaded with
+    fix_base_link = True, TT:493).  A movable joint would make the slab a mechanism, which the step kernels' axis-aligned boxes are not."""
+    root = robot.root()
+    frames = {root: (np.zeros(3), np.eye(3))}
+    pending = [j for j in robot.joints.values()]
+    while pending:
+        rest = []
+        for j in pending:
+            if j.parent in frames:
+                if j.type != "fixed":
+                    raise ValueError(f"joint {j.name} is {j.type}: a table asset must be one rigid piece (fixed joints only)")
+                po, pr = frames[j.parent]
+                r = scene.rpy_to_rot(*j.rpy)
+                frames[j.child] = (po + pr @ j.xyz, pr @ r)
+            else:
+                rest.append(j)
+        if len(rest) == len(pending):
+            raise ValueError(f"links not connected to the root: {sorted(j.child for j in rest)}")
+        pending = rest
+    return frames
+
+
+def _aligned_box(center, rot, size, what):
+    """(centre, half extents along the ROOT frame's axes) of a box whose own axes are a signed permutation of them — the kernels' slabs
+    (ppenv_box: centre + half extents) are axis-aligned; anything else raises instead of being squared off in silence."""
+    a = np.abs(rot)
+    if not np.allclose(a, np.round(a), atol=1e-6) or not np.allclose(np.round(a).sum(axis=0), 1.0) or not np.allclose(np.round(a).sum(axis=1), 1.0):
+        raise ValueError(f"{what}: the box is rotated off the table frame's axes; the step kernels' slabs are axis-aligned")
+    return np.asarray(center, dtype=np.float64), 0.5 * (np.round(a) @ np.asarray(size, dtype=np.float64))
+
+
+def table_scene(robot, surface_tol=5e-3):
+    """A table asset -> what scene.build_config(table=...) takes (the keys of scene.TABLE_GEOM + the offsets a file may carry).
+
+    The reference gives the table's material to `table_shape_props[0]` only (TT:580-582): shape 0 — the first <collision> of the first
+    link that has one, Isaac Gym's shape order — is therefore the playing surface, the SLAB.  The NET is the box that stands on the
+    slab's top face (its bottom within `surface_tol` of it) and is the thinnest such box along the table's length.  Every other box
+    (legs, frame) lies below the top face; the step kernels have no shape for them, so they are returned in `ignored` — and rejected
+    when one reaches above the playing surface or beyond the slab's footprint, where a ball could meet it before the slab.
+    Lengths in metres, in the frame of the table actor's root (the pose TT:575 places at (1.75, 0, 0))."""
+    frames = _static_frames(robot)
+    boxes = []
+    for name, link in robot.links.items():
+        off, rot = frames[name]
+        for k, c in enumerate(link.collisions):
+            if c.kind != "box":
+                raise ValueError(f"link {name}: a table asset's collisions must be boxes, found a {c.kind}")
+            ctr, half = _aligned_box(off + rot @ c.xyz, rot @ c.rot, c.size, f"link {name}, collision {k}")
+            boxes.append(dict(link=name, index=k, center=ctr, half=half))
+    if not boxes:
+        raise ValueError("the table asset has no <collision> box")
+    slab = boxes[0]
+    top = slab["center"][2] + slab["half"][2]
+    area = lambda b: b["half"][0] * b["half"][1]
+    if any(area(b) > area(slab) * (1 + 1e-9) for b in boxes[1:]):
+        raise ValueError("shape 0 of the table asset is not its largest horizontal box: the reference puts the table material on shape 0 "
+                         "(TT:580-582), so the playing surface must be the first <collision>")
+    standing = [b for b in boxes[1:] if abs((b["center"][2] - b["half"][2]) - top) <= surface_tol]
+    if len(standing) != 1:
+        raise ValueError(f"expected exactly one box standing on the playing surface (the net), found {len(standing)}")
+    net = standing[0]
+    if net["half"][0] > net["half"][1]:
+        raise ValueError("the net must run across the table (thin along x, the table's length)")
+    ignored = []
+    for b in boxes[1:]:
+        if b is net:
+            continue
+        if b["center"][2] + b["half"][2] > top + surface_tol:
+            raise ValueError(f"link {b['link']}: a second box reaches above the playing surface; only the slab and the net are ball shapes")
+        if np.any(np.abs(b["center"][:2] - slab["center"][:2]) + b["half"][:2] > slab["half"][:2] + surface_tol):
+            raise ValueError(f"link {b['link']}: a box below the surface sticks out of the slab's footprint; the kernels would let the ball through it")
+        ignored.append((b["link"], b["index"]))
+    return dict(length=float(2.0 * slab["half"][0]), width=float(2.0 * slab["half"][1]), top_z=float(top), slab=float(2.0 * slab["half"][2]),
+                net_height=float(2.0 * net["half"][2]), net_overhang=float(net["half"][1] - slab["half"][1]), net_half_thickness=float(net["half"][0]),
+                offset_xy=(float(slab["center"][0]), float(slab["center"][1])), net_offset_xy=(float(net["center"][0]), float(net["center"][1])),
+                net_bottom_z=float(net["center"][2] - net["half"][2]), ignored=ignored)
+
+
+def ball_params(robot, isotropy_tol=1e-6):
+    """A ball asset -> what scene.build_config(ball=...) takes: radius of its (single) sphere collision, mass, and the inertia factor
+    k = I / (m r^2) of its <inertial> (2/5 solid, 2/3 thin shell) — the three fields of ppenv_config the kernels' contact code reads
+    (ball_radius, ball_mass, ball_inertia_factor).  The angular damping is an Isaac Gym asset option (AssetOptions.angular_damping,
+    default 0.5; the reference leaves it untouched, TT:499-502), not URDF data: scene.BALL_GEOM keeps it."""
+    root = robot.root()
+    if len(robot.links) != 1 or robot.joints:
+        raise ValueError("a ball asset is one free link")
+    link = robot.links[root]
+    spheres = [c for c in link.collisions if c.kind == "sphere"]
+    if len(spheres) != 1 or len(link.collisions) != 1:
+        raise ValueError(f"link {root}: expected exactly one sphere collision, found {[c.kind for c in link.collisions]}")
+    if not np.allclose(spheres[0].xyz + 0.0, link.com, atol=1e-9):
+        raise ValueError("the ball's centre of mass must sit at the centre of its sphere (the kernels integrate a homogeneous ball)")
+    r, m = spheres[0].size[0], link.mass
+    if r <= 0.0 or m <= 0.0:
+        raise ValueError("the ball needs a positive radius and mass")
+    inertia = link.com_rot @ link.inertia @ link.com_rot.T
+    d = np.diag(inertia)
+    if not np.allclose(inertia, np.diag(d), atol=isotropy_tol * d.max()) or not np.allclose(d, d[0], rtol=isotropy_tol):
+        raise ValueError(f"the ball's inertia tensor is not isotropic: {inertia.tolist()}")
+    return dict(radius=float(r), mass=float(m), inertia_factor=float(d[0] / (m * r * r)))
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -276,8 +276,9 @@ class _HumanoidPingpongBase(VecTask):
     def create_sim(self):
         """TT:325-344: build the scene.  Here: scene constants -> ppenv_config -> native handle."""
         self.up_axis_idx = 2
+        table, ball = scene.asset_geometry(self.cfg["scene"])         # pingpong_table.urdf / small_ball.urdf when the cfg names them (TT:496,502)
         self.native_config = scene.build_config(self.VARIANT, cfg=self.cfg, num_envs=self.num_envs, seed=self._seed,
-                                                device_id=self.device_id, env_id_offset=self._env_id_offset)
+                                                device_id=self.device_id, env_id_offset=self._env_id_offset, table=table, ball=ball)
         k = self.control_freq_inv
         if k < 1:
             raise ValueError("controlFrequencyInv must be >= 1")
@@ -391,8 +392,10 @@ class HumanoidPingpongTiltNESSparse27DOF(VecTask):
         if self.control_freq_inv != 1:
             raise NotImplementedError("controlFrequencyInv != 1 is not wired for the 27-dof task (its yaml has none; "
                                       "cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml)")
+        table, ball = scene.asset_geometry(self.cfg.get("scene", {}))     # TA:551,557
+        scene_cfg = scene.build_ta_scene(self.num_envs, device_id=self.device_id, table=table, ball=ball) if (table or ball) else None
         with torch.cuda.device(self.device):
-            self.env = TAEnv(self.num_envs, device=self.device, seed=self._seed, env_id_offset=self._env_id_offset, env=env)
+            self.env = TAEnv(self.num_envs, device=self.device, seed=self._seed, env_id_offset=self._env_id_offset, env=env, scene_cfg=scene_cfg)
         e = self.env
         self.root_states = self.vec_root_states = e.root_states
         self.vec_dof_states = e.dof_states

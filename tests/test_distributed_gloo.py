@@ -232,6 +232,9 @@ def _grad_bucket_worker(rank, world, port, out_dir):
         b(name, ts)
     assert b.names == ["heads", "layer2"] and b.bytes == (8 * 64 + 8 + 12 + 4) * 4
     b.wait()
+    b("heads", [torch.zeros(3)])             # the next backward: names / bytes describe one backward, they do not grow for ever
+    assert b.names == ["heads"] and b.bytes == 12
+    b.wait()
     if rank == 0:
         torch.save(layers, os.path.join(out_dir, "buckets.pt"))
     dist.barrier()

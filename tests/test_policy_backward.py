@@ -320,6 +320,28 @@ def test_native_actor_critic_module_is_an_ordinary_differentiable_torch_module()
 
 
 @pytest.mark.gpu
+def test_backward_refuses_a_gradient_of_an_overwritten_forward():
+    """The activation buffers are the learner's own: a second forward before the first loss.backward() used to give silently wrong
+    gradients; now the backward of the stale graph raises, and accumulate + on_grads (double-reduced sums) is refused too."""
+    import torch
+    from isaacgym_amd.policy import NativeActorCritic
+    gen = torch.Generator().manual_seed(12)
+    m, num_obs, num_act, units = 128, 80, 7, (128, 64)
+    net = NativeActorCritic(_mlp(torch, num_obs, units, num_act, gen), _mlp(torch, num_obs, units, 1, gen), num_obs, "cuda:0", normalize_input=False)
+    x1, x2 = torch.randn(m, num_obs, generator=gen).cuda(), torch.randn(m, num_obs, generator=gen).cuda()
+    mu_old, _ = net(x1)                               # e.g. the old policy's evaluation ...
+    mu_new, v_new = net(x2)                           # ... then the new one's, same row count
+    with pytest.raises(RuntimeError, match="forward #1, but the activation buffers hold forward #2"):
+        mu_old.sum().backward()
+    (mu_new.sum() + v_new.sum()).backward()           # the latest forward's backward is the valid one
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters() if p.requires_grad)
+    lr = net.learner
+    d_head = torch.ones(m, num_act + 1, device="cuda")
+    with pytest.raises(ValueError, match="accumulate"):
+        lr.backward(d_head, accumulate=True, on_grads=lambda name, tensors: None)
+
+
+@pytest.mark.gpu
 def test_learner_forward_backward_is_graph_capturable():
     """The minibatch step's native part only enqueues (no allocation, no synchronisation once its buffers exist): RunningMeanStd update + forward +
     backward captured into one HIP graph; a replay reproduces the eager gradients bit for bit."""

@@ -252,6 +252,78 @@ def test_rlgames_state_dict_layout_is_parsed():
         layers_from_rlgames_state_dict({k: v for k, v in sd.items() if "critic_mlp" not in k})
 
 
+def test_rlgames_state_dict_layout_round_trips():
+    """CPU: rlgames_state_dict_from_layers is the inverse of layers_from_rlgames_state_dict (keys, shapes, values), and the
+    RunningMeanStd module saves / restores under rl_games' own buffer names, refreshing the fp32 tensors the kernels read IN PLACE."""
+    import torch
+    from isaacgym_amd.policy import RunningMeanStd, layers_from_rlgames_state_dict, rlgames_state_dict_from_layers
+    sd = _rlgames_state_dict(torch, 80, (64, 32, 16), 7, torch.Generator().manual_seed(1))
+    actor, critic = layers_from_rlgames_state_dict(sd)
+    rms = RunningMeanStd(80, "cpu")
+    assert sorted(rms.state_dict()) == ["count", "running_mean", "running_var"]          # mean / inv_std are derived, not saved
+    held_mean, held_inv = rms.mean, rms.inv_std                                          # what NativeMLP.set_normalization_tensors keeps
+    rms.load_state_dict({k.split(".", 1)[1]: v.double() for k, v in sd.items() if k.startswith("running_mean_std.")})
+    assert held_mean is rms.mean and held_inv is rms.inv_std
+    assert torch.allclose(held_mean, sd["running_mean_std.running_mean"].float())
+    assert torch.allclose(held_inv, torch.rsqrt(sd["running_mean_std.running_var"].float() + 1e-5))
+    back = rlgames_state_dict_from_layers(actor, critic, sigma=sd["a2c_network.sigma"], rms=rms)
+    assert sorted(back) == sorted(k for k in sd if not k.startswith("value_mean_std."))
+    for k, v in back.items():
+        assert v.shape == sd[k].shape and torch.equal(v.to(sd[k].dtype), sd[k]), k
+        assert v.data_ptr() != sd[k].data_ptr()                                         # clones
+
+
+@pytest.mark.gpu
+def test_actor_critic_checkpoint_round_trip_keeps_the_input_normaliser(tmp_path):
+    """A policy trained with normalize_input, saved with model.state_dict() (what rl_games does), comes back with its statistics: the
+    restored module, and the rl_games-layout export through from_rlgames and RLGamesPolicy, all reproduce mu / value exactly."""
+    import torch
+    from isaacgym_amd.policy import NativeActorCritic, RLGamesPolicy
+    gen = torch.Generator().manual_seed(21)
+    m, num_obs, num_act, units = 256, 80, 7, (256, 128)
+
+    def mlp(n_out):
+        layers, d = [], num_obs
+        for u in units + (n_out,):
+            layers.append((torch.randn(u, d, generator=gen) / d ** 0.5, torch.randn(u, generator=gen) * 0.1))
+            d = u
+        return layers
+    net = NativeActorCritic(mlp(num_act), mlp(1), num_obs, "cuda:0", normalize_input=True)
+    net.train()
+    for _ in range(3):                                  # training-mode forwards move the statistics away from mean 0 / var 1
+        net((torch.randn(m, num_obs, generator=gen) * 3.0 + 2.0).cuda())
+    assert float(net.running_mean_std.running_mean.abs().min()) > 0.5 and float(net.running_mean_std.count) == 1 + 3 * m
+    with torch.no_grad():
+        net.sigma.fill_(-1.5)
+    net.eval()
+    obs = (torch.randn(m, num_obs, generator=gen) * 3.0 + 2.0).cuda()
+    with torch.no_grad():
+        mu, value = (t.clone() for t in net(obs))
+    sd = net.state_dict()
+    assert {"running_mean_std.running_mean", "running_mean_std.running_var", "running_mean_std.count"} <= set(sd)
+    path = tmp_path / "native.pth"
+    torch.save(sd, path)
+    fresh = NativeActorCritic(mlp(num_act), mlp(1), num_obs, "cuda:0", normalize_input=True)      # other weights, statistics at their defaults
+    fresh.load_state_dict(torch.load(path, weights_only=True))
+    fresh.eval()
+    with torch.no_grad():
+        mu2, value2 = fresh(obs)
+    assert torch.equal(mu2, mu) and torch.equal(value2, value)
+    # ... and in rl_games' layout
+    rl = net.to_rlgames_state_dict()
+    assert rl["a2c_network.actor_mlp.2.weight"].shape == (128, 256) and rl["running_mean_std.count"].dtype == torch.float64
+    again = NativeActorCritic.from_rlgames(rl, "cuda:0")
+    again.eval()
+    with torch.no_grad():
+        mu3, value3 = again(obs)
+    assert torch.equal(mu3, mu) and torch.equal(value3, value) and torch.equal(again.sigma, net.sigma)
+    torch.save({"model": {k: v.cpu() for k, v in rl.items()}}, tmp_path / "rl.pth")
+    pol = RLGamesPolicy.load(str(tmp_path / "rl.pth"), "cuda:0")
+    act, val = pol.act(obs, deterministic=True)
+    assert torch.equal(act, torch.clamp(mu, -1.0, 1.0)) and torch.equal(val, value)
+    assert torch.allclose(pol.sigma, torch.full((num_act,), float(np.exp(-1.5)), device="cuda"))
+
+
 @pytest.mark.gpu
 def test_rlgames_checkpoint_is_served_by_the_native_forward(tmp_path):
     """A checkpoint file with rl_games' layout, loaded with weights_only, played deterministically: actions and de-normalised values

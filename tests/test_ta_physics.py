@@ -31,11 +31,16 @@ TOL = dict(root_pos=1e-4 * 1.0, root_quat=2e-4, root_vel=5e-4 * 10.0, q=1e-4 * 3
            rb_vel=5e-4 * 20.0, rb_ang=5e-4 * 100.0)   # a link's angular velocity stacks up to seven joint rates of <= 37 rad/s
 
 
-def ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root_after, rel=1e-6, seed=7):
+def ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root_after, rel=1e-6, seed=7, dof_after=None):
     """Envs whose ball sits on a switch of the contact model in this step, decided by the ORACLE alone (as helpers.SensitivityProbe
     does for the 7-dof tasks): two more oracle steps from the same state with the continuous inputs jittered by `rel`; an env whose
     oracle ball velocity moves by more than 1e-3 m/s under that jitter took a discrete decision (contact on / off, bounce threshold)
-    that fp32 and fp64 may legitimately take differently.  -> bool [N], True = on a switch."""
+    that fp32 and fp64 may legitimately take differently.  -> bool [N], True = on a switch.
+    dof_after (the oracle's stepped dof tensor; only the tests of an asset that does NOT stand level pass it): also set aside an env whose
+    ORACLE joint velocities move by more than a third of their tolerance under the same jitter — a sole corner on the steep part of the
+    contact ramp (round 4: the second URDF asset's left leg is 3 cm longer, its left sole starts 3 cm inside the ground; one env-step in
+    57 600 had the oracle's own ankle rate move by 0.3-0.7 rad/s, 15-35 x the tolerance, under a 1e-6 jitter, and the kernel arithmetic on
+    the host differed from the oracle there by MORE than the GPU did)."""
     rng = np.random.default_rng(seed)
     bad = np.zeros(root0.shape[0], bool)
     for _ in range(2):
@@ -43,6 +48,8 @@ def ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root_after, rel=1e-6
         d2 = (dof0 * (1.0 + rel * rng.uniform(-1, 1, dof0.shape))).astype(np.float32)
         oracle_lib.ta_simulate(cfg, m, act, r2, d2, threads=8)
         bad |= np.abs(r2[:, 2, 7:10] - root_after[:, 2, 7:10]).max(axis=1) > 1e-3
+        if dof_after is not None:
+            bad |= np.abs(d2[..., 1] - dof_after[..., 1]).max(axis=1) > TOL["qd"] / 3.0
     return bad
 
 
@@ -288,22 +295,30 @@ def test_ta_chain_kernel_step_matches_oracle(oracle_lib, monkeypatch, n):
     """The chain-wave kernel (one lane per env, one wave per limb: ppenv_ta_chain.hip) through ppenv_ta_step, against the oracle's
     rigid-body step followed by its post_physics_step, restarted from the oracle's tensors every step.  n = 1000 / 50 leave a
     ragged last workgroup; episodeLength 40 makes every env reset (with the keyed draws) inside the run."""
-    import torch
     from isaacgym_amd.tensor_api import TAEnv
     monkeypatch.setenv("PPENV_TA_KERNEL", "chain")
     cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
     env = TAEnv(n, device="cuda:0", seed=11, env={"episodeLength": 40}, materialize_rb=True, share_initial_rb=(n != 50))   # n = 50: the reference's per-env [N,42,13]
     assert env.sim.kernel == "chain" and env.initial_rb_states.shape[0] == (n if n == 50 else 1)
+    run_chain_step_parity(oracle_lib, env, cfg, m, f"gpu 27-dof chain-wave step vs oracle [n={n}]")
+    env.close()
+
+
+def run_chain_step_parity(oracle_lib, env, cfg, m, label, steps=90, min_resets_per_env=2, joint_probe=False):
+    """A TAEnv on the chain-wave kernel against the oracle's rigid-body step + post_physics_step with the same scene `cfg` and tree `m`,
+    restarted from the oracle's tensors every step (also used by tests/test_urdf.py for a library built for another asset)."""
+    import torch
+    n = env.num_envs
     p = env.params
     root, dof = env.root_states.cpu().numpy().copy(), env.dof_states.cpu().numpy().copy()
     irb = env.initial_rb_states.cpu().numpy().copy()
     flags, episode, progress = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int64)
     rng = np.random.default_rng(5)
     oa = _ta_obs_atol()
-    log = ExclusionLog(f"gpu 27-dof chain-wave step vs oracle [n={n}]", bound=0.005)
+    log = ExclusionLog(label, bound=0.005)
     resets = 0
     act = None
-    for t in range(90):
+    for t in range(steps):
         if t % 4 == 0:
             act = rng.uniform(-1.2, 1.2, (n, 27)).astype(np.float32)
             act[: n // 3] *= 0.1
@@ -313,7 +328,7 @@ def test_ta_chain_kernel_step_matches_oracle(oracle_lib, monkeypatch, n):
         env.step(torch.from_numpy(act).cuda())
         root0, dof0 = root.copy(), dof.copy()
         rb, frc, pvx = oracle_lib.ta_simulate(cfg, m, act, root, dof, threads=8)         # root / dof: stepped in place (pre-reset)
-        switch = ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root, seed=200 + t)
+        switch = ball_switch_probe(oracle_lib, cfg, m, act, root0, dof0, root, seed=200 + t, dof_after=dof if joint_probe else None)
         obs, rew, reset = oracle_lib.ta_post_physics_step(p, rb, irb, root, dof, frc, pvx, None, flags, episode, progress)
         g_rb = env._rb_states.cpu().numpy()
         np.testing.assert_array_equal(env.pre_ball_vx.cpu().numpy(), pvx)
@@ -345,10 +360,9 @@ def test_ta_chain_kernel_step_matches_oracle(oracle_lib, monkeypatch, n):
         assert_close(env.rew_buf.cpu().numpy()[keep], rew[keep], f"step {t}: rew", atol=1e-4 * 3000.0 * 0.5)   # alpha |vx| dominates (TA:1590)
         resets += int(reset.sum())
         flags[~keep] = env.state.flags.cpu().numpy().view(np.uint32)[~keep]                 # continue from a common state
-    assert resets >= 2 * n
+    assert resets >= min_resets_per_env * n
     log.close()
     assert env.sim.status == 0
-    env.close()
 
 
 @pytest.mark.gpu

@@ -275,6 +275,102 @@ def test_second_arm_asset_through_modelgen_into_the_kernel_arithmetic(oracle_lib
     assert moved > 0.5          # rad/s: the stock arm steps elsewhere from the same state
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The scene's other two assets: pingpong_table.urdf / small_ball.urdf (TT:496,502) -> the run-time slabs and ball constants
+def test_table_and_ball_urdf_importers_against_typed_in_numbers():
+    import urdf_assets
+    t = urdf.table_scene(urdf.parse(urdf_assets.TABLE_URDF))
+    # slab: the first <collision> (shape 0, the one the reference gives the table material, TT:580-582): 2.70 x 1.50 x 0.025 centred at
+    # (0.01, 0, 0.7375) -> top face at 0.75; net: 0.006 x 1.80 x 0.14 on a fixed joint at (0.01, 0, 0.75), collision origin +0.07 in z
+    expect = dict(length=2.70, width=1.50, top_z=0.75, slab=0.025, net_height=0.14, net_overhang=0.15, net_half_thickness=0.003, net_bottom_z=0.75)
+    for k, v in expect.items():
+        assert abs(t[k] - v) < 1e-12, (k, t[k], v)
+    assert t["offset_xy"] == (0.01, 0.0) and t["net_offset_xy"] == (0.01, 0.0)
+    assert t["ignored"] == [("leg_near", 0), ("leg_far", 0)]                      # legs below the surface, inside the footprint: no ball shape
+    b = urdf.ball_params(urdf.parse(urdf_assets.BALL_URDF))
+    assert b["radius"] == 0.0205 and b["mass"] == 0.0027
+    assert abs(b["inertia_factor"] - 6.8079e-07 / (0.0027 * 0.0205 ** 2)) < 1e-15 and abs(b["inertia_factor"] - 0.6) < 1e-4
+    # ... and into the config the kernels and the oracle read
+    cfg, stock = scene.build_config("TT", num_envs=4, table=t, ball=b), scene.build_config("TT", num_envs=4)
+    np.testing.assert_allclose(list(cfg.table.center), (1.75 + 0.01, 0.0, 0.7375), atol=1e-6)           # table actor at (1.75, 0, 0), TT:575
+    np.testing.assert_allclose(list(cfg.table.half), (1.35, 0.75, 0.0125), atol=1e-7)
+    np.testing.assert_allclose(list(cfg.net.center), (1.76, 0.0, 0.82), atol=1e-6)
+    np.testing.assert_allclose(list(cfg.net.half), (0.003, 0.90, 0.07), atol=1e-7)
+    assert cfg.ball_radius == np.float32(0.0205) and abs(cfg.ball_inertia_factor - 0.6) < 1e-4
+    assert (cfg.table.restitution, cfg.table.friction) == (stock.table.restitution, stock.table.friction)   # materials are the task's, not the file's
+    assert abs(stock.table.center[2] - 0.745) < 1e-6 and stock.ball_radius == np.float32(0.02)             # the placeholders differ
+    ta = scene.build_ta_scene(4, table=t, ball=b)
+    assert list(ta.table.half) == list(cfg.table.half) and ta.ball_radius == cfg.ball_radius
+
+
+def test_table_and_ball_importers_reject_what_the_kernels_cannot_represent():
+    import urdf_assets
+    T, B = urdf_assets.TABLE_URDF, urdf_assets.BALL_URDF
+    with pytest.raises(ValueError, match="rotated off"):                             # a slab yawed by 30 degrees is not an axis-aligned box
+        urdf.table_scene(urdf.parse(T.replace('<origin xyz="0.01 0 0.7375" rpy="0 0 0"/>', '<origin xyz="0.01 0 0.7375" rpy="0 0 0.5236"/>')))
+    with pytest.raises(ValueError, match="must be boxes"):
+        urdf.table_scene(urdf.parse(T.replace('<box size="0.006 1.80 0.14"/>', '<sphere radius="0.07"/>')))
+    with pytest.raises(ValueError, match="fixed joints only"):
+        urdf.table_scene(urdf.parse(T.replace('<joint name="net_joint" type="fixed">', '<joint name="net_joint" type="revolute">')))
+    with pytest.raises(ValueError, match="exactly one box standing"):                # no net: the net joint dropped 5 cm into the slab
+        urdf.table_scene(urdf.parse(T.replace('<origin xyz="0.01 0 0.75" rpy="0 0 0"/><parent link="table_top"/><child link="net"/>',
+                                              '<origin xyz="0.01 0 0.70" rpy="0 0 0"/><parent link="table_top"/><child link="net"/>')))
+    with pytest.raises(ValueError, match="sticks out"):                              # a leg outside the slab's footprint
+        urdf.table_scene(urdf.parse(T.replace('<origin xyz="1.0 0 0.3625" rpy="0 0 0"/>', '<origin xyz="1.5 0 0.3625" rpy="0 0 0"/>')))
+    with pytest.raises(ValueError, match="not its largest"):                         # shape 0 must be the playing surface
+        urdf.table_scene(urdf.parse(T.replace('<box size="2.70 1.50 0.025"/>', '<box size="0.1 0.1 0.025"/>')))
+    with pytest.raises(ValueError, match="not isotropic"):
+        urdf.ball_params(urdf.parse(B.replace('iyy="6.8079e-07"', 'iyy="9e-07"')))
+    with pytest.raises(ValueError, match="one sphere"):
+        urdf.ball_params(urdf.parse(B.replace('<sphere radius="0.0205"/>', '<box size="0.04 0.04 0.04"/>')))
+    with pytest.raises(ValueError, match="centre of mass"):
+        urdf.ball_params(urdf.parse(B.replace('<inertial><origin xyz="0 0 0"/>', '<inertial><origin xyz="0.001 0 0"/>')))
+    with pytest.raises(ValueError, match="unknown keys"):
+        scene.build_config("TT", num_envs=1, table=dict(lenght=2.7))
+
+
+def test_table_and_ball_from_urdf_reach_the_kernel_arithmetic(oracle_lib, tmp_path):
+    """The kernels' per-env arithmetic (host shim) follows the oracle on a scene whose table and ball come from the two URDFs — through
+    the cfg hook a task uses (scene.table_urdf / ball_urdf paths) — and the placeholder scene steps elsewhere from the same state."""
+    import shim_binding as sb
+    import urdf_assets
+    from helpers import ExclusionLog, SensitivityProbe, assert_close, assert_state_close, mask_envs, obs_atol, reward_atol
+    (tmp_path / "pingpong_table.urdf").write_text(urdf_assets.TABLE_URDF)
+    (tmp_path / "small_ball.urdf").write_text(urdf_assets.BALL_URDF)
+    task_cfg = scene.default_task_cfg("TT")
+    task_cfg["scene"] = dict(task_cfg["scene"], table_urdf=str(tmp_path / "pingpong_table.urdf"), ball_urdf=str(tmp_path / "small_ball.urdf"))
+    table, ball = scene.asset_geometry(task_cfg["scene"])
+    assert (table, ball) == urdf_assets.second_scene_geometry()
+    n = 128
+    cfg, stock_cfg = scene.build_config("TT", cfg=task_cfg, num_envs=n, seed=4, table=table, ball=ball), scene.build_config("TT", num_envs=n, seed=4)
+    o, s, o_stock = oracle_lib.OracleEnv(cfg), sb.ShimEnv(cfg), oracle_lib.OracleEnv(stock_cfg)
+    probe = SensitivityProbe(oracle_lib, cfg)
+    log = ExclusionLog("host shim on the URDF table + ball vs oracle [TT]", bound=0.005)
+    rng = np.random.default_rng(3)
+    oa, ra = obs_atol(), reward_atol(cfg)
+    moved = 0.0
+    for t in range(120):
+        actions = rng.uniform(-1.0, 1.0, (n, 7)).astype(np.float32)
+        s.copy_state_from(o)
+        st = o.get_state()
+        o_stock.set_state(st)
+        o.step(actions)
+        s.step(actions)
+        o_stock.step(actions)
+        same_reset = o_stock.reset_buf == o.reset_buf
+        moved = max(moved, float(np.abs(o_stock.ball[:3, same_reset] - o.ball[:3, same_reset]).max()) if same_reset.any() else 0.0)     # ball is SoA [13][N]
+        keep = ~probe.sensitive(st, actions, o)
+        log.add(keep)
+        sm, om = mask_envs(s, keep), mask_envs(o, keep)
+        np.testing.assert_array_equal(sm.reset_buf, om.reset_buf)
+        np.testing.assert_array_equal(sm.flags, om.flags)
+        assert_state_close(sm, om, f"urdf table + ball, step {t}")
+        assert_close(sm.obs_buf, om.obs_buf, f"urdf table + ball, obs step {t}", atol=oa)
+        assert_close(sm.rew_buf, om.rew_buf, f"urdf table + ball, rew step {t}", atol=ra)
+    log.close()
+    assert moved > 5e-3          # m: a bounce off a table 1 cm lower with a 0.5 mm larger ball lands elsewhere than the placeholder scene's
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("mapping", ["default", "lane"])
@@ -368,4 +464,90 @@ def test_gpu_7dof_step_on_a_library_built_for_the_second_arm_asset(oracle_lib):
         assert_close(gm.obs_buf, om.obs_buf, f"second arm on the GPU, obs step {t}", atol=oa)
         assert_close(gm.rew_buf, om.rew_buf, f"second arm on the GPU, rew step {t}", atol=ra)
     log.close()
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["TT", "T4"])
+def test_gpu_fused_step_on_a_table_and_ball_from_urdf(oracle_lib, variant):
+    """pingpong_table.urdf / small_ball.urdf stand-ins -> urdf.table_scene / ball_params -> scene.build_config(table=, ball=): the fused HIP
+    step (two-wave kernel; the 4-actor three-wave kernel) follows the oracle on that scene, and the placeholder scene steps elsewhere."""
+    import torch
+    import urdf_assets
+    from helpers import ExclusionLog, SensitivityProbe, assert_close, assert_state_close, mask_envs, obs_atol, reward_atol
+    from isaacgym_amd.env import PPEnv
+    from test_gpu_parity import DevView
+    n = 512
+    table, ball = urdf_assets.second_scene_geometry()
+    cfg, cfg2 = (scene.build_config(variant, num_envs=n, seed=6, table=table, ball=ball) for _ in range(2))
+    stock_cfg = scene.build_config(variant, num_envs=n, seed=6)
+    assert bytes(cfg) != bytes(stock_cfg)
+    env = PPEnv(cfg2, device="cuda:0")
+    o, o_stock = oracle_lib.OracleEnv(cfg), oracle_lib.OracleEnv(stock_cfg)
+    probe = SensitivityProbe(oracle_lib, cfg)
+    log = ExclusionLog(f"gpu fused step on the URDF table + ball vs oracle [{variant}, n={n}]", bound=0.005)
+    rng = np.random.default_rng(8)
+    A = 2 if variant == "T4" else 1
+    oa, ra = obs_atol(), A * reward_atol(cfg)
+    moved = 0.0
+    for t in range(120):
+        a = rng.uniform(-1.0, 1.0, (A * n, 7)).astype(np.float32)
+        st = o.get_state()
+        env.set_state(st)
+        o_stock.set_state(st)
+        o.step(a)
+        o_stock.step(a)
+        env.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        same_reset = o_stock.reset_buf[::A] == o.reset_buf[::A]
+        if same_reset.any():
+            moved = max(moved, float(np.abs(o_stock.ball[:3, same_reset] - o.ball[:3, same_reset]).max()))
+        keep = ~probe.sensitive(st, a, o)
+        log.add(keep)
+        gm, om = mask_envs(DevView(env), keep, A), mask_envs(o, keep, A)
+        np.testing.assert_array_equal(gm.reset_buf, om.reset_buf)
+        np.testing.assert_array_equal(gm.flags, om.flags)
+        assert_state_close(gm, om, f"urdf table + ball on the GPU, step {t}")
+        assert_close(gm.obs_buf, om.obs_buf, f"urdf table + ball on the GPU, obs step {t}", atol=oa)
+        assert_close(gm.rew_buf, om.rew_buf, f"urdf table + ball on the GPU, rew step {t}", atol=ra)
+    log.close()
+    assert moved > 5e-3
+    env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_chain_kernel_of_a_library_built_for_the_second_27dof_asset(oracle_lib, monkeypatch):
+    """urdf.ta_model -> _lib.build_for_ta_model: THAT library runs the changed tree on ta_chain_kernel (the 30-us-class kernel the default
+    library reserves for its own compiled tree) and follows the oracle given the same tables, on a scene whose table and ball come from the
+    URDF stand-ins too; the stock tree is in turn NOT this library's compiled model."""
+    import ctypes as C
+
+    import torch
+    import urdf_assets
+    from helpers import ExclusionLog
+    from isaacgym_amd import _lib
+    from isaacgym_amd.tensor_api import TAEnv, TASim
+    from test_ta_physics import initial_tensors, run_chain_step_parity
+    monkeypatch.delenv("PPENV_TA_KERNEL", raising=False)
+    n = 640
+    table, ball = urdf_assets.second_scene_geometry()
+    cfg, m, base = scene.build_ta_scene(n, table=table, ball=ball), urdf_assets.second_27dof_model(), scene.build_ta_model()
+    L = _lib.load(urdf_assets.build_second_ta_library())
+    assert L.ppenv_ta_model_is_compiled(C.byref(cfg), C.byref(m)) == 1 and _lib.lib().ppenv_ta_model_is_compiled(C.byref(cfg), C.byref(m)) == 0
+    assert L.ppenv_ta_model_is_compiled(C.byref(cfg), C.byref(base)) == 0
+    stock = TASim(n, device="cuda:0", scene_cfg=cfg, model=base, library=L)            # the other way round: table-driven for the stock tree
+    assert stock.kernel == "quad"
+    stock.close()
+    env = TAEnv(n, device="cuda:0", seed=13, env={"episodeLength": 40}, materialize_rb=True, scene_cfg=cfg, model=m, library=L)
+    assert env.sim.kernel == "chain"
+    # the placeholder tree steps elsewhere from the same state: the compiled tables are the asset's
+    root, dof = initial_tensors(64, seed=21)
+    act = np.random.default_rng(22).uniform(-1.2, 1.2, (64, 27)).astype(np.float32)
+    r3, d3 = root.copy(), dof.copy()
+    cfg64 = scene.build_ta_scene(64, table=table, ball=ball)
+    for _ in range(8):
+        oracle_lib.ta_simulate(cfg64, m, act, root, dof, threads=8)
+        oracle_lib.ta_simulate(cfg64, base, act, r3, d3, threads=8)
+    assert float(np.abs(d3[..., 1] - dof[..., 1]).max()) > 0.5
+    run_chain_step_parity(oracle_lib, env, cfg, m, f"gpu chain-wave kernel compiled for the second URDF asset vs oracle [n={n}]", joint_probe=True)
     env.close()

@@ -9,6 +9,7 @@ from isaacgym_amd import scene, urdf
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANT_DIR = os.path.join(ROOT, "build_variants", "second_arm")          # git-ignored; travels to the GPU box with the snapshot
+TA_VARIANT_DIR = os.path.join(ROOT, "build_variants", "second_ta")        # the chain-wave kernel compiled for second_27dof_model()
 ARM_JOINTS = [f"right_{n}_joint" for n in ("shoulder_pitch", "shoulder_roll", "shoulder_yaw", "elbow", "wrist_roll", "wrist_pitch", "wrist_yaw")]
 
 MASS_SCALE = 1.3
@@ -46,3 +47,49 @@ def build_second_arm_library(force=False):
     with second_arm_tables():
         cfg = scene.build_config("TT", num_envs=1)
     return _lib.build_for_arm_model(cfg, VARIANT_DIR, force=force)
+
+
+def build_second_ta_library(force=False):
+    """libppenv with the changed 27-dof tree compiled into the chain-wave kernel -> its path (isaacgym_amd._lib.build_for_ta_model)."""
+    from isaacgym_amd import _lib
+    return _lib.build_for_ta_model(second_27dof_model(), TA_VARIANT_DIR, force=force)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The scene's other two assets (the reference's pingpong_table.urdf / small_ball.urdf, TT:496,502 — neither is in the reference).
+# Hand-written stand-ins that DIFFER from scene.TABLE_GEOM / BALL_GEOM; tests/test_urdf.py types the expected numbers in.
+TABLE_URDF = """<?xml version="1.0"?>
+<robot name="pingpong_table">
+  <link name="table_top">
+    <inertial><mass value="40"/><inertia ixx="8" iyy="25" izz="32" ixy="0" ixz="0" iyz="0"/></inertial>
+    <collision><origin xyz="0.01 0 0.7375" rpy="0 0 0"/><geometry><box size="2.70 1.50 0.025"/></geometry></collision>
+  </link>
+  <link name="net">
+    <collision><origin xyz="0 0 0.07" rpy="0 0 0"/><geometry><box size="0.006 1.80 0.14"/></geometry></collision>
+  </link>
+  <joint name="net_joint" type="fixed"><origin xyz="0.01 0 0.75" rpy="0 0 0"/><parent link="table_top"/><child link="net"/></joint>
+  <link name="leg_near">
+    <collision><origin xyz="0 0 0" rpy="0 0 1.5707963267948966"/><geometry><box size="1.2 0.05 0.725"/></geometry></collision>
+  </link>
+  <joint name="leg_near_joint" type="fixed"><origin xyz="-1.0 0 0.3625" rpy="0 0 0"/><parent link="table_top"/><child link="leg_near"/></joint>
+  <link name="leg_far">
+    <collision><origin xyz="0 0 0" rpy="0 0 1.5707963267948966"/><geometry><box size="1.2 0.05 0.725"/></geometry></collision>
+  </link>
+  <joint name="leg_far_joint" type="fixed"><origin xyz="1.0 0 0.3625" rpy="0 0 0"/><parent link="table_top"/><child link="leg_far"/></joint>
+</robot>
+"""
+
+BALL_URDF = """<?xml version="1.0"?>
+<robot name="small_ball">
+  <link name="ball">
+    <inertial><origin xyz="0 0 0"/><mass value="0.0027"/>
+      <inertia ixx="6.8079e-07" iyy="6.8079e-07" izz="6.8079e-07" ixy="0" ixz="0" iyz="0"/></inertial>
+    <collision><origin xyz="0 0 0"/><geometry><sphere radius="0.0205"/></geometry></collision>
+  </link>
+</robot>
+"""
+
+
+def second_scene_geometry():
+    """(table, ball) dicts for scene.build_config / build_ta_scene, through the importers."""
+    return urdf.table_scene(urdf.parse(TABLE_URDF)), urdf.ball_params(urdf.parse(BALL_URDF))
