@@ -160,16 +160,17 @@ def cpu_baseline_ta(num_envs, cores, target_seconds):
             "sample": f"{steps} steps of the TA variant at num_envs={n}, OpenMP over envs in the rigid-body step, {dt:.1f} s"}
 
 
-def pmc_traffic(num_envs, variant=VARIANT):
+def pmc_traffic(num_envs, variant=VARIANT, kernel=None):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).
     bench.py cannot collect counters itself; null when no profile of this kernel at this workload size is committed."""
     import glob
     best = None
-    kernel = kernel_name(variant).replace(" ", "").rstrip(">")
+    norm = lambda name: name.replace(" ", "").replace("pp::", "").rstrip(">")     # older profiles: no namespace, fewer template arguments (defaults added later)
+    kernel = norm(kernel or kernel_name(variant))                                  # kernel: the name the handle reports (ppenv_step_kernel_name)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
         d = json.load(open(f))
-        k = d.get("kernel", "").replace(" ", "").rstrip(">")      # a profile may name the kernel with fewer template arguments (defaults added later)
+        k = norm(d.get("kernel", ""))
         if d.get("num_envs") == num_envs and k and (kernel.startswith(k) or k.startswith(kernel)):
             best = d["hbm_bytes_per_launch"]
     return best
@@ -440,7 +441,7 @@ def hbm_roofline(variant, n, kernel_us, region_us=None, region=None, observed_ke
     algo = ALGO_BYTES[variant]
     achieved = algo * n / (kernel_us * 1e-6) / 1e9
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "traffic": pmc_traffic(n, variant), "kernel": observed_kernel or kernel_name(variant), "avg_kernel_us": kernel_us,
+         "traffic": pmc_traffic(n, variant, observed_kernel), "kernel": observed_kernel or kernel_name(variant), "avg_kernel_us": kernel_us,
          "algorithmic_bytes_per_launch": algo * n,
          "traffic_source": "committed rocprofv3 --pmc passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE), not a counter read in this run"}
     if region_us is not None:

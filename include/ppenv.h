@@ -487,6 +487,9 @@ int ppenv_ta_sim_device(const ppenv_ta_sim* sim);
  * 0 = one lane per env (any tree).  PPENV_TA_KERNEL=chain|quad|lane forces one. */
 uint32_t ppenv_ta_sim_status(const ppenv_ta_sim* sim);
 int ppenv_ta_sim_kernel(const ppenv_ta_sim* sim);
+/* sim_params.gravity of the 27-DoF simulation (its yaml's randomization_params.sim_params.gravity, 27DOFG1.yaml:123-124; the task's own value
+ * is -9.8, TA:384-386): takes effect for every launch enqueued on `stream` after the call.  gravity_z <= 0. */
+int ppenv_ta_sim_set_gravity(ppenv_ta_sim* sim, float gravity_z, void* stream);
 /* ... and by name, as rocprofv3 prints it ("ta_chain_kernel<false>", "ta_chain_kernel<true>" with a randomisation set, ...). */
 const char* ppenv_ta_sim_kernel_name(const ppenv_ta_sim* sim);
 /* Domain randomisation of the 27-DoF task (cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml carries the same task.randomization_params block as the

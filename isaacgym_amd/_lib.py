@@ -150,6 +150,7 @@ def load(path):
     L.ppenv_status.argtypes = [vp]
     L.ppenv_step_kernel_name.restype = C.c_char_p
     L.ppenv_step_kernel_name.argtypes = [vp]
+    L.ppenv_ta_sim_set_gravity.argtypes = [vp, C.c_float, vp]
     L.ppenv_ta_sim_kernel_name.restype = C.c_char_p
     L.ppenv_ta_sim_kernel_name.argtypes = [vp]
     L.ppenv_ta_pd_targets.argtypes = [vp, C.c_int32, vp, vp, vp]

@@ -358,6 +358,9 @@ __global__ __launch_bounds__((A + BW) * kBlock) void step_kernel_split(const Ste
 #define PP_BALL_STORES_DOFS 1      // profiling builds: 0 = the arm wave stores the dof state of the one-humanoid variants too (it waits for the reset decision)
 #endif
     constexpr bool kBallStoresDofs = A == 1 && PP_BALL_STORES_DOFS;
+    // With several ball waves each publishes s_flag_ball = 1 on its own and the arm wave's wait is satisfied by the FIRST of them: were the arm wave to
+    // read the reset decisions of all 64 envs after that wait (the PP_BALL_STORES_DOFS=0 diagnostic build), it would race with the slower ball waves.
+    static_assert(A != 1 || BW == 1 || kBallStoresDofs, "BW > 1 needs PP_BALL_STORES_DOFS: the arm wave must not read s_reset behind a flag any one ball wave sets");
     __shared__ float s_geom[G ? 2 : 1][G ? A : 1][G ? kGeo : 1][G ? kBlock : 1];   // geometry of boundary s in slot s & 1
     __shared__ int s_gflag[A];                         // arm -> ball: boundaries whose geometry is in LDS
     __shared__ int s_bflag;                            // ball -> arm: substeps the ball has finished (slot reuse)

@@ -254,17 +254,27 @@ __device__ __forceinline__ LinkC dr_link(const LinkC& L, float ms, float kps, fl
 __device__ __forceinline__ float ta_dr_gauss(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t progress, uint32_t index) {
     return dr_gauss(seed, gid, episode, 2u * progress + (index >> 8), index & 255u);
 }
-struct DrKeys { const TAChainArgs* a; int env, n; uint32_t gid, ep, prog; };   // what a limb's load() needs to fetch its table entries and draw its action noise
+// Round 4: the per-env scales live in LDS, not in registers.  A limb's 3 N scales (21 for the seven-link arm) used to stay in VGPRs across the
+// whole role — on a kernel that sits at the 256-register limit six waves on four SIMDs impose, that was 245 spilled VGPRs (300 B of scratch per lane)
+// in the <true> instantiation.  Now load() parks them in [row][64] tiles like every other per-env quantity of this kernel (each lane reads back only
+// what it wrote itself: DS operations of a wave execute in order, no hand-off involved) and link_of() reads the three a link needs where it is used.
+struct DrShared { float kp[NDOF][kE], kd[NDOF][kE], ms[NL][kE]; };    // 82 rows x 256 B = 21 KB, DR instantiation only
+typedef __attribute__((address_space(3))) DrShared* DrLds;
+struct DrKeys { const TAChainArgs* a; int env, n; uint32_t gid, ep, prog; DrLds tab; };   // what a limb's load() needs to fetch its table entries and draw its action noise
 
 // ---- one limb: the three passes over a compile-time chain ---------------------------------------------------------------
 template <int FIRST, int N, bool DR = false>
 struct Limb {
     float q[N], qd[N], target[N], force[N];
-    float kps[DR ? N : 1], kds[DR ? N : 1], mss[DR ? N : 1];   // DR: this env's scales of the limb's links
+    DrLds tab;                                                  // DR: this env's scales of the limb's links, column `lane` of the LDS tables
+    int lane;
     LinkSave sv[N];
     JointOut jo[N];
     template <int K>
-    __device__ __forceinline__ LinkC link_of() const { return dr_link<DR>(T::link(FIRST + K), mss[DR ? K : 0], kps[DR ? K : 0], kds[DR ? K : 0]); }
+    __device__ __forceinline__ LinkC link_of() const {
+        if constexpr (!DR) return T::link(FIRST + K);
+        else return dr_link<true>(T::link(FIRST + K), tab->ms[FIRST + K][lane], tab->kp[FIRST - 1 + K][lane], tab->kd[FIRST - 1 + K][lane]);
+    }
 
     // pass 1: kinematics outwards from the parent's frame; GEO(link, frame) sees every link (collision geometry capture)
     template <class GEO>
@@ -316,6 +326,7 @@ struct Limb {
     // (the staging leaves the raw actions in S.act_frc: the clamp and the map onto the joint range happen here, where the joint is a
     // compile-time constant — in the staging loop the lanes of a wave look at different dofs and the limits were a table lookup)
     __device__ __forceinline__ void load(const Shared& S, int e, float clip_actions, const DrKeys& dk = DrKeys{}) {
+        tab = dk.tab; lane = e;
         static_for<N>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr LinkC L = T::link(FIRST + k);
@@ -324,9 +335,9 @@ struct Limb {
             float act = S.act_frc[d][e];
             if constexpr (DR) {                                       // this env's table entries (a NULL table = scale 1); the action noise goes in before the clamp
                 const TAChainArgs& a = *dk.a;
-                kps[k] = a.dr_kp ? a.dr_kp[(size_t)d * dk.n + dk.env] : 1.f;
-                kds[k] = a.dr_kd ? a.dr_kd[(size_t)d * dk.n + dk.env] : 1.f;
-                mss[k] = a.dr_ms ? a.dr_ms[(size_t)(FIRST + k) * dk.n + dk.env] : 1.f;
+                tab->kp[d][e] = a.dr_kp ? a.dr_kp[(size_t)d * dk.n + dk.env] : 1.f;
+                tab->kd[d][e] = a.dr_kd ? a.dr_kd[(size_t)d * dk.n + dk.env] : 1.f;
+                tab->ms[FIRST + k][e] = a.dr_ms ? a.dr_ms[(size_t)(FIRST + k) * dk.n + dk.env] : 1.f;
                 if (a.dr_act_sigma > 0.f) act += a.dr_act_sigma * ta_dr_gauss(a.p.seed, dk.gid, dk.ep, dk.prog, (uint32_t)d);
             }
             target[k] = pd_target(act, L.lo, L.hi, clip_actions);   // VecTask.step clamp + TA:1131, 729-733
@@ -631,8 +642,12 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     }
     __syncthreads();
 
-    DrKeys dk{&a, env, n, (uint32_t)(a.p.env_id_offset + env), 0u, 0u};
-    if constexpr (DR) { dk.ep = a.episode[env]; dk.prog = (uint32_t)a.progress[env]; }   // the noise keys: episode / progress at the step's start
+    DrKeys dk{&a, env, n, (uint32_t)(a.p.env_id_offset + env), 0u, 0u, nullptr};
+    if constexpr (DR) {
+        __shared__ DrShared Sdr;                                       // (only this instantiation carries it: 120 KB + 21 KB of the CU's 160 KB)
+        dk.tab = (DrLds)&Sdr;
+        dk.ep = a.episode[env]; dk.prog = (uint32_t)a.progress[env];   // the noise keys: episode / progress at the step's start
+    }
 
     CH_STAMP(1);
     // ---- physics: every wave runs its own role, start to finish (its limb's state lives in ITS registers only; the substep loop is
@@ -997,9 +1012,17 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             // observation noise (yaml: observations / gaussian / additive): on the finished tile, after the reward has been computed from the clean
             // state and before the row leaves (and before the policy's copy of it is made) — index 32 + k, clear of the 27 action draws
             if (a.dr_obs_sigma > 0.f) {
-                for (int t = tid; t < nvalid * PPENV_TA_NUM_OBS; t += kThreads) {
-                    const int ee = t / PPENV_TA_NUM_OBS, k = t - ee * PPENV_TA_NUM_OBS;
-                    S.u.obs[t] += a.dr_obs_sigma * ta_dr_gauss(a.p.seed, (uint32_t)(a.p.env_id_offset + e0 + ee), __float_as_uint(S.torso[0][ee]), __float_as_uint(S.torso[1][ee]), 32u + (uint32_t)k);
+                // a work item is a PAIR of neighbouring values: indices 32 + 2 j and 32 + 2 j + 1 share their Box-Muller radius and angle (dr_gauss_pair)
+                constexpr int kPairs = (PPENV_TA_NUM_OBS + 1) / 2;
+                for (int t = tid; t < nvalid * kPairs; t += kThreads) {
+                    const int ee = t / kPairs, j = t - ee * kPairs;
+                    const uint32_t index = 32u + 2u * (uint32_t)j;                   // ta_dr_gauss's folding of the 512-wide index space, for an even index
+                    float gc, gs;
+                    dr_gauss_pair(a.p.seed, (uint32_t)(a.p.env_id_offset + e0 + ee), __float_as_uint(S.torso[0][ee]), 2u * __float_as_uint(S.torso[1][ee]) + (index >> 8),
+                                  (index & 255u) >> 1, gc, gs);
+                    float* o = &S.u.obs[ee * PPENV_TA_NUM_OBS + 2 * j];
+                    o[0] += a.dr_obs_sigma * gc;
+                    if (2 * j + 1 < PPENV_TA_NUM_OBS) o[1] += a.dr_obs_sigma * gs;
                 }
             }
             __syncthreads();       // (S.dead is the same for every thread of the workgroup after B3)

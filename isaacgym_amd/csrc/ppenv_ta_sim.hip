@@ -674,6 +674,24 @@ void ppenv_ta_sim_destroy(ppenv_ta_sim* s) {
     delete s;
 }
 
+// sim_params.gravity of this simulation (cfg/task/HumanoidPingpongTiltNESSparse27DOFG1.yaml:123-124 randomises it): the humanoid's links read it from the
+// model constants (by value in the chain-wave kernel's argument, in device memory for the table-driven kernels), the ball from StepConsts — both
+// copies are refreshed in stream order, so every launch enqueued after this call on `stream` steps under the new value.
+int ppenv_ta_sim_set_gravity(ppenv_ta_sim* s, float gravity_z, void* stream) {
+    if (!s) { ppenv_set_error("ppenv_ta_sim_set_gravity: NULL handle"); return PPENV_EINVAL; }
+    if (!(gravity_z <= 0.f)) { ppenv_set_error("gravity_z must be <= 0 (the world's up axis is z)"); return PPENV_EINVAL; }
+    if (int rc = ta_use_device(s)) return rc;
+    s->host.sc.gravity_z = gravity_z;
+    s->K.gdv = gravity_z * s->K.hb;
+    // pageable host sources: staged before the calls return
+    if (hipMemcpyAsync(s->dev, &s->host, sizeof(TAConsts), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+        hipMemcpyAsync(s->devK, &s->K, sizeof(StepConsts), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+        ppenv_set_error("ppenv_ta_sim_set_gravity: uploading the constants failed");
+        return PPENV_EHIP;
+    }
+    return PPENV_OK;
+}
+
 // The kernel ppenv_ta_step launches for this handle now (demangled, as rocprofv3's kernel trace shows it).
 const char* ppenv_ta_sim_kernel_name(const ppenv_ta_sim* s) {
     if (!s) return "";

@@ -272,6 +272,16 @@ class NativeMLP:
         if max_rows:
             self._alloc(max_rows)
 
+    def sibling(self, max_rows=None):
+        """Another forward context on the SAME operand images and statistics (no copy: one set of weights in HBM / L2) with its own
+        activation buffers — one per env group when groups of envs are stepped on separate streams (collector.PipelinedRollout)."""
+        other = object.__new__(NativeMLP)
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("h", "head_out", "mu", "value", "x16", "_rows")})
+        other._rows = 0
+        if max_rows:
+            other._alloc(max_rows)
+        return other
+
     def load(self, actor, critic):
         """fp32 master weights -> the fp16 operand images (actor | critic stacked per layer)."""
         h = lambda t: t.detach().to(self.device, torch.float16).contiguous()
@@ -574,6 +584,21 @@ class NativeActorCritic(torch.nn.Module):
         actor = [(self.hidden_w[i][0], self.hidden_b[i][0]) for i in range(len(lr.net.units))] + [(self.mu_w, self.mu_b)]
         critic = [(self.hidden_w[i][1], self.hidden_b[i][1]) for i in range(len(lr.net.units))] + [(self.value_w, self.value_b)]
         return rlgames_state_dict_from_layers(actor, critic, sigma=self.sigma, rms=lr.rms)
+
+    def _ordered(self):
+        return list(self.hidden_w) + list(self.hidden_b) + [self.mu_w, self.mu_b, self.value_w, self.value_b]
+
+    def _versions(self):
+        return tuple(p._version for p in self._ordered())
+
+    def forward(self, obs):
+        if obs.shape[0] % 64:
+            raise ValueError(f"NativeActorCritic: {obs.shape[0]} rows; the minibatch must be a multiple of 64")
+        v = self._versions()
+        if v != self._seen:                          # an optimizer stepped (or a state dict was loaded): recast the operand images
+            self.learner.sync_weights()
+            self._seen = v
+        return _ActorCriticFn.apply(self, obs, *self._ordered())
 
 
 # ---- a trained rl_games checkpoint on the native forward (the reference's `train.py test=True checkpoint=...` play mode) ---------------

@@ -855,6 +855,9 @@ TASK_CFGS["TA"] = dict(
 )
 
 
+TA_GRAVITY_Z = -9.8      # TA:383-385 (the task overrides its yaml's -9.81 as the 7-dof tasks do)
+
+
 def build_ta_scene(num_envs, device_id=0, table=None, ball=None):
     """The ppenv_config part of the 27-DoF scene (ball, table, net, contact scalars, dt ...) with the humanoid's ball-collision
     shapes re-attached to links of the 28-link tree (ppenv_ta_model).  table / ball: as in build_config (TA:551,557)."""

@@ -102,6 +102,11 @@ class TASim:
         """Which kernel ppenv_ta_step launches: 'chain' (one lane per env, one wave per limb), 'quad' or 'lane'."""
         return {2: "chain", 1: "quad", 0: "lane"}[int(self.L.ppenv_ta_sim_kernel(self.h))]
 
+    def set_gravity(self, gravity_z):
+        """sim_params.gravity (ppenv_ta_sim_set_gravity): every later step of this simulation runs under gravity_z (<= 0)."""
+        self._ck(self.L.ppenv_ta_sim_set_gravity(self.h, float(gravity_z), self._stream()))
+        self.scene.gravity_z = float(gravity_z)
+
     @property
     def kernel_name(self):
         """... by the name rocprofv3's kernel trace shows (ppenv_ta_sim_kernel_name; 'ta_chain_kernel<true>' while a randomisation is set)."""
@@ -271,6 +276,9 @@ class TAEnv:
 
     def clear_randomization(self):
         self.sim.clear_randomization()
+
+    def set_gravity(self, gravity_z):
+        self.sim.set_gravity(gravity_z)
 
     def reset_idx(self, env_ids=None):
         """_reset_idx (TA:965-1028) outside a step, for the listed env ids (None: all).  A rare host-driven path: plain torch

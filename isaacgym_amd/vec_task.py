@@ -170,8 +170,8 @@ class VecTask:
         if obs:
             kw["observation_noise_sigma"] = float(obs["range"][1]) * sched(obs)
         g = (dr_params.get("sim_params") or {}).get("gravity")
-        if g and hasattr(self, "native_config"):      # (the 27-dof task keeps its gravity: its scene constants are uploaded once at create time)
-            base = self.native_config.gravity_z
+        if g:      # one value per simulation; the 27-dof task re-uploads its scene constants (ppenv_ta_sim_set_gravity)
+            base = self.native_config.gravity_z if hasattr(self, "native_config") else scene.TA_GRAVITY_Z
             dz = float(sample(g, (1,)).item()) if g.get("operation") == "additive" else 0.0
             self.env.set_gravity(min(base + dz, 0.0) if g.get("operation") == "additive" else base * float(sample(g, (1,)).item()))
         hum = ((dr_params.get("actor_params") or {}).get("humanoid") or {})

@@ -778,12 +778,13 @@ void ppo_set_serve_override(ppo_env* e, const float* serve /* [N,3] */, int on) 
 
 /* -------------------------------------------------------------------- the step */
 /* additive Gaussian white noise of the domain randomisation (yaml:106-113): Box-Muller on two counter-RNG draws keyed by
- * (seed, global env id, episode, progress * 256 + index); float arithmetic, the same in the kernel (ppenv_device.h dr_gauss) */
+ * (seed, global env id, episode, progress * 256 + index).  Indices 2 j and 2 j + 1 share their (u1, u2) and take the cosine / the sine branch,
+ * as in the kernel (ppenv_device.h dr_gauss_pair); libm here, the hardware's log2 / sqrt / sin / cos there: equal to ~1e-6 of a unit normal. */
 static float dr_gauss(uint64_t seed, uint32_t gid, uint32_t episode, uint32_t progress, uint32_t index) {
-    uint32_t k = progress * 256u + index;
+    uint32_t k = progress * 256u + (index & ~1u);
     float u1 = rng_uniform(seed ^ 0x5DEECE66Dull, gid, episode, 2u * k), u2 = rng_uniform(seed ^ 0x5DEECE66Dull, gid, episode, 2u * k + 1u);
     float rad = sqrtf(-2.0f * logf(fmaxf(u1, 5.9604645e-8f)));
-    return rad * cosf(6.2831853f * u2);
+    return (index & 1u) ? rad * sinf(6.2831853f * u2) : rad * cosf(6.2831853f * u2);
 }
 
 static void step_env(ppo_env* e, int i, const float* actions) {

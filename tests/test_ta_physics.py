@@ -304,6 +304,46 @@ def test_ta_chain_kernel_step_matches_oracle(oracle_lib, monkeypatch, n):
     env.close()
 
 
+@pytest.mark.gpu
+def test_ta_gravity_setter_reaches_every_kernel(oracle_lib, monkeypatch):
+    """ppenv_ta_sim_set_gravity (the yaml's randomization_params.sim_params.gravity for this task, 27DOFG1.yaml:123-124): the chain-wave
+    step — links through the by-value constants, ball through StepConsts in device memory — and the table-driven kernels follow the oracle
+    under the new gravity; the VecTask hook draws and applies it (round 3 skipped the key in silence)."""
+    import torch
+    import isaacgym_amd
+    from isaacgym_amd.tensor_api import TAEnv, TASim
+    monkeypatch.setenv("PPENV_TA_KERNEL", "chain")
+    n, gz = 320, -6.5
+    cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
+    cfg.gravity_z = gz
+    env = TAEnv(n, device="cuda:0", seed=17, env={"episodeLength": 40}, materialize_rb=True)
+    env.set_gravity(gz)
+    run_chain_step_parity(oracle_lib, env, cfg, m, f"gpu 27-dof chain-wave step under gravity {gz} vs oracle [n={n}]", steps=50, min_resets_per_env=1)
+    env.close()
+    monkeypatch.setenv("PPENV_TA_KERNEL", "quad")
+    sim = TASim(64, device="cuda:0")
+    sim.set_gravity(gz)
+    cfg64 = scene.build_ta_scene(64)
+    cfg64.gravity_z = gz
+    root, dof = initial_tensors(64, seed=3)
+    act = np.random.default_rng(4).uniform(-1, 1, (64, 27)).astype(np.float32)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    root_d, dof_d = dev(root), dev(dof)
+    rb_d, frc_d, pvx_d = torch.zeros(64, 42, 13, device="cuda"), torch.zeros(64, 27, device="cuda"), torch.zeros(64, device="cuda")
+    sim.simulate(dev(act), root_d, dof_d, rb_d, frc_d, pvx_d)
+    rb, frc, _ = oracle_lib.ta_simulate(cfg64, m, act, root, dof, threads=8)
+    check_step((root_d.cpu().numpy(), dof_d.cpu().numpy(), rb_d.cpu().numpy(), frc_d.cpu().numpy()), (root, dof, rb, frc), "quad kernel under the new gravity")
+    assert abs(float(root_d[0, 2, 9]) - (1.2 + 0.0)) > 0 and abs((root[0, 2, 9] - initial_tensors(64, seed=3)[0][0, 2, 9]) - gz * 0.0083) < 2e-3   # the ball fell by gz dt
+    sim.close()
+    with pytest.raises(isaacgym_amd._lib.PPEnvError, match="<= 0"):
+        TASim(8, device="cuda:0").set_gravity(1.0)
+    monkeypatch.delenv("PPENV_TA_KERNEL")
+    task = isaacgym_amd.make(task="HumanoidPingpongTiltNESSparse27DOFG1", num_envs=64, seed=2)
+    task.randomize, task.first_randomization, task.last_step, task.last_rand_step = True, True, 0, -1
+    task.apply_randomizations({"frequency": 1, "sim_params": {"gravity": {"range": [0.0, 0.4], "operation": "additive", "distribution": "gaussian"}}})
+    assert task.env.sim.scene.gravity_z != np.float32(scene.TA_GRAVITY_Z) and task.env.sim.scene.gravity_z <= 0.0
+
+
 def run_chain_step_parity(oracle_lib, env, cfg, m, label, steps=90, min_resets_per_env=2, joint_probe=False):
     """A TAEnv on the chain-wave kernel against the oracle's rigid-body step + post_physics_step with the same scene `cfg` and tree `m`,
     restarted from the oracle's tensors every step (also used by tests/test_urdf.py for a library built for another asset)."""

@@ -13,6 +13,6 @@ echo "== bench" | tee -a gpurun_out/progress.log
 timeout -k 10 600 python bench.py --steps 2000 --warmup 200 > gpurun_out/bench.json 2> gpurun_out/bench.err || { tail -20 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/bench.json
 echo "== rocprofv3 kernel trace" | tee -a gpurun_out/progress.log
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline > gpurun_out/bench_prof.json 2> gpurun_out/prof.err || { tail -20 gpurun_out/prof.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-configs > gpurun_out/bench_prof.json 2> gpurun_out/prof.err || { tail -20 gpurun_out/prof.err; exit 1; }
 cat gpurun_out/bench_prof.json
 find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -12 $f; done
