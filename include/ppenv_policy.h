@@ -42,6 +42,14 @@ typedef struct ppenv_mlp_layer {
  * workgroup, the largest that still gives three quarters of the CUs a workgroup); everything else the register-staged ones. */
 int ppenv_mlp_layer_forward(const ppenv_mlp_layer* layer, void* stream);
 
+/* The same launch with its grid sized for `cus` of the 256 CUs (0 = the whole chip, what ppenv_mlp_layer_forward does): the tile is
+ * chosen so that the layer is about one workgroup per CU of that share.  For env GROUPS stepped on separate streams (the reference's
+ * rollout is policy -> env -> policy per env, tasks/humanoid_pingpong_3_actor_all_dof.py:965-1028 under rl_games' play_steps; groups of
+ * envs are independent): with cus = 128 two groups' layers run side by side — one group's loads and stores under the other's MFMAs,
+ * and the 64-CU env step of one under the other's forward — instead of each launch claiming every CU in turn.  Same results as
+ * ppenv_mlp_layer_forward bit for bit (the tile choice does not change the summation order along k). */
+int ppenv_mlp_layer_forward_share(const ppenv_mlp_layer* layer, int32_t cus, void* stream);
+
 /* The first layer's input as its own small launch, so that layer 1 runs on the LDS-DMA kernels too:
  * out[m, ld_out] (fp16) = clamp((obs[m, k] - mean) * inv_std, -clip, clip) in columns < k, zero in columns k .. ld_out - 1
  * (ld_out: k rounded up to a multiple of 64; layer 1's weight rows are zero-padded to the same length).  mean / inv_std NULL: cast

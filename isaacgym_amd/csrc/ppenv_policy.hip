@@ -17,6 +17,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/ppenv.h"
 #include "../../include/ppenv_policy.h"
@@ -434,11 +435,21 @@ __device__ unsigned long long mlp_stamp_buf[256 * 8 * 32];
         __builtin_amdgcn_sched_barrier(0);                                                            \
         if (lane == 0 && blockIdx.x < 256 && blockIdx.y == 0) mlp_stamp_buf[(blockIdx.x * 8 + wave) * 32 + (k)] = t_; \
     } while (0)
+// the constant 100 MHz clock (s_memrealtime): comparable across workgroups and CUs, unlike the shader clock
+#define PPM_STAMP_RT(k)                                                                               \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (lane == 0 && blockIdx.x < 256 && blockIdx.y == 0) mlp_stamp_buf[(blockIdx.x * 8 + wave) * 32 + (k)] = t_; \
+    } while (0)
 #else
 #define PPM_STAMP_AT(k) do { } while (0)
+#define PPM_STAMP_RT(k) do { } while (0)
 #endif
 #ifndef PP_EXP
-#define PP_EXP 0          // timing experiments (diagnostic builds): 1 no fragment reads, 2 no DMA, 4 no barriers in the K loop — results are wrong
+#define PP_EXP 0          // timing experiments (diagnostic builds): 1 no fragment reads, 2 no DMA, 4 no barriers in the K loop, 8 no MFMAs, 16 no epilogue (8, 16: the ring kernel only) — results are wrong
 #endif
 #define PPM_TILE_STAMP(j) do { if (t == 8) PPM_STAMP_AT(j); else if (t == 9) PPM_STAMP_AT(9 + (j)); } while (0)
 
@@ -460,6 +471,7 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
     const int n0 = (id % tiles_n) * BN, m0 = (id / tiles_n) * BM, b = blockIdx.y;
     const _Float16* W = a.w + (size_t)b * a.w_stride;
     const _Float16* in = reinterpret_cast<const _Float16*>(a.in) + (size_t)b * a.in_stride;
+    PPM_STAMP_RT(27); PPM_STAMP_AT(26);
 
     // staging: thread -> (row tid >> 3 (+ 64 per issue), slot tid & 7) of the tile; its source k-chunk is slot ^ ((row >> 1) & 7)
     const int srow = tid >> 3, kc = (lane & 7) ^ ((srow >> 1) & 7);
@@ -549,6 +561,7 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
     PP_VM(2);
     PP_BARRIER();
     if (wm == 1) PP_BARRIER();                                     // group 1 runs one barrier behind
+    PPM_STAMP_AT(25);
     for (int t = 0; t < ktiles; t++) {
         const _Float16* tile = smem + (t & 1) * (BM + BN) * BK;
         const bool more = t + 1 < ktiles && !(PP_EXP & 2);
@@ -589,7 +602,7 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
     PPM_STAMP_AT(31);
     if constexpr (M16) epilogue16<8, NT>(a, acc16, smem, m0 + wm * 128, n0 + wn * 16 * NT, b);
     else epilogue<TI, TJ>(a, acc, smem, m0 + wm * 128, n0 + wn * 64, b);
-    PPM_STAMP_AT(29);
+    PPM_STAMP_AT(29); PPM_STAMP_RT(28);
 }
 
 // ---- the same scheme on 128-row tiles, for the layers whose 256 x 256 grid would leave CUs idle (M = 4096: SURVEY.md §8(f)) ----
@@ -599,17 +612,23 @@ __global__ __launch_bounds__(512) void mlp_layer_pp_kernel(const Args a, const i
 // group reads them, so the ring is three tiles deep and a phase issues tile t + 2: vmcnt(pieces of one tile) before the barrier that
 // ends tile t leaves exactly tile t + 2 in flight.  The buffer written in phase t is the one read in phase t - 1, one barrier
 // earlier for the other group: every wave therefore waits for its fragment reads (lgkmcnt(0)) BEFORE its barrier, not after.
-template <int TJ>
+//
+// S: the depth of the ring (a tile issued in phase t is read in phase t + S - 1).
+// (Round 4 tried S = 5 on the 128 x 128 tile on that theory — 5 x 32 KB, all of the CU's 160 KB: 15.8 / 10.5 us against 14.7 / 10.1 on the
+// 1024 -> 512 / 512 -> 512 layers at M = 4096.  The phase is NOT bound by the stream's latency; see mlp_layer_pp2_kernel for what it is bound by.)
+template <int TJ, int S = 3>
 __global__ __launch_bounds__(512) void mlp_layer_pp1_kernel(const Args a, const int tiles_n, const int tiles_m) {
     constexpr int BM = 128, BN = 128 * TJ, BK = 64, TI = 2, NA = 2, NB = 2 * TJ, P = NA + NB, TILE = (BM + BN) * BK;
-    constexpr int kOperand = 3 * TILE, kPatch = 8 * 64 * PATCH_LD;
-    __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];   // three [A | B] tiles; afterwards the epilogue patches
+    constexpr int kOperand = S * TILE, kPatch = 8 * 64 * PATCH_LD;
+    static_assert(S >= 3 && S <= 5 && (S - 2) * P <= 63 && kOperand * 2 <= 160 * 1024, "ring depth: vmcnt is a 6-bit count, the CU has 160 KB of LDS");
+    __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];   // S [A | B] tiles; afterwards the epilogue patches
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
     const int nwg = tiles_n * tiles_m, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     const int n0 = (id % tiles_n) * BN, m0 = (id / tiles_n) * BM, b = blockIdx.y;
     const _Float16* W = a.w + (size_t)b * a.w_stride;
     const _Float16* in = reinterpret_cast<const _Float16*>(a.in) + (size_t)b * a.in_stride;
+    PPM_STAMP_RT(27); PPM_STAMP_AT(26);
 
     const int srow = tid >> 3, kc = (lane & 7) ^ ((srow >> 1) & 7);
     const _Float16* pa[NA];
@@ -641,20 +660,34 @@ __global__ __launch_bounds__(512) void mlp_layer_pp1_kernel(const Args a, const 
     for (int kk = 0; kk < 4; kk++) swz[kk] = ((2 * kk + h) ^ ((r >> 1) & 7)) * 8;
     const int arow = (wm * 64 + r) * BK, brow = BM * BK + (wn * 32 * TJ + r) * BK;
     h8 fa[TI][4], fb[TJ][4];
-#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PP_WAIT_TILE(more) do { if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); if (!(PP_EXP & 4)) __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// wait until all but the `ahead` youngest TILES (P pieces each) of this wave's DMAs have landed; ahead is wave-uniform
+#define PP_WAIT_TILES(ahead)                                                                                        \
+    do {                                                                                                             \
+        const int ah_ = (PP_EXP & 2) ? 0 : (ahead);                                                                                     \
+        if (S >= 5 && ah_ >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * P) : "memory");                      \
+        else if (S >= 4 && ah_ == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * P) : "memory");                 \
+        else if (ah_ >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");                               \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    } while (0)
     const int ktiles = a.k / BK;
-    stage(0, 0);
-    if (ktiles > 1) stage(1, BK);
-    PP_WAIT_TILE(ktiles > 1);
+#pragma unroll
+    for (int s = 0; s < S - 1; s++) if (s < ktiles) stage(s, s * BK);
+    {   // tile 0 must have landed: tiles 1 .. min(S - 2, ktiles - 1) may stay in flight
+        const int ahead0 = ktiles - 1 < S - 2 ? ktiles - 1 : S - 2;
+        PP_WAIT_TILES(ahead0);
+    }
     PP_BARRIER();
     if (wm == 1) PP_BARRIER();                                     // group 1 runs one barrier behind
     int buf = 0;
-    PPM_STAMP_AT(30);
+    PPM_STAMP_AT(30); PPM_STAMP_AT(25);
     for (int t = 0; t < ktiles; t++) {
         const _Float16* tile = smem + buf * TILE;
-        const bool more = t + 2 < ktiles;
+        // after this phase's issue the wave has tiles t + 1 .. min(t + S - 1, ktiles - 1) outstanding; tile t + 1 must land before the barrier
+        // that ends the phase: all but the youngest min(S - 2, ktiles - t - 2) tiles
+        const int rem = ktiles - t - 2, ahead = rem < 0 ? 0 : (rem < S - 2 ? rem : S - 2);
         PPM_TILE_STAMP(0);
+        if (!((PP_EXP & 1) && t > 0)) {
 #pragma unroll
         for (int i = 0; i < TI; i++)
 #pragma unroll
@@ -663,37 +696,302 @@ __global__ __launch_bounds__(512) void mlp_layer_pp1_kernel(const Args a, const 
         for (int j = 0; j < TJ; j++)
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) fb[j][kk] = *reinterpret_cast<const h8*>(&tile[brow + j * 32 * BK + swz[kk]]);
-        const int wbuf = buf == 0 ? 2 : buf - 1;                   // (t + 2) % 3: the buffer read in phase t - 1
+        }
+        const int wbuf = buf == 0 ? S - 1 : buf - 1;               // (t + S - 1) % S: the buffer read in phase t - 1
         PPM_TILE_STAMP(1);
-        if (more) stage(wbuf, (t + 2) * BK);
+        if (t + S - 1 < ktiles && !(PP_EXP & 2)) stage(wbuf, (t + S - 1) * BK);
         PPM_TILE_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PPM_TILE_STAMP(3);
-        if (wm == 1) PP_WAIT_TILE(more);
+        if (wm == 1) PP_WAIT_TILES(ahead);
         PPM_TILE_STAMP(4);
         PP_BARRIER();
         PPM_TILE_STAMP(5);
-        __builtin_amdgcn_s_setprio(1);
+        if (!(PP_EXP & 32)) __builtin_amdgcn_s_setprio(1);
+        if (!((PP_EXP & 8) && t > 0)) {
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
 #pragma unroll
             for (int i = 0; i < TI; i++)
 #pragma unroll
                 for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        }
+        if (!(PP_EXP & 32)) __builtin_amdgcn_s_setprio(0);
         PPM_TILE_STAMP(6);
-        if (wm == 0) PP_WAIT_TILE(more);
+        if (wm == 0) PP_WAIT_TILES(ahead);
         PPM_TILE_STAMP(7);
         PP_BARRIER();
         PPM_TILE_STAMP(8);
+        buf = buf == S - 1 ? 0 : buf + 1;
+    }
+    if (wm == 0) PP_BARRIER();
+#undef PP_BARRIER
+#undef PP_WAIT_TILES
+    PPM_STAMP_AT(31);
+    if (PP_EXP & 16) { if (acc[0][0][0] == 123.f) reinterpret_cast<_Float16*>(a.out)[0] = 1; return; }     // experiment: no epilogue
+    epilogue<TI, TJ>(a, acc, smem, m0 + wm * 64, n0 + wn * 32 * TJ, b);
+    PPM_STAMP_AT(29); PPM_STAMP_RT(28);
+}
+
+// ---- the ring kernel with the DMA issue moved out of the read phase (round 4) ----
+//
+// tools/gpu_mlp_exp1.py (builds with one ingredient of the K loop removed, profiles/r04_b_mlp_exp1.txt): at M = 4096 the K loop of
+// mlp_layer_pp1_kernel runs at half the matrix cores' rate — a barrier interval lasts as long as the READING group's phase (fragment reads,
+// its share of the DMA issue at 100-185 cycles a piece, the waits), 800-1000 cycles against 256 TJ cycles of MFMAs in the other group.
+// Here the LEADING group (wm = 0) issues every piece of tile t + 2 between the MFMAs of tile t, where a piece costs ~60 cycles and the
+// matrix cores keep running; the read phases of both groups are fragment reads only.  Only the leading group has DMAs outstanding, so only
+// it waits (vmcnt(2P): all but tile t + 2) before the barrier that releases tile t + 1 — to itself at once, to the lagging group one barrier
+// later.  Tile t + 2 overwrites the buffer of tile t - 1, which the lagging group finished reading (lgkmcnt(0)) before its first barrier of
+// iteration t - 1 = the leading group's second barrier of t - 1; the leading group issues after its first barrier of t.
+template <int TJ>
+__global__ __launch_bounds__(512) void mlp_layer_pp3_kernel(const Args a, const int tiles_n, const int tiles_m) {
+    constexpr int BM = 128, BN = 128 * TJ, BK = 64, TI = 2, NA = 2, NB = 2 * TJ, P2 = 2 * (NA + NB), TILE = (BM + BN) * BK;   // P2: pieces per LEADING wave and tile
+    constexpr int kOperand = 3 * TILE, kPatch = 8 * 64 * PATCH_LD;
+    static_assert(P2 % 4 == 0 && P2 <= 63, "a quarter of the pieces after each K sub-step");
+    __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];   // three [A | B] tiles; afterwards the epilogue patches
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int nwg = tiles_n * tiles_m, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int n0 = (id % tiles_n) * BN, m0 = (id / tiles_n) * BM, b = blockIdx.y;
+    const _Float16* W = a.w + (size_t)b * a.w_stride;
+    const _Float16* in = reinterpret_cast<const _Float16*>(a.in) + (size_t)b * a.in_stride;
+    PPM_STAMP_RT(27); PPM_STAMP_AT(26);
+
+    // staging by the four leading waves: piece (i, hf) of an operand = rows 64 i + 32 hf + 8 wn .. + 7 (one 1 KiB piece per wave), thread ->
+    // row srow = (tid & 255) >> 3 of the 32, 16-byte slot tid & 7 holding k-chunk slot ^ ((row >> 1) & 7) (32 hf and 64 i do not change that term)
+    const int srow = (tid & 255) >> 3, kc = (lane & 7) ^ ((srow >> 1) & 7);
+    unsigned offa[NA][2], offb[NB][2];                             // element offsets from `in` / W: 32-bit, the bases stay scalar
+#pragma unroll
+    for (int i = 0; i < NA; i++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) { const int ra = m0 + i * 64 + hf * 32 + srow; offa[i][hf] = (unsigned)(ra < a.m ? ra : a.m - 1) * (unsigned)a.lda + kc * 8; }
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) { const int rb = n0 + i * 64 + hf * 32 + srow; offb[i][hf] = (unsigned)(rb < a.n ? rb : a.n - 1) * (unsigned)a.ldw + kc * 8; }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    // piece q of a tile, q = 0 .. P2 - 1: A pieces first (what a phase reads first), then B
+    auto piece = [&](int buf, int k0, int q) {
+        if (q < 2 * NA) __builtin_amdgcn_global_load_lds((glb_ptr)(in + offa[q >> 1][q & 1] + k0), (lds_ptr)(smem + buf * TILE + ((q >> 1) * 64 + (q & 1) * 32 + wn * 8) * BK), 16, 0, 0);
+        else { const int qb = q - 2 * NA; __builtin_amdgcn_global_load_lds((glb_ptr)(W + offb[qb >> 1][qb & 1] + k0), (lds_ptr)(smem + buf * TILE + BM * BK + ((qb >> 1) * 64 + (qb & 1) * 32 + wn * 8) * BK), 16, 0, 0); }
+    };
+
+    f16v acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    int swz[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) swz[kk] = ((2 * kk + h) ^ ((r >> 1) & 7)) * 8;
+    const int arow = (wm * 64 + r) * BK, brow = BM * BK + (wn * 32 * TJ + r) * BK;
+    h8 fa[TI][4], fb[TJ][4];
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    const int ktiles = a.k / BK;
+    if (wm == 0) {
+#pragma unroll
+        for (int q = 0; q < P2; q++) piece(0, 0, q);
+        if (ktiles > 1) {
+#pragma unroll
+            for (int q = 0; q < P2; q++) piece(1, BK, q);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P2) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP_BARRIER();
+    if (wm == 1) PP_BARRIER();                                     // group 1 runs one barrier behind
+    int buf = 0;
+    PPM_STAMP_AT(30); PPM_STAMP_AT(25);
+    for (int t = 0; t < ktiles; t++) {
+        const _Float16* tile = smem + buf * TILE;
+        const bool more = t + 2 < ktiles;
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) fa[i][kk] = *reinterpret_cast<const h8*>(&tile[arow + i * 32 * BK + swz[kk]]);
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) fb[j][kk] = *reinterpret_cast<const h8*>(&tile[brow + j * 32 * BK + swz[kk]]);
+        const int wbuf = buf == 0 ? 2 : buf - 1;                   // (t + 2) % 3: the buffer of tile t - 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+#pragma unroll
+            for (int i = 0; i < TI; i++)
+#pragma unroll
+                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+            if (wm == 0 && more) {
+#pragma unroll
+                for (int q = 0; q < P2 / 4; q++) piece(wbuf, (t + 2) * BK, kk * (P2 / 4) + q);
+            }
+        }
+        if (wm == 0) { if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P2) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        PP_BARRIER();
         buf = buf == 2 ? 0 : buf + 1;
     }
     if (wm == 0) PP_BARRIER();
 #undef PP_BARRIER
-#undef PP_WAIT_TILE
     PPM_STAMP_AT(31);
     epilogue<TI, TJ>(a, acc, smem, m0 + wm * 64, n0 + wn * 32 * TJ, b);
-    PPM_STAMP_AT(29);
+    PPM_STAMP_AT(29); PPM_STAMP_RT(28);
+}
+
+// ---- K tiles taken in turn by the two wave groups (round 4): the narrow layers at the rollout's M = 4096 ----
+//
+// In mlp_layer_pp1_kernel both groups work on every K tile, each on its half of the workgroup's rows: per K tile a wave reads 8 + 4 TJ
+// fragments for 8 TJ MFMAs and meets two barriers, and a barrier interval lasts as long as the READING group needs (fragment reads, its
+// share of the DMA issue, the wait) — 800-1000 cycles against 256 TJ of MFMAs: the K tile of the 128 x 128 kernel takes 1600-2100 cycles for
+// 512 cycles of matrix work per SIMD (tools/gpu_mlp_phases.py; a deeper ring changed nothing — it is not the stream's latency).  Here
+// group t & 1 owns K tile t entirely: 4 waves as 2 x 2 over the 128 x BN tile, 64 x (32 TJW) per wave, twice the MFMAs per fragment read
+// (8 + 4 TJW reads for 8 TJW MFMAs) and ONE barrier per K tile — while one group multiplies tile t the other reads tile t + 1.  Each group
+// ends with a partial sum over its K tiles; they swap halves through LDS (group 0 finishes the left half of every wave tile, group 1 the
+// right half: sum = group 0's part + group 1's part on both sides) and all eight waves run the epilogue.
+//
+// Ring of R buffers, tile t in buffer t % R.  During interval t tile t is in its group's registers (read in interval t - 1, behind a barrier),
+// so its buffer takes tile t + R; tile t + 1 is being read, tiles t + 2 .. t + R are in flight or landed, and before the barrier that ends
+// the interval every wave waits for its pieces of tile t + 2: all but the youngest R - 2 tiles.
+template <int TJW, int R>
+__global__ __launch_bounds__(512) void mlp_layer_pp2_kernel(const Args a, const int tiles_n, const int tiles_m) {
+    constexpr int BM = 128, BN = 64 * TJW, BK = 64, TI = 2, TJH = TJW / 2, NA = 2, NB = BN / 64, P = NA + NB, TILE = (BM + BN) * BK;
+    constexpr int kOperand = R * TILE, kPatch = 8 * 64 * PATCH_LD, kSwap = 8 * TI * TJH * 16 * 64 * 2;   // in fp16 units (the swap area holds floats)
+    static_assert(TJW == 2 || TJW == 4, "wave tile 64 x 64 or 64 x 128");
+    static_assert(R >= 3 && R <= 5 && (R - 2) * P <= 63 && kOperand * 2 <= 160 * 1024 && kSwap <= kOperand, "ring depth / LDS");
+    __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int nwg = tiles_n * tiles_m, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int n0 = (id % tiles_n) * BN, m0 = (id / tiles_n) * BM, b = blockIdx.y;
+    const _Float16* W = a.w + (size_t)b * a.w_stride;
+    const _Float16* in = reinterpret_cast<const _Float16*>(a.in) + (size_t)b * a.in_stride;
+    PPM_STAMP_RT(27); PPM_STAMP_AT(26);
+
+    const int srow = tid >> 3, kc = (lane & 7) ^ ((srow >> 1) & 7);
+    const _Float16* pa[NA];
+    const _Float16* pb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; i++) { const int ra = m0 + i * 64 + srow; pa[i] = in + (size_t)(ra < a.m ? ra : a.m - 1) * a.lda + kc * 8; }
+#pragma unroll
+    for (int i = 0; i < NB; i++) { const int rb = n0 + i * 64 + srow; pb[i] = W + (size_t)(rb < a.n ? rb : a.n - 1) * a.ldw + kc * 8; }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) __builtin_amdgcn_global_load_lds((glb_ptr)(pa[i] + k0), (lds_ptr)(smem + buf * TILE + (i * 512 + wave * 64) * 8), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; i++) __builtin_amdgcn_global_load_lds((glb_ptr)(pb[i] + k0), (lds_ptr)(smem + buf * TILE + BM * BK + (i * 512 + wave * 64) * 8), 16, 0, 0);
+    };
+
+    f16v acc[TI][TJW];
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJW; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    int swz[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) swz[kk] = ((2 * kk + h) ^ ((r >> 1) & 7)) * 8;
+    const int arow = (wm * 64 + r) * BK, brow = BM * BK + (wn * 32 * TJW + r) * BK;
+    h8 fa[TI][4], fb[TJW][4];
+    auto read_frags = [&](const _Float16* tile) {
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) fa[i][kk] = *reinterpret_cast<const h8*>(&tile[arow + i * 32 * BK + swz[kk]]);
+#pragma unroll
+        for (int j = 0; j < TJW; j++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) fb[j][kk] = *reinterpret_cast<const h8*>(&tile[brow + j * 32 * BK + swz[kk]]);
+    };
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// wait until all but the `ahead` youngest TILES (P pieces each) of this wave's DMAs have landed; ahead is wave-uniform, 0 .. R - 2
+#define PP_WAIT_TILES(ahead)                                                                                        \
+    do {                                                                                                             \
+        const int ah_ = (ahead);                                                                                     \
+        if (R >= 5 && ah_ >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * P) : "memory");                      \
+        else if (R >= 4 && ah_ == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * P) : "memory");                 \
+        else if (ah_ >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");                               \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    } while (0)
+    const int ktiles = a.k / BK;
+#pragma unroll
+    for (int s = 0; s < R; s++) if (s < ktiles) stage(s, s * BK);
+    {   // tiles 0 and 1 must have landed (group 0 reads tile 0 now, group 1 reads tile 1 in interval 0): tiles 2 .. min(R, ktiles) - 1 may fly on
+        const int staged = ktiles < R ? ktiles : R, ahead0 = staged > 2 ? staged - 2 : 0;
+        PP_WAIT_TILES(ahead0);
+    }
+    PP_BARRIER();
+    if (grp == 0) { read_frags(smem); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    PP_BARRIER();                                                  // buffer 0 is free from here on
+    PPM_STAMP_AT(30); PPM_STAMP_AT(25);
+    int buf = 0;                                                   // t % R
+    for (int t = 0; t < ktiles; t++) {
+        const int nbuf = buf == R - 1 ? 0 : buf + 1;               // (t + 1) % R
+        if (t + R < ktiles) stage(buf, (t + R) * BK);
+        if (grp == (t & 1)) {
+            if (!(PP_EXP & 32)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int i = 0; i < TI; i++)
+#pragma unroll
+                    for (int j = 0; j < TJW; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+            if (!(PP_EXP & 32)) __builtin_amdgcn_s_setprio(0);
+        } else if (t + 1 < ktiles) {
+            read_frags(smem + nbuf * TILE);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // before the barrier: the next interval's DMA overwrites this buffer
+        }
+        // tile t + 2 is read in the next interval: of this wave's tiles t + 2 .. min(t + R, ktiles - 1) all but the first may stay in flight
+        const int rem = ktiles - t - 3, ahead = rem < 0 ? 0 : (rem < R - 2 ? rem : R - 2);
+        PP_WAIT_TILES(ahead);
+        PP_BARRIER();
+        buf = nbuf;
+    }
+#undef PP_WAIT_TILES
+    PPM_STAMP_AT(31);
+    // swap halves: a wave keeps columns [32 TJH g, 32 TJH (g + 1)) of its 64 x (32 TJW) tile and sends the other half to wave ^ 4 (same tile, other group)
+    f4v* swap = reinterpret_cast<f4v*>(smem);
+    auto send = [&](auto G) {                                      // G: this wave's group as a compile-time constant (register arrays need constant indices)
+        constexpr int g = decltype(G)::value;
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJH; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f16v& src = acc[i][(1 - g) * TJH + j];
+                    swap[(((wave * TI + i) * TJH + j) * 4 + q) * 64 + lane] = f4v{src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]};
+                }
+    };
+    if (grp == 0) send(std::integral_constant<int, 0>{}); else send(std::integral_constant<int, 1>{});
+    PP_BARRIER();
+#undef PP_BARRIER
+    f16v fin[TI][TJH];
+    auto take = [&](auto G) {
+        constexpr int g = decltype(G)::value;
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJH; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f4v got = swap[((((wave ^ 4) * TI + i) * TJH + j) * 4 + q) * 64 + lane];
+                    const f16v& own = acc[i][g * TJH + j];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) fin[i][j][4 * q + e] = g == 0 ? own[4 * q + e] + got[e] : got[e] + own[4 * q + e];   // group 0's part first on both sides
+                }
+    };
+    if (grp == 0) take(std::integral_constant<int, 0>{}); else take(std::integral_constant<int, 1>{});
+    epilogue<TI, TJH>(a, fin, smem, m0 + wm * 64, n0 + wn * 32 * TJW + grp * 32 * TJH, b);
+    PPM_STAMP_AT(29); PPM_STAMP_RT(28);
 }
 
 // obs [m, k] fp32 -> out [m, ld_out] fp16, normalised and clamped, zero beyond k.  One thread per two output columns: every load is
@@ -780,6 +1078,15 @@ __global__ __launch_bounds__(256) void mlp_heads_kernel(const Args a, const Samp
     for (int i = 0; i < 16; i++) acc[i] = 0.f;
     const int ksteps = a.k / 16;
     int ks = wave;
+    // sixteen K steps of this wave per trip (k = 1024, the stacked features of the reference's network: the whole row at once) — the launch is
+    // one round trip to memory per trip, and with four steps per trip it was four of them (8.8 us at M = 4096 for 8 MB of features)
+    for (; ks + 60 < ksteps; ks += 64) {
+        h8 fa[16], fb[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { fa[u] = *reinterpret_cast<const h8*>(pa + (ks + 4 * u) * 16); fb[u] = *reinterpret_cast<const h8*>(pw + (ks + 4 * u) * 16); }
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb[u], acc, 0, 0, 0);
+    }
     for (; ks + 12 < ksteps; ks += 16) {                         // four K steps of this wave per trip: eight loads in flight
         h8 fa[4], fb[4];
 #pragma unroll
@@ -889,7 +1196,8 @@ struct BwdInput {                  // what ppenv_mlp_layer_backward_input adds t
     const _Float16* aux; long long aux_stride; int ldaux;
     float* colsum; long long colsum_stride; int ldcs;
 };
-int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream) {
+int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream, int cus = 0) {
+    if (cus <= 0) cus = 256;                     // the CUs this launch should fill: 256 = the chip; fewer when another launch sequence runs beside it (ppenv_mlp_layer_forward_share)
     if (!L || !L->in || !L->w || !L->out || L->m <= 0 || L->n <= 0 || L->k <= 0 || L->batch <= 0 || L->lda < L->k || L->ldw < L->k || L->ldo < L->n) {
         ppenv_set_error("ppenv_mlp_layer_forward: NULL pointer or inconsistent sizes (need lda >= k, ldw >= k, ldo >= n)");
         return PPENV_EINVAL;
@@ -914,7 +1222,8 @@ int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream) {
     // register-staged kernels for what those cannot take (fp32 input, ragged K, unaligned rows, the narrow heads).
     // 517: the 16x16x32 kernel on 256 x 192 tiles, where the 256 x 256 grid is a single partial round that 192-column tiles fill
     // (2048 -> 1536 at M = 4096: 192 -> 256 workgroups).
-    // PPENV_MLP_TILE = 128 | 129 | 384 | 385 | 512 | 513 | 514 | 516 | 517 forces one.
+    // PPENV_MLP_TILE = 128 | 129 | 384 | 385 | 512 | 513 | 514 | 515 | 516 | 517 | 518 | 520 | 521 forces one (518: K tiles taken in turn by the wave
+    // groups, 64 x 64 per wave — 19.5 us against 15.4 on the 1024 -> 512 layer at M = 4096; its 64 x 128 form needs 256 + 153 registers).
     const char* env = getenv("PPENV_MLP_TILE");   // read per call: the tests switch it inside one process
     const int forced = env ? atoi(env) : 0;
     auto wgs = [&](int bm, int bn) { return (long long)((L->n + bn - 1) / bn) * ((L->m + bm - 1) / bm) * L->batch; };
@@ -922,13 +1231,16 @@ int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream) {
     if (cfg == 0) {
         // the first layer (fp32 observations, K = 80 or 313) converts its obs tile once per column tile: wide tiles and a K step of 32
         // (less zero padding of K) — 54 us against 86 (256 x 256 / BK 32 vs 128 x 128 / BK 64, M = 4096, K = 313)
-        if (L->in_f32) cfg = (wgs(256, 256) >= 128 && L->n >= 256) ? 385 : 129;
+        if (L->in_f32) cfg = (wgs(256, 256) >= cus / 2 && L->n >= 256) ? 385 : 129;
         else if (L->n <= 32 && L->out_f32 && L->batch == 1 && L->k % 16 == 0 && L->lda % 8 == 0 && L->ldw % 8 == 0 &&
                  (reinterpret_cast<uintptr_t>(L->in) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->w) & 15) == 0) cfg = 600;   // the heads
         else if (L->n >= 128) {                                                                        // falls back below when the operands do not qualify
             const long long w256 = wgs(256, 256), w192 = wgs(256, 192);
-            if (w256 >= 192) cfg = (w256 < 256 && w192 > w256 && w192 <= 256) ? 517 : (L->k >= 1024 ? 516 : 512);   // one partial round: 192-column tiles fill it
-            else cfg = wgs(128, 256) >= 192 ? 513 : 514;
+            if (w256 >= 3 * cus / 4) cfg = (w256 < cus && w192 > w256 && w192 <= cus) ? 517 : (L->k >= 1024 ? 516 : 512);   // one partial round: 192-column tiles fill it
+            else {
+                static const bool old_ring = getenv("PPENV_MLP_RING") && atoi(getenv("PPENV_MLP_RING")) == 1;     // A/B switch: 1 = the round-2 ring kernels
+                cfg = wgs(128, 256) >= 3 * cus / 4 ? (old_ring ? 513 : 521) : (old_ring ? 514 : 520);               // 521 / 520: the DMA issue among the MFMAs
+            }
         }
         else cfg = 128;
         // backward-input mode: the 32 x 32 x 16 kernel, whose store pass prefetches the ELU outputs (measured at M = 32768, dX of the 1024 -> 1024 /
@@ -942,10 +1254,10 @@ int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream) {
         if (L->in_f32) hipLaunchKernelGGL((mlp_layer_kernel<true, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);        \
         else hipLaunchKernelGGL((mlp_layer_kernel<false, WM_, WN_, TI_, TJ_, BK_>), grid, block, 0, (hipStream_t)stream, a);                  \
     } while (0)
-    if (cfg == 512 || cfg == 513 || cfg == 514 || cfg == 516 || cfg == 517) {
+    if (cfg >= 512 && cfg <= 521 && cfg != 519) {
         const bool ok = !L->in_f32 && L->k % 64 == 0 && L->lda % 8 == 0 && L->ldw % 8 == 0 && L->in_stride % 8 == 0 && L->w_stride % 8 == 0 &&
                         (reinterpret_cast<uintptr_t>(L->in) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->w) & 15) == 0;
-        if (!ok) cfg = (wgs(256, 256) >= 192 && L->n >= 256) ? 384 : 128;
+        if (!ok) cfg = (wgs(256, 256) >= 3 * cus / 4 && L->n >= 256) ? 384 : 128;
     }
     if (cfg == 600) {
         hipLaunchKernelGGL(mlp_heads_kernel, dim3((L->m + 31) / 32), dim3(256), 0, (hipStream_t)stream, a, SampleArgs{});
@@ -960,10 +1272,20 @@ int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream) {
         hipLaunchKernelGGL((mlp_layer_pp_kernel<true, 3>), dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
     } else if (cfg == 513) {
         const int tn = (L->n + 255) / 256, tm = (L->m + 127) / 128;
-        hipLaunchKernelGGL(mlp_layer_pp1_kernel<2>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
-    } else if (cfg == 514) {
+        hipLaunchKernelGGL((mlp_layer_pp1_kernel<2, 3>), dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+    } else if (cfg == 520) {
         const int tn = (L->n + 127) / 128, tm = (L->m + 127) / 128;
-        hipLaunchKernelGGL(mlp_layer_pp1_kernel<1>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+        hipLaunchKernelGGL(mlp_layer_pp3_kernel<1>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+    } else if (cfg == 521) {
+        const int tn = (L->n + 255) / 256, tm = (L->m + 127) / 128;
+        hipLaunchKernelGGL(mlp_layer_pp3_kernel<2>, dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+    } else if (cfg == 518) {
+        const int tn = (L->n + 127) / 128, tm = (L->m + 127) / 128;
+        hipLaunchKernelGGL((mlp_layer_pp2_kernel<2, 4>), dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+    } else if (cfg == 514 || cfg == 515) {                                  // 515: the same with a five-deep ring (round 4: measured, no faster)
+        const int tn = (L->n + 127) / 128, tm = (L->m + 127) / 128;
+        if (cfg == 514) hipLaunchKernelGGL((mlp_layer_pp1_kernel<1, 3>), dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
+        else hipLaunchKernelGGL((mlp_layer_pp1_kernel<1, 5>), dim3(tn * tm, L->batch), dim3(512), 0, (hipStream_t)stream, a, tn, tm);
     } else if (cfg == 384) PP_LAUNCH(2, 4, 4, 2, 64);
     else if (cfg == 385) PP_LAUNCH(2, 4, 4, 2, 32);
     else if (cfg == 129) PP_LAUNCH(2, 2, 2, 2, 32);
@@ -975,6 +1297,13 @@ int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream) {
 }  // namespace
 
 extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) { return launch_layer(L, nullptr, stream); }
+
+// The same layer with its grid sized for `cus` of the chip's 256 CUs (include/ppenv_policy.h): the tile choice above aims at one workgroup
+// per CU of that share, so that the launch sequences of two (cus = 128) env groups on two streams run side by side instead of queueing.
+extern "C" int ppenv_mlp_layer_forward_share(const ppenv_mlp_layer* L, int32_t cus, void* stream) {
+    if (cus < 0 || cus > 256) { ppenv_set_error("ppenv_mlp_layer_forward_share: cus must be 0 (the whole chip) .. 256"); return PPENV_EINVAL; }
+    return launch_layer(L, nullptr, stream, cus);
+}
 
 // dX of a layer as a launch of the forward kernels (include/ppenv_policy.h): g describes dx[m, k_fwd] = dz[m, n_fwd] . wt[k_fwd, n_fwd]^T in
 // forward form (in = dz, w = wt: the transposed weights, K-contiguous for this product), bias NULL, elu 0, fp16 out.

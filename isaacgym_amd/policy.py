@@ -68,6 +68,7 @@ def _lib_policy():
     L.ppenv_running_mean_std_update.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.c_float, vp, vp]
     L._policy_bound = True
     L.ppenv_mlp_layer_forward.argtypes = [C.POINTER(MLPLayer), C.c_void_p]
+    L.ppenv_mlp_layer_forward_share.argtypes = [C.POINTER(MLPLayer), C.c_int32, C.c_void_p]
     L.ppenv_mlp_prepare_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
     L.ppenv_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ppenv_mlp_heads_sample.argtypes = [C.POINTER(MLPLayer), C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -112,10 +113,14 @@ def _descriptor(out, x, w, bias, elu, batch=1, in_stride=0, w_stride=0, bias_str
     return d
 
 
-def layer_forward(out, x, w, bias, elu, **kw):
-    """One launch of ppenv_mlp_layer_forward on torch tensors (x: fp16 activations or fp32 observations; w: fp16 [n, k])."""
+def layer_forward(out, x, w, bias, elu, cus=0, **kw):
+    """One launch of ppenv_mlp_layer_forward on torch tensors (x: fp16 activations or fp32 observations; w: fp16 [n, k]).
+    cus: size the grid for that many of the 256 CUs (ppenv_mlp_layer_forward_share; 0 = the whole chip)."""
     d = _descriptor(out, x, w, bias, elu, **kw)
-    _lib.check(_lib_policy().ppenv_mlp_layer_forward(C.byref(d), torch.cuda.current_stream(x.device).cuda_stream))
+    if cus:
+        _lib.check(_lib_policy().ppenv_mlp_layer_forward_share(C.byref(d), cus, torch.cuda.current_stream(x.device).cuda_stream))
+    else:
+        _lib.check(_lib_policy().ppenv_mlp_layer_forward(C.byref(d), torch.cuda.current_stream(x.device).cuda_stream))
 
 
 def heads_sample(out, x, w, bias, num_actions, actions, sigma, seed, counter, lo=-1.0, hi=1.0, neglogp=None):
@@ -256,12 +261,14 @@ class NativeMLP:
     """Actor + critic forward on the MFMA kernel.  `actor` / `critic`: lists of (weight [out, in], bias [out]) fp32 tensors, hidden
     layers first, the head last (what `[m for m in net if isinstance(m, nn.Linear)]` yields for the reference's architecture)."""
 
-    def __init__(self, actor, critic, num_obs, device, mean=None, var=None, eps=1e-5, clip=5.0, max_rows=None, fuse_input=False):
-        """fuse_input: layer 1 reads the fp32 observations in place and normalises while staging (one launch fewer, but the
+    def __init__(self, actor, critic, num_obs, device, mean=None, var=None, eps=1e-5, clip=5.0, max_rows=None, fuse_input=False, cus=0):
+        """cus: the share of the chip's 256 CUs each layer launch is sized for (0 = all): 128 when two env groups' forwards run side by
+        side on two streams (collector.PipelinedRollout); results do not depend on it.
+        fuse_input: layer 1 reads the fp32 observations in place and normalises while staging (one launch fewer, but the
         register-staged kernel); default: a small normalise-and-pad launch first, then layer 1 on the LDS-DMA kernel like the rest
         (M = 4096, 313 observations: 54 us fused, see DESIGN.md §5a for the split path)."""
         self.device = torch.device(device)
-        self.fuse_input = bool(fuse_input)
+        self.fuse_input, self.cus = bool(fuse_input), int(cus)
         assert len(actor) == len(critic) and all(a[0].shape[0] == c[0].shape[0] for a, c in zip(actor[:-1], critic[:-1]))
         self.num_obs, self.clip = int(num_obs), float(clip)
         self.units = [a[0].shape[0] for a in actor[:-1]]
@@ -353,13 +360,13 @@ class NativeMLP:
         # layer 1: both networks read the same rows -> one N = 2 u0 GEMM over the stacked weights
         w0 = self.w[0].view(2 * u[0], self.w[0].shape[-1])
         if self.fuse_input:
-            layer_forward(self.h[0], obs, w0, self.b[0].view(-1), elu=True, mean=self.mean, inv_std=self.inv_std, clip=self.clip, k=self.num_obs)
+            layer_forward(self.h[0], obs, w0, self.b[0].view(-1), elu=True, cus=self.cus, mean=self.mean, inv_std=self.inv_std, clip=self.clip, k=self.num_obs)
         else:
             if not prepared:
                 prepare_input(self.x16, obs, self.mean, self.inv_std, self.clip)
-            layer_forward(self.h[0], self.x16, w0, self.b[0].view(-1), elu=True)
+            layer_forward(self.h[0], self.x16, w0, self.b[0].view(-1), elu=True, cus=self.cus)
         for i in range(1, len(u)):
-            layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],
+            layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, cus=self.cus, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],
                           bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])
         ho = self.head_out if head_out is None else head_out
         mu, value = ho[:, :self.num_actions], ho[:, self.num_actions:]

@@ -76,7 +76,7 @@ def test_weight_gradient_kernel_exact_on_integer_data(m, n, k, batch, splits):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", [0, 128, 384, 512, 513, 514, 516])
+@pytest.mark.parametrize("tile", [0, 128, 384, 512, 513, 514, 516, 520, 521])
 @pytest.mark.parametrize("m,n,k,batch", [(333, 328, 192, 1), (640, 256, 128, 2), (1500, 136, 64, 2)])
 def test_input_gradient_launch_exact_on_integer_data(monkeypatch, tile, m, n, k, batch):
     """dX = (dZ . Wt^T) * ELU'(y) and its per-64-row column sums on every tile kernel the launcher can pick (PPENV_MLP_TILE): exact

@@ -73,7 +73,7 @@ def test_layer_kernel_exact_on_integer_data():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", [128, 384, 512, 513, 514, 516, 517])
+@pytest.mark.parametrize("tile", [128, 384, 512, 513, 514, 515, 516, 517, 518, 520, 521])
 @pytest.mark.parametrize("out_f32", [False, True])
 def test_every_tile_exact_on_integer_data(tile, out_f32, monkeypatch):
     """The same bit-for-bit check for each tile configuration the launcher can pick (PPENV_MLP_TILE forces one), as the batched
@@ -93,6 +93,28 @@ def test_every_tile_exact_on_integer_data(tile, out_f32, monkeypatch):
     want = torch.cat([a[:, j * k:(j + 1) * k].float() @ w[j].float().t() + bias[j].float() for j in range(2)], dim=1)
     assert float(want.abs().max()) < 2048                              # exact in fp16 too
     assert torch.equal(out.cpu().float(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", [513, 514, 515, 518, 520, 521])
+@pytest.mark.parametrize("k", [64, 128, 256, 320, 512])
+def test_ring_kernels_exact_for_every_short_k(tile, k, monkeypatch):
+    """The ring kernels keep S - 1 K tiles in flight (S = 5 for the 128 x 128 tile since round 4): K of one to eight tiles crosses every case
+    of the prologue and of the tail's counted waits (fewer tiles than the ring is deep, exactly as many, more)."""
+    import torch
+    from isaacgym_amd.policy import layer_forward
+    monkeypatch.setenv("PPENV_MLP_TILE", str(tile))
+    m, n = 515, 384
+    gen = torch.Generator().manual_seed(tile * 1000 + k)
+    a = torch.randint(-3, 4, (m, 2 * k), generator=gen).to(torch.float16)
+    w = torch.randint(-2, 3, (2, n, k), generator=gen).to(torch.float16)
+    bias = torch.randint(-2, 3, (2, n), generator=gen).to(torch.float16)
+    want = torch.cat([a[:, j * k:(j + 1) * k].float() @ w[j].float().t() + bias[j].float() for j in range(2)], dim=1)
+    for rep in range(3):
+        out = torch.full((m, 2 * n), -7.0, dtype=torch.float32, device="cuda")
+        layer_forward(out, a.cuda(), w.cuda(), bias.cuda(), elu=False, batch=2, in_stride=k, w_stride=n * k, bias_stride=n, out_stride=n, m=m, n=n, k=k)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), want), (tile, k, rep)
 
 
 @pytest.mark.gpu
@@ -165,7 +187,7 @@ def test_heads_kernel_exact_on_integer_data(m, n, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", [512, 513, 514, 516, 517])
+@pytest.mark.parametrize("tile", [512, 513, 514, 515, 516, 517, 518, 520, 521])
 def test_dma_tiles_exact_at_full_size_repeated(tile, monkeypatch):
     """Race screen for the LDS-DMA kernels' own barrier / vmcnt structure: the reference's widest layer (2048 -> 1536, two problems) at
     M = 4096 with the chip full, 32 K tiles per workgroup, small-integer operands so that every launch must reproduce the fp32 matmul
