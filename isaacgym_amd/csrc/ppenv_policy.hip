@@ -25,6 +25,14 @@
 
 void ppenv_set_error(const char* msg);   // ppenv.hip
 
+#ifndef PP_OUT_NT
+#define PP_OUT_NT 0       // 1: the activations leave by non-temporal stores (experiment, tools/gpu_mlp_exp1.py)
+#endif
+#if PP_OUT_NT
+#define PP_STORE_H8(dst, v) __builtin_nontemporal_store((v), reinterpret_cast<h8*>(dst))
+#else
+#define PP_STORE_H8(dst, v) (*reinterpret_cast<h8*>(dst) = (v))
+#endif
 namespace {
 constexpr int PATCH_LD = 72;   // row stride (fp16) of the epilogue patch; the operand tiles use BK + 8 (BK = K step, a template parameter)
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -181,7 +189,7 @@ __device__ __forceinline__ void epilogue(const Args& a, f16v (&acc)[TI][TJ], _Fl
                         for (int q = 0; q < 8; q++) cs[q] += col + q < a.n ? (float)v[q] : 0.f;
                     }
                     _Float16* dst = out + (size_t)row * a.ldo + col;
-                    if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
+                    if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) PP_STORE_H8(dst, v);
                     else {
 #pragma unroll
                         for (int q = 0; q < 8; q++) if (col + q < a.n) dst[q] = v[q];
@@ -295,7 +303,7 @@ __device__ __forceinline__ void epilogue16(const Args& a, f4v (&acc)[MT][NT], _F
                 }
             }
             _Float16* dst = out + (size_t)row * a.ldo + col;
-            if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<h8*>(dst) = v;
+            if (col + 8 <= a.n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) PP_STORE_H8(dst, v);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; e++) if (col + e < a.n) dst[e] = v[e];
