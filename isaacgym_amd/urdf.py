@@ -187,6 +187,8 @@ def parse(text, mesh_bounds=None, on_mesh="error"):
         name, jtype = e.get("name"), e.get("type")
         if jtype not in ("revolute", "continuous", "fixed"):
             raise ValueError(f"joint {name}: type {jtype!r} is not supported (revolute / continuous / fixed)")
+        if e.find("mimic") is not None:
+            raise ValueError(f"joint {name}: <mimic> couples it to another joint; the kernels drive every dof independently (no coupled joints in the tables)")
         o = e.find("origin")
         xyz = _floats(o.get("xyz") if o is not None else None, 3, (0, 0, 0))
         rpy = _floats(o.get("rpy") if o is not None else None, 3, (0, 0, 0))

@@ -100,6 +100,91 @@ HAND_URDF = """<?xml version="1.0"?>
 """
 
 
+def test_features_of_a_real_file_rotated_inertials_off_diagonals_nested_welds():
+    """What a manufacturer's URDF carries that the placeholder does not: <inertial> frames with an rpy, inertia tensors
+    with off-diagonal terms, welded bodies hanging on welded bodies through rotated fixed joints.  The 27-dof file is edited that way — torso:
+    rotated inertial frame + products of inertia; mid360_link re-hung under head_link, both welds rotated — and the importer's merged torso
+    and weld frames are compared with a composition written out here (homogeneous frames + parallel axes), not with scene.composite_inertial."""
+    import xml.etree.ElementTree as ET
+    root = ET.fromstring(open(FIXTURE).read())
+    link = {e.get("name"): e for e in root.findall("link")}
+    joint = {e.find("child").get("link"): e for e in root.findall("joint")}
+    rot = scene.rpy_to_rot
+    # the torso's own inertial: frame rotated, tensor with products of inertia (given in that rotated frame, as the URDF convention says)
+    t_in = link["torso_link"].find("inertial")
+    t_in.find("origin").set("rpy", "0.3 -0.2 0.5")
+    for k, v in (("ixy", "1.1e-3"), ("ixz", "-0.7e-3"), ("iyz", "0.4e-3")):
+        t_in.find("inertia").set(k, v)
+    # head welded with a rotation; mid360 re-hung under the head, rotated again; the head gets a rotated inertial too
+    joint["head_link"].find("origin").set("rpy", "0.0 0.25 0.1")
+    joint["mid360_link"].find("parent").set("link", "head_link")
+    joint["mid360_link"].find("origin").set("xyz", "0.01 -0.02 0.12")
+    joint["mid360_link"].find("origin").set("rpy", "-0.4 0.0 0.2")
+    link["head_link"].find("inertial").find("origin").set("rpy", "0.1 0.2 0.3")
+    link["head_link"].find("inertial").find("inertia").set("ixy", "2.0e-4")
+    text = ET.tostring(root, encoding="unicode")
+    robot = urdf.parse(text)
+    m = urdf.ta_model(robot, urdf.ta_dof_joint_names(), urdf.G1_BODY_NAMES)
+
+    def f(e, key, n=3):
+        return np.array([float(x) for x in e.get(key, " ".join(["0"] * n)).split()])
+
+    def frame_in_torso(name):          # (offset, rotation) of a body's link frame in the torso's, by walking the file's own joints
+        off, r = np.zeros(3), np.eye(3)
+        while name != "torso_link":
+            o = joint[name].find("origin")
+            jr = rot(*f(o, "rpy"))
+            off, r = f(o, "xyz") + jr @ off, jr @ r
+            name = joint[name].find("parent").get("link")
+        return off, r
+
+    ti = m.link[15]                    # link 15 = the torso (12 leg dofs + waist yaw, roll, torso joint)
+    assert ti.body == urdf.G1_BODY_NAMES.index("torso_link")
+    bodies = ["torso_link"] + [n for n in urdf.G1_BODY_NAMES if n != "torso_link" and n in joint and joint[n].get("type") == "fixed"
+                               and _welded_to(joint, n) == "torso_link"]
+    mass, first, second = 0.0, np.zeros(3), np.zeros((3, 3))
+    for n in bodies:
+        inert = link[n].find("inertial")
+        if inert is None:
+            continue
+        off, r = frame_in_torso(n)
+        mb = float(inert.find("mass").get("value"))
+        c = off + r @ f(inert.find("origin"), "xyz")
+        ri = r @ rot(*f(inert.find("origin"), "rpy"))
+        i = inert.find("inertia")
+        g = lambda k: float(i.get(k, 0.0))
+        ib = ri @ np.array([[g("ixx"), g("ixy"), g("ixz")], [g("ixy"), g("iyy"), g("iyz")], [g("ixz"), g("iyz"), g("izz")]]) @ ri.T
+        mass += mb
+        first += mb * c
+        second += ib + mb * (c.dot(c) * np.eye(3) - np.outer(c, c))          # about the torso frame's origin
+    com = first / mass
+    about_com = second - mass * (com.dot(com) * np.eye(3) - np.outer(com, com))
+    assert ti.mass == pytest.approx(mass, rel=1e-6)
+    np.testing.assert_allclose(list(ti.com), com, rtol=0, atol=2e-7)
+    want6 = [about_com[0, 0], about_com[1, 1], about_com[2, 2], about_com[0, 1], about_com[0, 2], about_com[1, 2]]
+    np.testing.assert_allclose(list(ti.inertia), want6, rtol=2e-6, atol=2e-9)
+    assert abs(want6[3]) > 5e-4 and abs(want6[4]) > 3e-4                        # the products of inertia did arrive
+    # the nested weld: mid360's frame in the torso = head weld o mid360 weld
+    fx = {m.fixed[k].body: m.fixed[k] for k in range(scene.TA_NUM_FIXED)}
+    off, r = frame_in_torso("mid360_link")
+    mid = fx[urdf.G1_BODY_NAMES.index("mid360_link")]
+    assert mid.link == 15
+    np.testing.assert_allclose(list(mid.xyz), off, atol=2e-7)
+    np.testing.assert_allclose(np.array(list(mid.rot)).reshape(3, 3), r, atol=2e-7)
+    assert np.linalg.norm(off - f(joint["mid360_link"].find("origin"), "xyz")) > 0.1     # not the one-level value
+    # and what the tables cannot carry is refused by name
+    ET.SubElement(joint["left_elbow_link"], "mimic", joint="right_elbow_joint", multiplier="1")
+    with pytest.raises(ValueError, match="mimic"):
+        urdf.parse(ET.tostring(root, encoding="unicode"))
+
+
+def _welded_to(joint, name):
+    """The first ancestor reached through fixed joints only that itself hangs on a movable joint (or is the root)."""
+    while name in joint and joint[name].get("type") == "fixed":
+        name = joint[name].find("parent").get("link")
+    return name
+
+
 def test_collision_geometry_of_a_hand_written_urdf():
     """<collision> primitives -> ball shapes, paddle blade and ground-contact points; the expected tables are typed in, the asset is
     not derived from scene.py."""
