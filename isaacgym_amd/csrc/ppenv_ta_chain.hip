@@ -48,7 +48,15 @@ void ppenv_set_error(const char* msg);   // ppenv.hip
 
 namespace {
 using T = ModelG1Tree;
-constexpr int kE = 64;                 // lanes per wave = rows of every LDS tile
+constexpr int kE = 64;                 // lanes per wave = envs of a workgroup = columns of every LDS tile
+// Row pitch of the [row][env] tiles.  A role reads and writes a tile with lane = env (conflict-free at any pitch); the staging at the start and
+// the flush at the end move the Isaac-Gym-layout tensors ([env][row]) as flat float4 — lane = a run of four ROWS of one env — where a pitch of 64
+// floats puts the lanes of an env into one LDS bank.  Round 4 measured the odd pitch (-DTA_TILE_PAD=1): the staging 5.9k -> 5.2k cycles and the state
+// tiles' flush 4.6k -> 3.7k (stamps), the launch 30.4 -> 30.7 us in a same-box A/B (the roles' row addresses lose their shifts): not adopted.
+#ifndef TA_TILE_PAD
+#define TA_TILE_PAD 0
+#endif
+constexpr int kP = kE + TA_TILE_PAD;
 // Envs per workgroup.  64 in the product.  Diagnostic builds (tools/gpu_ta_narrow.sh, round 3) set 32 or 16: the upper lanes of every wave idle (they chew on
 // a copy of the workgroup's last env, like the lanes of a ragged last workgroup) and the grid has 2x / 4x the workgroups — at 4096 envs 128 / 256 CUs get one
 // instead of 64.  Measured: the chain does not get shorter (a wave issues an instruction in four passes whatever its EXEC mask), see DESIGN.md §9.
@@ -110,21 +118,21 @@ static_assert(T::kPaddleLink == 27 && T::kBoundLink == kTorso, "collision geomet
 // ---- LDS ----------------------------------------------------------------------------------------------------------------
 // Everything is [row][64]: lane e reads / writes element e of a row, so an access of a wave is one conflict-free 256-byte row.
 struct __attribute__((aligned(16))) Shared {
-    float q[NDOF][kE], qd[NDOF][kE];
-    float act_frc[NDOF][kE];          // clamped-and-mapped PD targets at the start, the reported drive torques at the end
-    float root[39][kE];               // rows 0..12: the base state (start of the current substep / final), 13..25 table, 26..38 ball
-    float torso[18][kE];              // pass 1 hand-off: Rw 9, pw 3, w 3, v 3 of the torso (link 15)
-    float sums[5][3][kE];             // final phase: each chain wave's share of the balance sums (pos, vel, norm)
-    float paddle[3][kE];              // final phase: paddle position (body 39)
+    float q[NDOF][kP], qd[NDOF][kP];
+    float act_frc[NDOF][kP];          // clamped-and-mapped PD targets at the start, the reported drive torques at the end
+    float root[39][kP];               // rows 0..12: the base state (start of the current substep / final), 13..25 table, 26..38 ball
+    float torso[18][kP];              // pass 1 hand-off: Rw 9, pw 3, w 3, v 3 of the torso (link 15)
+    float sums[5][3][kP];             // final phase: each chain wave's share of the balance sums (pos, vel, norm)
+    float paddle[3][kP];              // final phase: paddle position (body 39)
     float pre_vx[kE];                 // the ball's vx before the step (TA:1143)
     union {
         struct {
-            float art_leg[2][27][kE]; // pass 2: what a leg adds to the pelvis (A6 B9 D6 pn3 pf3)
-            float art_arm[2][27][kE]; // pass 2: what an arm adds to the torso
-            float acc_base[6][kE];    // pelvis acceleration (alpha, a)
-            float acc_torso[6][kE];   // torso acceleration
-            float geo_w[2][kGeoW][kE];   // collision geometry of the pelvis / torso shapes + bound centre, slot = substep & 1
-            float geo_ra[2][kGeoRA][kE]; // ... of the forearm / hand shapes and the paddle blade
+            float art_leg[2][27][kP]; // pass 2: what a leg adds to the pelvis (A6 B9 D6 pn3 pf3)
+            float art_arm[2][27][kP]; // pass 2: what an arm adds to the torso
+            float acc_base[6][kP];    // pelvis acceleration (alpha, a)
+            float acc_torso[6][kP];   // torso acceleration
+            float geo_w[2][kGeoW][kP];   // collision geometry of the pelvis / torso shapes + bound centre, slot = substep & 1
+            float geo_ra[2][kGeoRA][kP]; // ... of the forearm / hand shapes and the paddle blade
         } hub;
         float obs[kE * PPENV_TA_NUM_OBS];   // final phase: the observation rows, row-major (flushed as one contiguous block)
     } u;
@@ -156,15 +164,15 @@ __device__ __forceinline__ bool await(int* flag, int value) {
         }                                                                                                            \
     } while (0)
 
-__device__ __forceinline__ V3 row3(const float (*r)[kE], int k0, int e) { return mk(r[k0][e], r[k0 + 1][e], r[k0 + 2][e]); }
-__device__ __forceinline__ void put3(float (*r)[kE], int k0, int e, V3 v) { r[k0][e] = v.x; r[k0 + 1][e] = v.y; r[k0 + 2][e] = v.z; }
-__device__ __forceinline__ void put_art(float (*r)[kE], int e, const ArtI& I) {
+__device__ __forceinline__ V3 row3(const float (*r)[kP], int k0, int e) { return mk(r[k0][e], r[k0 + 1][e], r[k0 + 2][e]); }
+__device__ __forceinline__ void put3(float (*r)[kP], int k0, int e, V3 v) { r[k0][e] = v.x; r[k0 + 1][e] = v.y; r[k0 + 2][e] = v.z; }
+__device__ __forceinline__ void put_art(float (*r)[kP], int e, const ArtI& I) {
     const float v[27] = {I.A.xx, I.A.yy, I.A.zz, I.A.xy, I.A.xz, I.A.yz, I.B.m[0], I.B.m[1], I.B.m[2], I.B.m[3], I.B.m[4], I.B.m[5], I.B.m[6], I.B.m[7], I.B.m[8],
                          I.D.xx, I.D.yy, I.D.zz, I.D.xy, I.D.xz, I.D.yz, I.pn.x, I.pn.y, I.pn.z, I.pf.x, I.pf.y, I.pf.z};
 #pragma unroll
     for (int t = 0; t < 27; t++) r[t][e] = v[t];
 }
-__device__ __forceinline__ ArtI get_art(const float (*r)[kE], int e) {
+__device__ __forceinline__ ArtI get_art(const float (*r)[kP], int e) {
     float v[27];
 #pragma unroll
     for (int t = 0; t < 27; t++) v[t] = r[t][e];
@@ -209,7 +217,7 @@ __device__ __forceinline__ void kin_step(float q, float qd, Frame& f, float& c, 
     f.Rw = mul(f.Rw, E);
     f.w = wn; f.v = vn;
 }
-__device__ __forceinline__ Frame base_frame(const float (*root)[kE], int e) {
+__device__ __forceinline__ Frame base_frame(const float (*root)[kP], int e) {
     float quat[4] = {root[3][e], root[4][e], root[5][e], root[6][e]};
     Frame f;
     f.Rw = quat_to_m3(quat);
@@ -451,7 +459,7 @@ __device__ __forceinline__ void limb_out(TaskCtx& c, const Limb<FIRST, N>& lb, F
 
 // collision geometry of the shapes riding on link LI -> rows of a hand-off slot (a va b vb per shape in the order of ArmGeom; paddle; bound)
 template <int LI, int NROWS>
-__device__ __forceinline__ void geo_capture(float (*slot)[kE], int e, const Frame& f, int& row) {
+__device__ __forceinline__ void geo_capture(float (*slot)[kP], int e, const Frame& f, int& row) {
     constexpr LinkC L = T::link(LI);
     static_for<T::kShapes>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
@@ -525,11 +533,11 @@ __device__ __forceinline__ void flush_store(V v, V* p) {
 }
 // flat copies between an [rows][64] SoA tile and the workgroup's contiguous block of a row-major [N, W] tensor
 template <int W>
-__device__ __forceinline__ void tile_in(float (*tile)[kE], const float* __restrict__ src, int nvalid, int tid) {
+__device__ __forceinline__ void tile_in(float (*tile)[kP], const float* __restrict__ src, int nvalid, int tid) {
     for (int t = tid; t < nvalid * W; t += kWaves * 64) { const int e = t / W, c = t - e * W; tile[c][e] = src[t]; }
 }
 template <int W>
-__device__ __forceinline__ void tile_out(float* __restrict__ dst, const float (*tile)[kE], int nvalid, int tid) {
+__device__ __forceinline__ void tile_out(float* __restrict__ dst, const float (*tile)[kP], int nvalid, int tid) {
     for (int t = tid; t < nvalid * W; t += kWaves * 64) { const int e = t / W, c = t - e * W; __builtin_nontemporal_store(tile[c][e], &dst[t]); }
 }
 
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             if constexpr (decltype(with_geo)::value) {              // the right arm carries collision shapes and the paddle
                 if (sub >= 2) TA_AWAIT(&S.f_ball, sub - 1);         // the ball wave is done with this geometry slot
                 int grow = 0;
-                float (*gslot)[kE] = S.u.hub.geo_ra[sub & 1];
+                float (*gslot)[kP] = S.u.hub.geo_ra[sub & 1];
                 L.pass1(ft, [&](auto lc, const Frame& f) { geo_capture<decltype(lc)::value, kGeoRA>(gslot, e, f, grow); });
                 publish(&S.f_geo_ra, sub + 1);
             } else {
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             publish(&S.f_torso, sub + 1);
             {   // collision geometry of the pelvis / torso shapes for the ball wave
                 int grow = 0;
-                float (*gslot)[kE] = S.u.hub.geo_w[sub & 1];
+                float (*gslot)[kP] = S.u.hub.geo_w[sub & 1];
                 geo_capture<0, kGeoW>(gslot, e, f0, grow);
                 static_for<3>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
@@ -794,12 +802,12 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             V3 bound[1];
             static_for<T::kShapes>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                const float (*slot)[kE] = gm.slot[s] == 0 ? S.u.hub.geo_w[sub & 1] : S.u.hub.geo_ra[sub & 1];
+                const float (*slot)[kP] = gm.slot[s] == 0 ? S.u.hub.geo_w[sub & 1] : S.u.hub.geo_ra[sub & 1];
                 g[0].a[s] = row3(slot, gm.row[s], e); g[0].va[s] = row3(slot, gm.row[s] + 3, e);
                 g[0].b[s] = row3(slot, gm.row[s] + 6, e); g[0].vb[s] = row3(slot, gm.row[s] + 9, e);
             });
             {
-                const float (*slot)[kE] = S.u.hub.geo_ra[sub & 1];
+                const float (*slot)[kP] = S.u.hub.geo_ra[sub & 1];
                 g[0].pc = row3(slot, gm.paddle_row, e); g[0].pn = row3(slot, gm.paddle_row + 3, e);
                 g[0].vpc = row3(slot, gm.paddle_row + 6, e); g[0].pnd = row3(slot, gm.paddle_row + 9, e);
                 bound[0] = row3(S.u.hub.geo_w[sub & 1], gm.bound_row, e);
@@ -880,6 +888,40 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
     CH_STAMP(22);
     __syncthreads();   // B2
     CH_STAMP(23);
+
+    // ---- final phase 2a (the five limb waves, beside the ball wave's phase 2): the policy's input, where the row is already final ------
+    // ppenv_ta_sim_set_policy_input: clamp((obs - mean) * inv_std, +-clip) as fp16, rows padded with zeros to ld — the arithmetic of
+    // ppenv_mlp_prepare_input, which this replaces.  Thread t < 320 owns the column PAIR t % 160 of the rows t / 160 + 2 k: its four statistics are
+    // loaded once, a wave-store is 256 contiguous bytes, and the LDS reads of a wave step through the row two floats apart (2-way, not the 8-way of
+    // wider pieces).  Columns [60, 121) of a row — the dof entries a resetting env gets rewritten, the ball — are the ball wave's to finish, and
+    // observation noise rewrites the whole tile after B3: those pairs wait for B3.  (Round 4 also sent the final part of the fp32 tile from here:
+    // the predicate broke the store loop's pipelining, 3.6k + 4.4k cycles against 2.2k for the plain loop after B3 — the tile is not what the tail waits for.)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    bool noisy = false;
+    if constexpr (DR) noisy = a.dr_obs_sigma > 0.f;
+    const bool pin_fast = a.pin_out && nvalid == kE && a.pin_ld == 320;
+    const int pcol = 2 * (tid % 160), prow0 = tid / 160;
+    const bool pin_early = !noisy && (pcol + 1 < 60 || pcol >= 121);
+    float pmu0 = 0.f, pmu1 = 0.f, pis0 = 0.f, pis1 = 0.f;
+    auto pin_rows = [&]() {                                       // this thread's 32 rows of its column pair
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const int c0 = pcol < PPENV_TA_NUM_OBS ? pcol : PPENV_TA_NUM_OBS - 1, c1 = pcol + 1 < PPENV_TA_NUM_OBS ? pcol + 1 : PPENV_TA_NUM_OBS - 1;
+        _Float16* dst = reinterpret_cast<_Float16*>(a.pin_out) + (size_t)e0 * 320 + pcol;
+#pragma unroll 8
+        for (int k = 0; k < kE / 2; k++) {
+            const int ee = prow0 + 2 * k;
+            float g0 = (S.u.obs[ee * PPENV_TA_NUM_OBS + c0] - pmu0) * pis0;
+            float g1 = (S.u.obs[ee * PPENV_TA_NUM_OBS + c1] - pmu1) * pis1;
+            g0 = fminf(fmaxf(g0, -a.pin_clip), a.pin_clip); g1 = fminf(fmaxf(g1, -a.pin_clip), a.pin_clip);
+            const h2 v = {(_Float16)(pcol < PPENV_TA_NUM_OBS ? g0 : 0.f), (_Float16)(pcol + 1 < PPENV_TA_NUM_OBS ? g1 : 0.f)};
+            *reinterpret_cast<h2*>(dst + (size_t)ee * 320) = v;
+        }
+    };
+    if (wave != W_BALL && pin_fast && !S.dead) {
+        const int c0 = pcol < PPENV_TA_NUM_OBS ? pcol : PPENV_TA_NUM_OBS - 1, c1 = pcol + 1 < PPENV_TA_NUM_OBS ? pcol + 1 : PPENV_TA_NUM_OBS - 1;
+        pmu0 = a.pin_mean[c0]; pmu1 = a.pin_mean[c1]; pis0 = a.pin_inv_std[c0]; pis1 = a.pin_inv_std[c1];
+        if (pin_early) pin_rows();
+    }
 
     // ---- final phase 2 (ball wave): reward, reset, the rest of the row — ppenv_ta_task.h ta_task_env, one lane per env ---------
     bool any_here = false;
@@ -1006,7 +1048,6 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
 
     // ---- final phase 3: the tiles leave as the workgroup's contiguous blocks ------------------------------------------------------
     if (!S.dead) {
-        typedef float f4v __attribute__((ext_vector_type(4)));
         constexpr int kThreads = kWaves * 64;
         if constexpr (DR) {
             // observation noise (yaml: observations / gaussian / additive): on the finished tile, after the reward has been computed from the clean
@@ -1037,6 +1078,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                 const int i = it * kThreads + tid;
                 if (i < nO) flush_store(reinterpret_cast<const f4v*>(S.u.obs)[i], reinterpret_cast<f4v*>(dobs) + i);
             }
+            CH_STAMP(27);
             f4v* dd = reinterpret_cast<f4v*>(a.dof_states + (size_t)e0 * 2 * NDOF);
 #pragma unroll
             for (int it = 0; it < (nD + kThreads - 1) / kThreads; it++) {
@@ -1049,6 +1091,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                     flush_store(v, dd + i);
                 }
             }
+            CH_STAMP(28);
             f4v* df = reinterpret_cast<f4v*>(a.dof_force + (size_t)e0 * NDOF);
 #pragma unroll
             for (int it = 0; it < (nF + kThreads - 1) / kThreads; it++) {
@@ -1061,6 +1104,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                     flush_store(v, df + i);
                 }
             }
+            CH_STAMP(29);
             f4v* dr = reinterpret_cast<f4v*>(a.root_states + (size_t)e0 * 39);
 #pragma unroll
             for (int it = 0; it < (nR + kThreads - 1) / kThreads; it++) {
@@ -1073,7 +1117,10 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
                     flush_store(v, dr + i);
                 }
             }
-            if (a.pin_out) {
+            CH_STAMP(30);
+            if (pin_fast) {
+                if (wave != W_BALL && !pin_early) pin_rows();                      // the column pairs phase 2a could not send (all of them with observation noise on)
+            } else if (a.pin_out) {
                 // The policy's input straight from the tile: clamp((obs - mean) * inv_std, +-clip) as fp16, rows
                 // padded with zeros to pin_ld — the same arithmetic as ppenv_mlp_prepare_input, which this replaces.  Two columns per
                 // lane: 256 contiguous bytes per wave-store; the statistics are L1 hits after the first row.

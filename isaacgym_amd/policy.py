@@ -343,6 +343,7 @@ class NativeMLP:
         if env.num_envs != self._rows:
             self._alloc(env.num_envs)
         env.set_policy_input(self.x16, self.mean, self.inv_std, self.clip)
+        prepare_input(self.x16, env.obs_buf, self.mean, self.inv_std, self.clip)    # the rows of the CURRENT obs_buf: the first forward runs before any step has written them
 
     def forward(self, obs, prepared=False, sample=None, head_out=None):
         """obs: fp32 [M, num_obs] on this device (the env's obs_buf, read in place) -> (mu [M, A], value [M, 1]) fp32 (buffers reused).

@@ -243,6 +243,33 @@ def test_step_kernel_writes_the_policy_input(n):
     env.close(); ref.close()
 
 
+@pytest.mark.gpu
+def test_attached_env_feeds_the_forward_from_the_first_call():
+    """NativeMLP.attach_env: the step kernel writes the network's first-layer input, and attach_env itself fills it from the CURRENT obs_buf —
+    forward(prepared=True) equals the forward with its own normalise-and-pad launch bit for bit before any step and after every step."""
+    import torch
+    from isaacgym_amd.policy import NativeMLP
+    from isaacgym_amd.tensor_api import TAEnv
+    n = 256
+    env = TAEnv(n, device="cuda:0", seed=5)
+    if env.sim.kernel != "chain":
+        pytest.skip("the chain-wave kernel is not the one in use")
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    dims = [313, 256, 128]
+    mk = lambda n_out: [((torch.randn(o, i, device="cuda", generator=gen) / i ** 0.5), torch.randn(o, device="cuda", generator=gen) * 0.1)
+                        for i, o in zip(dims, dims[1:] + [n_out])]
+    actor, critic = mk(27), mk(1)
+    kw = dict(mean=torch.randn(313, device="cuda", generator=gen) * 0.2, var=torch.rand(313, device="cuda", generator=gen) + 0.5, max_rows=n)
+    fed, plain = NativeMLP(actor, critic, 313, "cuda:0", **kw), NativeMLP(actor, critic, 313, "cuda:0", **kw)
+    fed.attach_env(env)
+    for t in range(5):
+        mu1, v1 = fed.forward(env.obs_buf, prepared=True)
+        mu0, v0 = plain.forward(env.obs_buf)
+        assert torch.equal(mu1, mu0) and torch.equal(v1, v0), t
+        env.step(torch.clamp(mu0, -1, 1).contiguous())
+    env.close()
+
+
 def _rlgames_state_dict(torch, num_obs, units, num_act, gen):
     """A state dict with the key layout of rl_games' a2c_continuous_logstd model for a `separate: True` network."""
     sd, d = {}, num_obs

@@ -38,8 +38,8 @@ names = {"0": ["waist", "right leg", "left arm", "right arm", "left leg", "ball"
          "2": ["waist", "right leg", "left leg", "right arm", "left arm", "ball"]}[os.environ.get("TA_ROLE_MAP", "1")]   # wave index order (ppenv_ta_chain.hip W_*, per TA_ROLE_MAP)
 pts = {0: "start", 1: "inputs staged", 2: "s1 begin", 3: "s1 pass1 done", 7: "s1 (waist) pelvis dyn", 4: "s1 pass2 done / arms in", 8: "s1 (waist) waist pass2", 9: "s1 (waist) legs in",
        5: "s1 accel in/out", 6: "s1 end", 10: "s2 begin", 11: "s2 pass1 done", 15: "s2 (waist) pelvis dyn", 12: "s2 pass2 done / arms in", 16: "s2 (waist) waist pass2",
-       17: "s2 (waist) legs in", 13: "s2 accel in/out", 14: "s2 end", 20: "B1 arrive", 21: "B1 leave", 22: "B2 arrive", 23: "B2 leave", 24: "B3 arrive", 25: "B3 leave", 26: "end"}
-order = [0, 1, 2, 3, 7, 4, 8, 9, 5, 6, 10, 11, 15, 12, 16, 17, 13, 14, 20, 21, 22, 23, 24, 25, 26]
+       17: "s2 (waist) legs in", 13: "s2 accel in/out", 14: "s2 end", 20: "B1 arrive", 21: "B1 leave", 22: "B2 arrive", 23: "B2 leave", 24: "B3 arrive", 25: "B3 leave", 27: "obs rest stored", 28: "dof_states stored", 29: "dof_force stored", 30: "root_states stored", 26: "end"}
+order = [0, 1, 2, 3, 7, 4, 8, 9, 5, 6, 10, 11, 15, 12, 16, 17, 13, 14, 20, 21, 22, 23, 24, 25, 27, 28, 29, 30, 26]
 print(f"N={n}: {nb} workgroups; median cycles since the workgroup's first stamp (s_memtime, 100 MHz-independent shader clock)")
 print("%-28s" % "point" + "".join("%11s" % x for x in names))
 for k in order:
