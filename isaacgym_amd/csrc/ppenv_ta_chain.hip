@@ -116,11 +116,19 @@ static_assert(chain_ok(1, 6, 0) && chain_ok(7, 6, 0) && chain_ok(13, 3, 0) && ch
 static_assert(T::kPaddleLink == 27 && T::kBoundLink == kTorso, "collision geometry owners");
 
 // ---- LDS ----------------------------------------------------------------------------------------------------------------
-// Everything is [row][64]: lane e reads / writes element e of a row, so an access of a wave is one conflict-free 256-byte row.
+// The tiles are [row][64]: lane e reads / writes element e of a row, so an access of a wave is one conflict-free 256-byte row.
+// Two of the three Isaac-Gym-layout tensors (round 4) live here IN THEIR OWN LAYOUT instead, env-major — the workgroup's block of dof_states
+// [64][27][2] and of actions / dof_force [64][27] — so that their staging at the start and their flush at the end are flat 16-byte copies (as
+// [row][env] tiles they are transposed on the way, lane = four rows of one env: all the lanes of an env in one LDS bank).  A role touches them
+// only when it loads / stores its limb's state, lane = env at a pitch of 54 / 27 floats (2-way / conflict-free).  root_states keeps the
+// [row][env] form: the waist and the ball wave read and write it every substep, and env-major it cost the roles more (14 more spilled
+// registers, substeps +1.5k cycles) than its flush gained.  Stamped timeline at 4096 envs (profiles/r04_c_TA_chain_stamps.txt): inputs staged
+// 5.9k -> 4.1k cycles, the state tiles' flush 4.6k -> 1.9k, workgroup span 67.7k -> 64.6k; the launch itself, same box, 30.3 us before and after
+// (tools/gpu_r4_ta_ab.sh) — what the stamps gain the un-stamped build does not show.  Kept for the simpler copies, not for speed.
 struct __attribute__((aligned(16))) Shared {
-    float q[NDOF][kP], qd[NDOF][kP];
-    float act_frc[NDOF][kP];          // clamped-and-mapped PD targets at the start, the reported drive torques at the end
-    float root[39][kP];               // rows 0..12: the base state (start of the current substep / final), 13..25 table, 26..38 ball
+    float dof[kE * 2 * NDOF];         // (q, qd) pairs: element (e, d, k) at e * 54 + 2 d + k
+    float act[kE * NDOF];             // raw actions at the start, the reported drive torques at the end: (e, d) at e * 27 + d
+    float root[39][kP];               // rows 0..12: the base state (start of the current substep / final), 13..25 table, 26..38 ball ([row][env]: the waist and the ball wave read and write it every substep)
     float torso[18][kP];              // pass 1 hand-off: Rw 9, pw 3, w 3, v 3 of the torso (link 15)
     float sums[5][3][kP];             // final phase: each chain wave's share of the balance sums (pos, vel, norm)
     float paddle[3][kP];              // final phase: paddle position (body 39)
@@ -331,7 +339,7 @@ struct Limb {
             outward_step(P, L, E, sv[k].w, sv[k].v, jo[k], aw, av, target[k], q[k], qd[k], force[k]);
         });
     }
-    // (the staging leaves the raw actions in S.act_frc: the clamp and the map onto the joint range happen here, where the joint is a
+    // (the staging leaves the raw actions in S.act: the clamp and the map onto the joint range happen here, where the joint is a
     // compile-time constant — in the staging loop the lanes of a wave look at different dofs and the limits were a table lookup)
     __device__ __forceinline__ void load(const Shared& S, int e, float clip_actions, const DrKeys& dk = DrKeys{}) {
         tab = dk.tab; lane = e;
@@ -339,8 +347,8 @@ struct Limb {
             constexpr int k = decltype(kc)::value;
             constexpr LinkC L = T::link(FIRST + k);
             constexpr int d = FIRST - 1 + k;                          // the dof of link FIRST + k
-            q[k] = S.q[d][e]; qd[k] = S.qd[d][e]; force[k] = 0.f;
-            float act = S.act_frc[d][e];
+            q[k] = S.dof[(e) * (2 * NDOF) + 2 * (d)]; qd[k] = S.dof[(e) * (2 * NDOF) + 2 * (d) + 1]; force[k] = 0.f;
+            float act = S.act[(e) * NDOF + (d)];
             if constexpr (DR) {                                       // this env's table entries (a NULL table = scale 1); the action noise goes in before the clamp
                 const TAChainArgs& a = *dk.a;
                 tab->kp[d][e] = a.dr_kp ? a.dr_kp[(size_t)d * dk.n + dk.env] : 1.f;
@@ -351,17 +359,17 @@ struct Limb {
             target[k] = pd_target(act, L.lo, L.hi, clip_actions);   // VecTask.step clamp + TA:1131, 729-733
         });
     }
-    // the final phase only needs the new (q, qd): S.act_frc holds the drive torques by then
+    // the final phase only needs the new (q, qd): S.act holds the drive torques by then
     __device__ __forceinline__ void load_state(const Shared& S, int e) {
         static_for<N>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            q[k] = S.q[FIRST - 1 + k][e]; qd[k] = S.qd[FIRST - 1 + k][e]; target[k] = 0.f; force[k] = 0.f;
+            q[k] = S.dof[(e) * (2 * NDOF) + 2 * (FIRST - 1 + k)]; qd[k] = S.dof[(e) * (2 * NDOF) + 2 * (FIRST - 1 + k) + 1]; target[k] = 0.f; force[k] = 0.f;
         });
     }
     __device__ __forceinline__ void store(Shared& S, int e) const {
         static_for<N>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            S.q[FIRST - 1 + k][e] = q[k]; S.qd[FIRST - 1 + k][e] = qd[k]; S.act_frc[FIRST - 1 + k][e] = force[k];
+            S.dof[(e) * (2 * NDOF) + 2 * (FIRST - 1 + k)] = q[k]; S.dof[(e) * (2 * NDOF) + 2 * (FIRST - 1 + k) + 1] = qd[k]; S.act[(e) * NDOF + (FIRST - 1 + k)] = force[k];
         });
     }
 };
@@ -531,16 +539,6 @@ __device__ __forceinline__ void flush_store(V v, V* p) {
     *p = v;
 #endif
 }
-// flat copies between an [rows][64] SoA tile and the workgroup's contiguous block of a row-major [N, W] tensor
-template <int W>
-__device__ __forceinline__ void tile_in(float (*tile)[kP], const float* __restrict__ src, int nvalid, int tid) {
-    for (int t = tid; t < nvalid * W; t += kWaves * 64) { const int e = t / W, c = t - e * W; tile[c][e] = src[t]; }
-}
-template <int W>
-__device__ __forceinline__ void tile_out(float* __restrict__ dst, const float (*tile)[kP], int nvalid, int tid) {
-    for (int t = tid; t < nvalid * W; t += kWaves * 64) { const int e = t / W, c = t - e * W; __builtin_nontemporal_store(tile[c][e], &dst[t]); }
-}
-
 // ---- the kernel -------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ Frame torso_frame(const Shared& S, int e) {
     Frame f;
@@ -591,60 +589,30 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         for (int it = 0; it < tA; it++) { const int i = it * kThreads + tid; va[it] = i < nA ? sa[i] : f4v{0, 0, 0, 0}; }
 #pragma unroll
         for (int it = 0; it < tR; it++) { const int i = it * kThreads + tid; vr[it] = i < nR ? sr[i] : f4v{0, 0, 0, 0}; }
-        // (one division per float4, then a running (env, column) pair: the four divisions per vector were a third of the staging's instructions)
+        // the LDS images have the tensors' own layout: flat 16-byte copies
 #pragma unroll
-        for (int it = 0; it < tD; it++) {
-            const int i = it * kThreads + tid;
-            if (i < nD) {
-                int ee = (4 * i) / (2 * NDOF), c = 4 * i - ee * 2 * NDOF;
+        for (int it = 0; it < tD; it++) { const int i = it * kThreads + tid; if (i < nD) reinterpret_cast<f4v*>(S.dof)[i] = vd[it]; }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (c & 1) S.qd[c >> 1][ee] = vd[it][k]; else S.q[c >> 1][ee] = vd[it][k];
-                    if (++c == 2 * NDOF) { c = 0; ee++; }
-                }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < tA; it++) {
-            const int i = it * kThreads + tid;
-            if (i < nA) {
-                int ee = (4 * i) / NDOF, d = 4 * i - ee * NDOF;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    S.act_frc[d][ee] = va[it][k];   // raw: Limb::load maps it to the PD target
-                    if (++d == NDOF) { d = 0; ee++; }
-                }
-            }
-        }
+        for (int it = 0; it < tA; it++) { const int i = it * kThreads + tid; if (i < nA) reinterpret_cast<f4v*>(S.act)[i] = va[it]; }   // raw: Limb::load maps them to PD targets
 #pragma unroll
         for (int it = 0; it < tR; it++) {
             const int i = it * kThreads + tid;
             if (i < nR) {
                 int ee = (4 * i) / 39, c = 4 * i - ee * 39;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    S.root[c][ee] = vr[it][k];
-                    if (++c == 39) { c = 0; ee++; }
-                }
+                for (int k = 0; k < 4; k++) { S.root[c][ee] = vr[it][k]; if (++c == 39) { c = 0; ee++; } }
             }
         }
     } else {
-        for (int t = tid; t < nvalid * 2 * NDOF; t += kWaves * 64) {
-            const int ee = t / (2 * NDOF), c = t - ee * 2 * NDOF;
-            const float v = a.dof_states[(size_t)e0 * 2 * NDOF + t];
-            if (c & 1) S.qd[c >> 1][ee] = v; else S.q[c >> 1][ee] = v;
-        }
-        for (int t = tid; t < nvalid * NDOF; t += kWaves * 64) {
-            const int ee = t / NDOF, d = t - ee * NDOF;
-            S.act_frc[d][ee] = a.actions[(size_t)e0 * NDOF + t];
-        }
-        tile_in<39>(S.root, a.root_states + (size_t)e0 * 39, nvalid, tid);
+        for (int t = tid; t < nvalid * 2 * NDOF; t += kWaves * 64) S.dof[t] = a.dof_states[(size_t)e0 * 2 * NDOF + t];
+        for (int t = tid; t < nvalid * NDOF; t += kWaves * 64) S.act[t] = a.actions[(size_t)e0 * NDOF + t];
+        for (int t = tid; t < nvalid * 39; t += kWaves * 64) { const int ee = t / 39, c = t - ee * 39; S.root[c][ee] = a.root_states[(size_t)e0 * 39 + t]; }
     }
     __syncthreads();
     if (!live) {   // a ragged last workgroup: give the idle lanes a valid state to chew on (copies of its last env)
         const int src = nvalid - 1;
         if (wave == W_WAIST) {
-            for (int d = 0; d < NDOF; d++) { S.q[d][e] = S.q[d][src]; S.qd[d][e] = S.qd[d][src]; S.act_frc[d][e] = S.act_frc[d][src]; }
+            for (int d = 0; d < NDOF; d++) { S.dof[(e) * (2 * NDOF) + 2 * (d)] = S.dof[(src) * (2 * NDOF) + 2 * (d)]; S.dof[(e) * (2 * NDOF) + 2 * (d) + 1] = S.dof[(src) * (2 * NDOF) + 2 * (d) + 1]; S.act[(e) * NDOF + (d)] = S.act[(src) * NDOF + (d)]; }
             for (int k = 0; k < 39; k++) S.root[k][e] = S.root[k][src];
         }
     }
@@ -872,10 +840,10 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
         dr_prog0 = (uint32_t)(prog - 1);
 #pragma unroll
         for (int d = 0; d < NDOF; d++) {
-            const float qv = S.q[d][e], qdv = S.qd[d][e];
+            const float qv = S.dof[(e) * (2 * NDOF) + 2 * (d)], qdv = S.dof[(e) * (2 * NDOF) + 2 * (d) + 1];
             const float epd = p.init_dof_pos[d] - qv, evd = p.init_dof_vel[d] - qdv;
             if (d < 22) { s22 += epd * epd; sv += evd * evd; } else s5 += epd * epd;
-            power += fabsf(S.act_frc[d][e] * qdv);
+            power += fabsf(S.act[(e) * NDOF + (d)] * qdv);
             orow[60 + d] = qv; orow[60 + NDOF + d] = qdv * 0.1f;                               // TA:1881-1882 (overwritten below if the env resets)
             // the constant tail of the row (TA:1921-1927: the initial dof state)
             orow[121 + 6 * tatask::TA_NBAL + d] = p.init_dof_pos[d]; orow[121 + 6 * tatask::TA_NBAL + NDOF + d] = p.init_dof_vel[d];
@@ -1027,7 +995,7 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             bp = mk(p.init_root[2][0], ov[0], ov[1]); bv = mk(ov[2], ov[3], ov[4]);
 #pragma unroll
             for (int d = 0; d < NDOF; d++) {
-                S.q[d][e] = p.init_dof_pos[d]; S.qd[d][e] = p.init_dof_vel[d];
+                S.dof[(e) * (2 * NDOF) + 2 * (d)] = p.init_dof_pos[d]; S.dof[(e) * (2 * NDOF) + 2 * (d) + 1] = p.init_dof_vel[d];
                 orow[60 + d] = p.init_dof_pos[d]; orow[60 + NDOF + d] = p.init_dof_vel[d] * 0.1f;
             }
             prog = 0;
@@ -1083,26 +1051,14 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
 #pragma unroll
             for (int it = 0; it < (nD + kThreads - 1) / kThreads; it++) {
                 const int i = it * kThreads + tid;
-                if (i < nD) {
-                    f4v v;
-                    int ee = (4 * i) / (2 * NDOF), c = 4 * i - ee * 2 * NDOF;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { v[k] = (c & 1) ? S.qd[c >> 1][ee] : S.q[c >> 1][ee]; if (++c == 2 * NDOF) { c = 0; ee++; } }
-                    flush_store(v, dd + i);
-                }
+                if (i < nD) flush_store(reinterpret_cast<const f4v*>(S.dof)[i], dd + i);
             }
             CH_STAMP(28);
             f4v* df = reinterpret_cast<f4v*>(a.dof_force + (size_t)e0 * NDOF);
 #pragma unroll
             for (int it = 0; it < (nF + kThreads - 1) / kThreads; it++) {
                 const int i = it * kThreads + tid;
-                if (i < nF) {
-                    f4v v;
-                    int ee = (4 * i) / NDOF, d = 4 * i - ee * NDOF;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { v[k] = S.act_frc[d][ee]; if (++d == NDOF) { d = 0; ee++; } }
-                    flush_store(v, df + i);
-                }
+                if (i < nF) flush_store(reinterpret_cast<const f4v*>(S.act)[i], df + i);
             }
             CH_STAMP(29);
             f4v* dr = reinterpret_cast<f4v*>(a.root_states + (size_t)e0 * 39);
@@ -1155,12 +1111,9 @@ __global__ __launch_bounds__(kWaves * 64) void ta_chain_kernel(const TAScal P, c
             for (int t = tid; t < nvec; t += kThreads)
                 __builtin_nontemporal_store(reinterpret_cast<const f4v*>(S.u.obs)[t], reinterpret_cast<f4v*>(dobs) + t);
             if (tid < rem) dobs[4 * nvec + tid] = S.u.obs[4 * nvec + tid];
-            for (int t = tid; t < nvalid * 2 * NDOF; t += kThreads) {
-                const int ee = t / (2 * NDOF), c = t - ee * 2 * NDOF;
-                __builtin_nontemporal_store((c & 1) ? S.qd[c >> 1][ee] : S.q[c >> 1][ee], &a.dof_states[(size_t)e0 * 2 * NDOF + t]);
-            }
-            tile_out<NDOF>(a.dof_force + (size_t)e0 * NDOF, S.act_frc, nvalid, tid);
-            tile_out<39>(a.root_states + (size_t)e0 * 39, S.root, nvalid, tid);
+            for (int t = tid; t < nvalid * 2 * NDOF; t += kThreads) __builtin_nontemporal_store(S.dof[t], &a.dof_states[(size_t)e0 * 2 * NDOF + t]);
+            for (int t = tid; t < nvalid * NDOF; t += kThreads) __builtin_nontemporal_store(S.act[t], &a.dof_force[(size_t)e0 * NDOF + t]);
+            for (int t = tid; t < nvalid * 39; t += kThreads) { const int ee = t / 39, c = t - ee * 39; __builtin_nontemporal_store(S.root[c][ee], &a.root_states[(size_t)e0 * 39 + t]); }
         }
     }
     CH_STAMP(26);
