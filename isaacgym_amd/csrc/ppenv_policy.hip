@@ -1244,7 +1244,11 @@ int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream, int
                  (reinterpret_cast<uintptr_t>(L->in) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->w) & 15) == 0) cfg = 600;   // the heads
         else if (L->n >= 128) {                                                                        // falls back below when the operands do not qualify
             const long long w256 = wgs(256, 256), w192 = wgs(256, 192);
-            if (w256 >= 3 * cus / 4) cfg = (w256 < cus && w192 > w256 && w192 <= cus) ? 517 : (L->k >= 1024 ? 516 : 512);   // one partial round: 192-column tiles fill it
+            // rounds of workgroups x tile area: a launch of 1.5 rounds takes as long as one of 2 (2048 -> 1536 at M = 8192, the yaml's minibatch: 384
+            // tiles of 256 x 256 against 512 of 256 x 192 = two FULL rounds at 0.75 the area, 3 % taken off for the narrower tile's efficiency)
+            const long long r256 = (w256 + cus - 1) / cus, r192 = (w192 + cus - 1) / cus;
+            const bool fits192 = L->n % 192 == 0 && !bw;           // (the 192-column kernel has no backward store pass)
+            if (w256 >= 3 * cus / 4) cfg = (fits192 && w192 > w256 && 0.77 * (double)r192 < (double)r256) ? 517 : (L->k >= 1024 ? 516 : 512);   // (one partial round at M = 4096: 192-column tiles fill it)
             else {
                 static const bool old_ring = getenv("PPENV_MLP_RING") && atoi(getenv("PPENV_MLP_RING")) == 1;     // A/B switch: 1 = the round-2 ring kernels
                 cfg = wgs(128, 256) >= 3 * cus / 4 ? (old_ring ? 513 : 521) : (old_ring ? 514 : 520);               // 521 / 520: the DMA issue among the MFMAs

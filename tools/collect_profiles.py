@@ -15,8 +15,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 key = sys.argv[2] if len(sys.argv) > 2 else "step_kernel"
-out = os.path.join(ROOT, "profiles")
+out = os.environ.get("PROFILES_OUT", os.path.join(ROOT, "profiles"))     # on the GPU box: a directory under gpurun_out/ (the raw counter csvs are then deleted there)
 go = os.path.join(ROOT, "gpurun_out")
+os.makedirs(out, exist_ok=True)
 
 shutil.copy(os.path.join(go, "bench.json"), os.path.join(out, f"{tag}_bench.json"))
 stats = sorted(glob.glob(os.path.join(go, "prof", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
