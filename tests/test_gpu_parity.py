@@ -253,6 +253,28 @@ def test_full_size_determinism_sharding_and_invariants(torch_cuda):
         e.close()
 
 
+def test_largest_size_is_the_same_env_by_env(torch_cuda):
+    """Maximum size (the top of tools/gpu_sizes.sh's sweep: 131 072 envs, 8 x BASELINE config 3, two rounds of workgroups per CU): the first
+    16 384 envs of the big handle go through the same trajectory, bit for bit, as a 16 384-env handle — an env's result depends on its global
+    id and its actions only, never on the launch's size or on which workgroup it rides in — and the whole batch stays finite and in range."""
+    torch = torch_cuda
+    big_n, n, steps = 131072, 16384, 48
+    big = make_env(scene.build_config("TT", num_envs=big_n, seed=11))
+    ref = make_env(scene.build_config("TT", num_envs=n, seed=11))
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    for t in range(steps):
+        a = torch.rand(big_n, 7, device="cuda", generator=gen) * 2 - 1
+        big.step(a)
+        ref.step(a[:n].contiguous())
+    for name in ("obs_buf", "rew_buf", "reset_buf", "progress_buf"):
+        assert torch.equal(getattr(big, name)[:n], getattr(ref, name)), name
+    assert torch.equal(big.ball[:, :n], ref.ball) and torch.equal(big.episode[:n], ref.episode)
+    assert bool(torch.isfinite(big.obs_buf).all()) and bool(torch.isfinite(big.rew_buf).all())
+    assert float((big.ball[3:7].pow(2).sum(0) - 1).abs().max()) < 1e-4 and float(big.ball[2].min()) > -0.05
+    assert big.status == 0
+    big.close(); ref.close()
+
+
 def test_vec_task_surface(torch_cuda):
     torch = torch_cuda
     import isaacgym_amd

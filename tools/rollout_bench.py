@@ -30,8 +30,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--policy", default="native", choices=["native", "torch"])
-    ap.add_argument("--fused-input", action="store_true", help="TA: the step kernel writes the policy's first-layer input itself (ppenv_ta_sim_set_policy_input) "
-                    "instead of the separate normalise-and-pad launch — measured 207 against 205 us per rollout step: not the default")
+    ap.add_argument("--no-fused-input", dest="fused_input", action="store_false",
+                    help="TA: keep the separate normalise-and-pad launch instead of letting the step kernel write the policy's first-layer input itself "
+                         "(ppenv_ta_sim_set_policy_input; round 4's pair-wise path: 204.6 against 207.2 us per rollout step, same box — the default since)")
     args = ap.parse_args()
 
     import torch
