@@ -50,6 +50,21 @@ int ppenv_mlp_layer_forward(const ppenv_mlp_layer* layer, void* stream);
  * ppenv_mlp_layer_forward bit for bit (the tile choice does not change the summation order along k). */
 int ppenv_mlp_layer_forward_share(const ppenv_mlp_layer* layer, int32_t cus, void* stream);
 
+/* 2 .. 4 CONSECUTIVE hidden layers in one launch: layers[i + 1] reads exactly what layers[i] writes (in == out, k == n, lda == ldo,
+ * in_stride == out_stride), all with the same m and batch, all qualifying for the LDS-DMA tiles (see ppenv_mlp_layer_forward).  The
+ * layers' 128-row tiles are drawn by ticket by one persistent workgroup per CU; a tile starts when the tiles of the layer below that cover
+ * its 128 rows are done (device-scope release / acquire on a counter per layer, problem and row panel) — no launch boundary, no
+ * device-wide barrier, no assumption about workgroup order or co-residency; every wait is bounded (a timeout sets the word
+ * ppenv_mlp_chain_status reads and the launch still ends).  Same results as the per-layer launches bit for bit.
+ * workspace: ppenv_mlp_chain_workspace_bytes(m, batch, count) bytes of device memory, zeroed ONCE by the caller before the first use (each
+ * launch leaves its counters zeroed again) and not shared between launches that may run concurrently.  The reference's rollout has
+ * eight dependent launches per policy forward (cfg/train/HumanoidPingpongTiltG1PPO.yaml:25-31: six hidden layers, heads, input
+ * normalisation); at 4096 rows each launch boundary costs about as much as a narrow layer's arithmetic. */
+size_t ppenv_mlp_chain_workspace_bytes(int32_t m, int32_t batch, int32_t count);
+int ppenv_mlp_chain_forward(const ppenv_mlp_layer* layers, int32_t count, void* workspace, void* stream);
+/* 0, or 1 after a wait inside ppenv_mlp_chain_forward timed out (sticky; synchronises with the device) */
+int ppenv_mlp_chain_status(const void* workspace);
+
 /* The first layer's input as its own small launch, so that layer 1 runs on the LDS-DMA kernels too:
  * out[m, ld_out] (fp16) = clamp((obs[m, k] - mean) * inv_std, -clip, clip) in columns < k, zero in columns k .. ld_out - 1
  * (ld_out: k rounded up to a multiple of 64; layer 1's weight rows are zero-padded to the same length).  mean / inv_std NULL: cast

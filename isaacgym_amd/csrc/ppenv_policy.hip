@@ -751,16 +751,16 @@ __global__ __launch_bounds__(512) void mlp_layer_pp1_kernel(const Args a, const 
 // it waits (vmcnt(2P): all but tile t + 2) before the barrier that releases tile t + 1 — to itself at once, to the lagging group one barrier
 // later.  Tile t + 2 overwrites the buffer of tile t - 1, which the lagging group finished reading (lgkmcnt(0)) before its first barrier of
 // iteration t - 1 = the leading group's second barrier of t - 1; the leading group issues after its first barrier of t.
-template <int TJ>
-__global__ __launch_bounds__(512) void mlp_layer_pp3_kernel(const Args a, const int tiles_n, const int tiles_m) {
-    constexpr int BM = 128, BN = 128 * TJ, BK = 64, TI = 2, NA = 2, NB = 2 * TJ, P2 = 2 * (NA + NB), TILE = (BM + BN) * BK;   // P2: pieces per LEADING wave and tile
-    constexpr int kOperand = 3 * TILE, kPatch = 8 * 64 * PATCH_LD;
+template <int TJ> struct PP3 {
+    static constexpr int BM = 128, BN = 128 * TJ, BK = 64, TI = 2, NA = 2, NB = 2 * TJ, P2 = 2 * (NA + NB), TILE = (BM + BN) * BK;   // P2: pieces per LEADING wave and tile
+    static constexpr int kOperand = 3 * TILE, kPatch = 8 * 64 * PATCH_LD, kSmem = kOperand > kPatch ? kOperand : kPatch;            // three [A | B] tiles; afterwards the epilogue patches
     static_assert(P2 % 4 == 0 && P2 <= 63, "a quarter of the pieces after each K sub-step");
-    __shared__ __attribute__((aligned(16))) _Float16 smem[kOperand > kPatch ? kOperand : kPatch];   // three [A | B] tiles; afterwards the epilogue patches
+};
+// one 128 x BN tile of `out` (problem b, origin (m0, n0)) by the calling workgroup; smem: PP3<TJ>::kSmem fp16, free on entry (every wave past a barrier after its last use)
+template <int TJ>
+__device__ __forceinline__ void pp3_tile(const Args& a, _Float16* smem, const int m0, const int n0, const int b) {
+    constexpr int BM = PP3<TJ>::BM, BK = PP3<TJ>::BK, TI = PP3<TJ>::TI, NA = PP3<TJ>::NA, NB = PP3<TJ>::NB, P2 = PP3<TJ>::P2, TILE = PP3<TJ>::TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
-    const int nwg = tiles_n * tiles_m, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int n0 = (id % tiles_n) * BN, m0 = (id / tiles_n) * BM, b = blockIdx.y;
     const _Float16* W = a.w + (size_t)b * a.w_stride;
     const _Float16* in = reinterpret_cast<const _Float16*>(a.in) + (size_t)b * a.in_stride;
     PPM_STAMP_RT(27); PPM_STAMP_AT(26);
@@ -848,6 +848,89 @@ __global__ __launch_bounds__(512) void mlp_layer_pp3_kernel(const Args a, const 
     PPM_STAMP_AT(31);
     epilogue<TI, TJ>(a, acc, smem, m0 + wm * 64, n0 + wn * 32 * TJ, b);
     PPM_STAMP_AT(29); PPM_STAMP_RT(28);
+}
+template <int TJ>
+__global__ __launch_bounds__(512) void mlp_layer_pp3_kernel(const Args a, const int tiles_n, const int tiles_m) {
+    __shared__ __attribute__((aligned(16))) _Float16 smem[PP3<TJ>::kSmem];
+    const int nwg = tiles_n * tiles_m, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;      // consecutive workgroup ids go round the XCDs: a contiguous run of tiles each
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    pp3_tile<TJ>(a, smem, (id / tiles_n) * PP3<TJ>::BM, (id % tiles_n) * PP3<TJ>::BN, blockIdx.y);
+}
+
+// ---- consecutive layers in ONE launch (round 4): persistent workgroups take tiles by ticket, a tile waits for its rows of the layer below ----
+//
+// A layer launch at M = 4096 is one round of workgroups that load, multiply and store in step: per launch ~3 us of dispatch and first round trip
+// and 2.5-6 us of dirty-line write-back sit outside the K loops (tools/gpu_mlp_phases.py), four to seven times per forward.  Here up to four
+// consecutive hidden layers (all on the 128-row ring tiles) are the tiles of one launch: gridDim.x workgroups (one per CU) draw tickets from a
+// counter; ticket order is layer by layer, and within a layer row panel by row panel, so the tile a workgroup draws depends only on tiles with
+// LOWER tickets — every one of which some running workgroup has already drawn and will finish without waiting on anything higher: no ordering
+// or co-residency of workgroups is assumed.  A tile of layer l > 0 for the 128-row panel p of problem b waits until all tiles_n[l - 1] tiles of
+// (l - 1, b, p) have been counted; a finished tile is counted after every thread's agent-scope fence behind its stores and a barrier (release),
+// the waiting lane reads the counter with acquire semantics (which also drops the CU's stale L1 / L2 lines of the activation buffer, rewritten
+// every forward) and the barrier behind it releases the other waves.  Every wait is bounded: a timeout sets word 2 of the workspace and goes on.
+// The last workgroup to finish zeroes the counters for the next launch.
+struct ChainArgs {
+    Args a[4];
+    int count, batch, tiles_m, debug;    // debug (PPENV_CHAIN_DEBUG, diagnostic): 1 no tiles (tickets and counters only), 2 no waits
+    int tj[4], tiles_n[4], first[5];      // per layer: 128-column units per tile (1 | 2), tiles along N, first ticket (first[count] = all tickets)
+    unsigned* sync;                      // [0] ticket, [1] workgroups finished, [2] error flag (sticky), [3 + (l * batch + b) * tiles_m + p] tiles done
+};
+__global__ __launch_bounds__(512) void mlp_chain_pp3_kernel(const ChainArgs c) {
+    __shared__ __attribute__((aligned(16))) _Float16 smem[PP3<2>::kSmem];
+    __shared__ unsigned s_word;
+    const int tid = threadIdx.x;
+    // one value from thread 0 to the whole workgroup, as a SCALAR (the loop below and every branch in it are then uniform for the compiler too: with the
+    // ticket in a vector register it nested the barrier inside per-lane exit masks).  Also the barrier that frees smem between two tiles.
+    auto broadcast = [&](unsigned v) -> int {
+        if (tid == 0) s_word = v;
+        __syncthreads();
+        const int r = __builtin_amdgcn_readfirstlane((int)s_word);
+        __syncthreads();                                            // s_word may be rewritten after this
+        return r;
+    };
+    auto ticket = [&]() -> int {
+        unsigned v = 0;
+        if (tid == 0) v = __hip_atomic_fetch_add(&c.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return broadcast(v);
+    };
+    const int total = c.first[c.count];
+    for (int t = ticket(); t < total; t = ticket()) {
+        int l = 0;
+        while (l + 1 < c.count && t >= c.first[l + 1]) l++;
+        const int idx = t - c.first[l], tn = c.tiles_n[l];
+        const int j = idx % tn, pb = idx / tn, b = pb % c.batch, p = pb / c.batch;      // row panel by row panel, both problems of a panel side by side
+        if (l > 0 && !(c.debug & 2)) {
+            if (tid == 0) {
+                const unsigned* cnt = &c.sync[3 + ((l - 1) * c.batch + b) * c.tiles_m + p];
+                const unsigned need = (unsigned)c.tiles_n[l - 1];
+                // relaxed polls (an acquire per poll would invalidate the XCD's L2 under the working tiles), ONE acquire fence once the count is there.
+                // Bounded: ~0.1 s, and after the first timeout anywhere (word 2) nobody waits any more — the launch ends, its results are void.
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if ((++spins & 63u) == 0 && (spins > (1u << 16) || __hip_atomic_load(&c.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        __hip_atomic_store(&c.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+        }
+        if (c.debug & 1) { }
+        else if (c.tj[l] == 2) pp3_tile<2>(c.a[l], smem, p * 128, j * 256, b);
+        else pp3_tile<1>(c.a[l], smem, p * 128, j * 128, b);
+        if (l + 1 < c.count) {
+            __syncthreads();                                       // every wave's stores of the tile are performed (workgroup-scope release: vmcnt(0)) ...
+            if (tid == 0) __hip_atomic_fetch_add(&c.sync[3 + (l * c.batch + b) * c.tiles_m + p], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... and ONE write-back of the L2 publishes them with the count
+        }
+    }
+    unsigned last = 0;
+    if (tid == 0) last = __hip_atomic_fetch_add(&c.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    if (broadcast(last)) {                                         // nobody else touches the workspace any more
+        const int words = 3 + (c.count - 1) * c.batch * c.tiles_m;
+        for (int i = tid; i < words; i += 512) if (i != 2) __hip_atomic_store(&c.sync[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- K tiles taken in turn by the two wave groups (round 4): the narrow layers at the rollout's M = 4096 ----
@@ -1309,6 +1392,54 @@ int launch_layer(const ppenv_mlp_layer* L, const BwdInput* bw, void* stream, int
 }  // namespace
 
 extern "C" int ppenv_mlp_layer_forward(const ppenv_mlp_layer* L, void* stream) { return launch_layer(L, nullptr, stream); }
+
+// 2 .. 4 consecutive hidden layers in one launch (include/ppenv_policy.h)
+extern "C" size_t ppenv_mlp_chain_workspace_bytes(int32_t m, int32_t batch, int32_t count) {
+    if (m <= 0 || batch <= 0 || count < 2 || count > 4) return 0;
+    return sizeof(unsigned) * (size_t)(3 + (count - 1) * batch * ((m + 127) / 128));
+}
+extern "C" int ppenv_mlp_chain_status(const void* workspace) {
+    unsigned w[3] = {0, 0, 0};
+    if (!workspace || hipMemcpy(w, workspace, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) { ppenv_set_error("ppenv_mlp_chain_status: NULL or unreadable workspace"); return PPENV_EHIP; }
+    return w[2] ? 1 : 0;
+}
+extern "C" int ppenv_mlp_chain_forward(const ppenv_mlp_layer* layers, int32_t count, void* workspace, void* stream) {
+    if (!layers || !workspace || count < 2 || count > 4 || (reinterpret_cast<uintptr_t>(workspace) & 3)) {
+        ppenv_set_error("ppenv_mlp_chain_forward: 2 .. 4 layers and a 4-byte aligned workspace of ppenv_mlp_chain_workspace_bytes (zeroed once, by the caller)");
+        return PPENV_EINVAL;
+    }
+    ChainArgs c{};
+    { const char* dbg = getenv("PPENV_CHAIN_DEBUG"); c.debug = dbg ? atoi(dbg) : 0; }
+    c.count = count; c.batch = layers[0].batch; c.tiles_m = (layers[0].m + 127) / 128; c.sync = reinterpret_cast<unsigned*>(workspace);
+    int ticket = 0;
+    for (int l = 0; l < count; l++) {
+        const ppenv_mlp_layer* L = &layers[l];
+        const bool ok = L->in && L->w && L->out && L->m == layers[0].m && L->batch == c.batch && L->m > 0 && L->n >= 128 && L->k > 0 && !L->in_f32 && !L->out_f32 &&
+                        L->k % 64 == 0 && L->lda >= L->k && L->ldw >= L->k && L->ldo >= L->n && L->lda % 8 == 0 && L->ldw % 8 == 0 && L->ldo % 8 == 0 &&
+                        L->in_stride % 8 == 0 && L->w_stride % 8 == 0 && L->out_stride % 8 == 0 &&
+                        (reinterpret_cast<uintptr_t>(L->in) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->w) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->out) & 15) == 0;
+        const bool chained = l == 0 || (L->in == layers[l - 1].out && L->k == layers[l - 1].n && L->lda == layers[l - 1].ldo && L->in_stride == layers[l - 1].out_stride);
+        if (!ok || !chained) {
+            ppenv_set_error("ppenv_mlp_chain_forward: every layer must qualify for the LDS-DMA ring tiles (fp16 in / out, k % 64 == 0, n >= 128, 16-byte aligned rows, "
+                            "equal m and batch) and read exactly what the layer before it writes");
+            return PPENV_EINVAL;
+        }
+        c.a[l] = Args{L->m, L->n, L->k, L->lda, L->ldw, L->ldo, L->elu, L->out_f32, L->in, (long long)L->in_stride, L->mean, L->inv_std, L->clip,
+                      reinterpret_cast<const _Float16*>(L->w), (long long)L->w_stride, reinterpret_cast<const _Float16*>(L->bias), (long long)L->bias_stride,
+                      L->out, (long long)L->out_stride};
+        const long long w256 = (long long)((L->n + 255) / 256) * c.tiles_m * c.batch;
+        c.tj[l] = w256 >= 192 ? 2 : 1;                              // as launch_layer: 128 x 256 where that still gives three quarters of the CUs a tile
+        c.tiles_n[l] = (L->n + 128 * c.tj[l] - 1) / (128 * c.tj[l]);
+        c.first[l] = ticket;
+        ticket += c.tiles_n[l] * c.tiles_m * c.batch;
+    }
+    c.first[count] = ticket;
+    static int cus = 0;
+    if (cus == 0) { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { ppenv_set_error("hipGetDeviceProperties failed"); return PPENV_EHIP; } cus = prop.multiProcessorCount; }
+    hipLaunchKernelGGL(mlp_chain_pp3_kernel, dim3(ticket < cus ? ticket : cus), dim3(512), 0, (hipStream_t)stream, c);
+    if (hipGetLastError() != hipSuccess) { ppenv_set_error("launching mlp_chain_pp3_kernel failed"); return PPENV_EHIP; }
+    return PPENV_OK;
+}
 
 // The same layer with its grid sized for `cus` of the chip's 256 CUs (include/ppenv_policy.h): the tile choice above aims at one workgroup
 // per CU of that share, so that the launch sequences of two (cus = 128) env groups on two streams run side by side instead of queueing.

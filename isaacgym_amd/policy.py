@@ -13,6 +13,7 @@ kernel (v_mfma_f32_32x32x16_f16, fp32 accumulation):
 PyTorch is only the owner of the device buffers here.  Weights are cast to fp16 once (`load`), as autocast does per call.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -69,6 +70,10 @@ def _lib_policy():
     L._policy_bound = True
     L.ppenv_mlp_layer_forward.argtypes = [C.POINTER(MLPLayer), C.c_void_p]
     L.ppenv_mlp_layer_forward_share.argtypes = [C.POINTER(MLPLayer), C.c_int32, C.c_void_p]
+    L.ppenv_mlp_chain_workspace_bytes.restype = C.c_size_t
+    L.ppenv_mlp_chain_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.ppenv_mlp_chain_forward.argtypes = [C.POINTER(MLPLayer), C.c_int32, C.c_void_p, C.c_void_p]
+    L.ppenv_mlp_chain_status.argtypes = [C.c_void_p]
     L.ppenv_mlp_prepare_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
     L.ppenv_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ppenv_mlp_heads_sample.argtypes = [C.POINTER(MLPLayer), C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -121,6 +126,23 @@ def layer_forward(out, x, w, bias, elu, cus=0, **kw):
         _lib.check(_lib_policy().ppenv_mlp_layer_forward_share(C.byref(d), cus, torch.cuda.current_stream(x.device).cuda_stream))
     else:
         _lib.check(_lib_policy().ppenv_mlp_layer_forward(C.byref(d), torch.cuda.current_stream(x.device).cuda_stream))
+
+
+def chain_workspace(m, batch, count, device):
+    """The zeroed workspace of ppenv_mlp_chain_forward for `count` chained layers of m rows x batch problems."""
+    n = _lib_policy().ppenv_mlp_chain_workspace_bytes(m, batch, count)
+    assert n > 0
+    return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
+
+
+def chain_forward(descriptors, workspace):
+    """ppenv_mlp_chain_forward on a list of layer descriptors (_descriptor): consecutive hidden layers in one launch."""
+    arr = (MLPLayer * len(descriptors))(*descriptors)
+    _lib.check(_lib_policy().ppenv_mlp_chain_forward(arr, len(descriptors), workspace.data_ptr(), torch.cuda.current_stream(workspace.device).cuda_stream))
+
+
+def chain_status(workspace):
+    return _lib_policy().ppenv_mlp_chain_status(workspace.data_ptr())
 
 
 def heads_sample(out, x, w, bias, num_actions, actions, sigma, seed, counter, lo=-1.0, hi=1.0, neglogp=None):
@@ -269,6 +291,10 @@ class NativeMLP:
         (M = 4096, 313 observations: 54 us fused, see DESIGN.md §5a for the split path)."""
         self.device = torch.device(device)
         self.fuse_input, self.cus = bool(fuse_input), int(cus)
+        # chain = (first, last): the hidden layers first .. last (1-based, first >= 2) run as ONE launch (ppenv_mlp_chain_forward); PPENV_MLP_CHAIN="3,6" sets it
+        env_chain = os.environ.get("PPENV_MLP_CHAIN")
+        self.chain = tuple(int(x) for x in env_chain.split(",")) if env_chain else None
+        self._chain_ws = None
         assert len(actor) == len(critic) and all(a[0].shape[0] == c[0].shape[0] for a, c in zip(actor[:-1], critic[:-1]))
         self.num_obs, self.clip = int(num_obs), float(clip)
         self.units = [a[0].shape[0] for a in actor[:-1]]
@@ -283,8 +309,8 @@ class NativeMLP:
         """Another forward context on the SAME operand images and statistics (no copy: one set of weights in HBM / L2) with its own
         activation buffers — one per env group when groups of envs are stepped on separate streams (collector.PipelinedRollout)."""
         other = object.__new__(NativeMLP)
-        other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("h", "head_out", "mu", "value", "x16", "_rows")})
-        other._rows = 0
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("h", "head_out", "mu", "value", "x16", "_rows", "_chain_ws")})
+        other._rows, other._chain_ws = 0, None        # (the chain workspace belongs to one launch sequence: groups on separate streams each get their own)
         if max_rows:
             other._alloc(max_rows)
         return other
@@ -366,9 +392,19 @@ class NativeMLP:
             if not prepared:
                 prepare_input(self.x16, obs, self.mean, self.inv_std, self.clip)
             layer_forward(self.h[0], self.x16, w0, self.b[0].view(-1), elu=True, cus=self.cus)
-        for i in range(1, len(u)):
-            layer_forward(self.h[i], self.h[i - 1], self.w[i], self.b[i], elu=True, cus=self.cus, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],
-                          bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])
+        hidden = lambda i: dict(out=self.h[i], x=self.h[i - 1], w=self.w[i], bias=self.b[i], elu=True, batch=2, in_stride=u[i - 1], w_stride=u[i] * self.w[i].shape[-1],
+                                bias_stride=u[i], out_stride=u[i], m=m, n=u[i], k=u[i - 1])
+        i = 1
+        while i < len(u):
+            if self.chain and not self.cus and i == self.chain[0] - 1:          # layers chain[0] .. chain[1] in one launch
+                last = min(self.chain[1], len(u))
+                if self._chain_ws is None or self._chain_rows != m:
+                    self._chain_ws, self._chain_rows = chain_workspace(m, 2, last - i, self.device), m
+                chain_forward([_descriptor(**hidden(k)) for k in range(i, last)], self._chain_ws)
+                i = last
+                continue
+            layer_forward(cus=self.cus, **hidden(i))
+            i += 1
         ho = self.head_out if head_out is None else head_out
         mu, value = ho[:, :self.num_actions], ho[:, self.num_actions:]
         if sample is None or self.num_actions + 1 > 32:        # the skinny heads kernel (and with it the fused draw) takes up to 32 columns

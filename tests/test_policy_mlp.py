@@ -244,6 +244,40 @@ def test_step_kernel_writes_the_policy_input(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,span", [(4096, (3, 6)), (4096, (5, 6)), (2048, (2, 5)), (1000, (3, 6)), (8192, (4, 6))])
+def test_chained_layers_equal_the_per_layer_launches(m, span, monkeypatch):
+    """ppenv_mlp_chain_forward: consecutive hidden layers of the reference's network as ONE launch (persistent workgroups, tiles by ticket, a
+    tile waits for its rows of the layer below) — every activation buffer bit-identical to the per-layer launches (same tile kernels, same
+    summation order), on random fp16 data with ELU, repeated (the release / acquire hand-off must hold launch after launch on the SAME buffers),
+    ragged M included; the workspace's error word stays clear."""
+    import torch
+    from isaacgym_amd.policy import UNITS, _descriptor, chain_forward, chain_status, chain_workspace, layer_forward
+    gen = torch.Generator(device="cuda").manual_seed(m + span[0])
+    u = UNITS
+    first, last = span                                     # 1-based hidden layers first .. last; layer i reads h[i - 2], writes h[i - 1]
+    w = {i: (torch.randn(2, u[i - 1], u[i - 2], device="cuda", generator=gen) / u[i - 2] ** 0.5).half() for i in range(first, last + 1)}
+    b = {i: (torch.randn(2, u[i - 1], device="cuda", generator=gen) * 0.1).half() for i in range(first, last + 1)}
+    kw = lambda i, h: dict(out=h[i - 1], x=h[i - 2], w=w[i], bias=b[i], elu=True, batch=2, in_stride=u[i - 2], w_stride=u[i - 1] * u[i - 2], bias_stride=u[i - 1],
+                           out_stride=u[i - 1], m=m, n=u[i - 1], k=u[i - 2])
+    ws = chain_workspace(m, 2, last - first + 1, "cuda")
+    for rep in range(6):
+        x = torch.randn(m, 2 * u[first - 2], device="cuda", generator=gen).half()
+        ha = {first - 2: x, **{i - 1: torch.full((m, 2 * u[i - 1]), 7.0, dtype=torch.float16, device="cuda") for i in range(first, last + 1)}}
+        hb = {first - 2: x, **{i - 1: torch.full((m, 2 * u[i - 1]), -7.0, dtype=torch.float16, device="cuda") for i in range(first, last + 1)}} if rep == 0 else hb
+        hb[first - 2] = x
+        for i in range(first, last + 1):           # the per-layer launch on the tile the chain uses for this layer (128 x 256 where that gives 192 tiles, else 128 x 128)
+            monkeypatch.setenv("PPENV_MLP_TILE", "521" if ((u[i - 1] + 255) // 256) * ((m + 127) // 128) * 2 >= 192 else "520")
+            layer_forward(**kw(i, ha))
+        monkeypatch.delenv("PPENV_MLP_TILE")
+        chain_forward([_descriptor(**kw(i, hb)) for i in range(first, last + 1)], ws)
+        torch.cuda.synchronize()
+        for i in range(first, last + 1):
+            assert torch.equal(ha[i - 1], hb[i - 1]), (rep, i, int((ha[i - 1] != hb[i - 1]).sum()))
+    assert chain_status(ws) == 0
+    assert int(ws[:2].abs().sum()) == 0 and int(ws[3:].abs().sum()) == 0          # the counters are left zeroed for the next launch
+
+
+@pytest.mark.gpu
 def test_attached_env_feeds_the_forward_from_the_first_call():
     """NativeMLP.attach_env: the step kernel writes the network's first-layer input, and attach_env itself fills it from the CURRENT obs_buf —
     forward(prepared=True) equals the forward with its own normalise-and-pad launch bit for bit before any step and after every step."""
