@@ -211,8 +211,8 @@ def test_dma_tiles_exact_at_full_size_repeated(tile, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [4096, 1000])
-def test_step_kernel_writes_the_policy_input(n):
+@pytest.mark.parametrize("n,noise", [(4096, False), (1000, False), (1024, True)])
+def test_step_kernel_writes_the_policy_input(n, noise):
     """SURVEY.md §8(f) N2, "fuse obs normalisation into the step kernel": with ppenv_ta_sim_set_policy_input the chain-wave step writes
     the policy's first-layer input next to obs_buf — bit for bit what ppenv_mlp_prepare_input makes of the obs_buf of the same step
     (ragged last workgroup included), obs_buf itself unchanged; and switched off again it is no longer written."""
@@ -223,6 +223,9 @@ def test_step_kernel_writes_the_policy_input(n):
     if env.sim.kernel != "chain":
         pytest.skip("the chain-wave kernel is not the one in use")
     ref = TAEnv(n, device="cuda:0", seed=3)
+    if noise:      # observation noise rewrites the whole tile after the task arithmetic: the policy's rows must be made from the NOISY row (what obs_buf holds)
+        for e in (env, ref):
+            e.set_randomization(action_noise_sigma=0.01, observation_noise_sigma=0.004)
     gen = torch.Generator(device="cuda").manual_seed(9)
     mean = torch.randn(313, device="cuda", generator=gen) * 0.3
     inv_std = torch.rand(313, device="cuda", generator=gen) * 3 + 0.2
