@@ -185,6 +185,52 @@ def _welded_to(joint, name):
     return name
 
 
+def test_parser_ignores_what_a_real_file_carries_beside_the_dynamics():
+    """A manufacturer's URDF is full of elements the tables have no use for — <visual> meshes and materials, <dynamics>, <safety_controller>,
+    <gazebo> / <transmission> blocks, comments, a <limit> without lower / upper on a continuous joint: none of them may change the model or trip
+    the parser, and the elements that DO matter are read from the same joint."""
+    text = """<?xml version="1.0"?>
+    <!-- exported by some CAD plug-in -->
+    <robot name="excerpt" xmlns:xacro="http://www.ros.org/wiki/xacro">
+      <material name="dark"><color rgba="0.2 0.2 0.2 1"/></material>
+      <link name="base">
+        <inertial><origin xyz="0 0 0.1" rpy="0 0 0"/><mass value="2.0"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.02" iyz="0" izz="0.03"/></inertial>
+        <visual><origin xyz="0 0 0"/><geometry><mesh filename="meshes/base.STL" scale="1 1 1"/></geometry><material name="dark"/></visual>
+        <collision><origin xyz="0 0 0.1"/><geometry><box size="0.2 0.2 0.2"/></geometry></collision>
+      </link>
+      <link name="arm">
+        <inertial><origin xyz="0.1 0 0"/><mass value="0.5"/><inertia ixx="0.001" iyy="0.002" izz="0.002"/></inertial>
+        <visual><geometry><mesh filename="meshes/arm.STL"/></geometry></visual>
+        <collision><origin xyz="0.1 0 0" rpy="0 1.5708 0"/><geometry><cylinder radius="0.02" length="0.2"/></geometry></collision>
+      </link>
+      <link name="wheel"><inertial><mass value="0.1"/><inertia ixx="1e-4" iyy="1e-4" izz="1e-4"/></inertial></link>
+      <joint name="shoulder" type="revolute">
+        <origin xyz="0 0 0.2" rpy="0 0 0"/><parent link="base"/><child link="arm"/><axis xyz="0 1 0"/>
+        <limit lower="-1.0" upper="2.0" effort="25" velocity="37"/>
+        <dynamics damping="0.001" friction="0.1"/>
+        <safety_controller soft_lower_limit="-0.9" soft_upper_limit="1.9" k_position="100" k_velocity="10"/>
+      </joint>
+      <joint name="spin" type="continuous"><origin xyz="0.2 0 0"/><parent link="arm"/><child link="wheel"/><axis xyz="1 0 0"/><limit effort="5" velocity="22"/></joint>
+      <transmission name="t1"><type>transmission_interface/SimpleTransmission</type><joint name="shoulder"/></transmission>
+      <gazebo reference="arm"><material>Gazebo/Grey</material></gazebo>
+    </robot>"""
+    r = urdf.parse(text)
+    assert set(r.links) == {"base", "arm", "wheel"} and set(r.joints) == {"shoulder", "spin"}
+    j = r.joints["shoulder"]
+    assert (j.lower, j.upper, j.effort, j.velocity) == (-1.0, 2.0, 25.0, 37.0) and tuple(j.axis) == (0.0, 1.0, 0.0)
+    c = r.joints["spin"]
+    assert c.type == "continuous" and c.effort == 5.0 and c.lower == pytest.approx(-np.pi) and c.upper == pytest.approx(np.pi)
+    assert [col.kind for col in r.links["base"].collisions] == ["box"] and [col.kind for col in r.links["arm"].collisions] == ["cylinder"]   # visuals are not collisions
+    assert r.links["arm"].mass == 0.5 and np.allclose(r.links["arm"].inertia, np.diag([0.001, 0.002, 0.002]))                                   # missing ixy / ixz / iyz are zero
+    assert not r.dropped_mesh_collisions
+    specs = urdf.arm_specs(r, ["shoulder", "spin"])
+    assert [s["axis"] for s in specs] == [1, 0] and specs[0]["limits"] == (-1.0, 2.0)
+    with pytest.raises(ValueError, match="not \\+x, \\+y or \\+z"):          # a flipped axis changes the sign convention of q: refused by name, not silently mirrored
+        urdf.arm_specs(urdf.parse(text.replace('<axis xyz="0 1 0"/>', '<axis xyz="0 -1 0"/>')), ["shoulder"])
+    with pytest.raises(ValueError, match="prismatic"):
+        urdf.parse(text.replace('type="continuous"', 'type="prismatic"'))
+
+
 def test_collision_geometry_of_a_hand_written_urdf():
     """<collision> primitives -> ball shapes, paddle blade and ground-contact points; the expected tables are typed in, the asset is
     not derived from scene.py."""
