@@ -59,17 +59,18 @@ def test_post_physics_matches_reference_golden(torch_cuda, variant):
     env.close()
 
 
-@pytest.mark.parametrize("variant,n", [("TT", 1024), ("TN", 1024), ("T3", 1024), ("TT", 4096), ("T3", 4096)])
+@pytest.mark.parametrize("variant,n", [("TT", 1024), ("TN", 1024), ("T3", 1024), ("TT", 4096), ("T3", 4096), ("TT", 16384)])
 def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant, n):
     """The fused step kernel vs the oracle, both restarted from the oracle's state every step.  (TT / T3 at 4096 envs: BASELINE.json
-    configs[1] as named — "3-actor, num_envs=4096 on 1 MI355X, fp32, random actions, obs/reward parity".)"""
+    configs[1] as named — "3-actor, num_envs=4096 on 1 MI355X, fp32, random actions, obs/reward parity"; TT at 16 384 envs: configs[2], the bandwidth run's size, one full
+    round of workgroups on the chip.)"""
     torch = torch_cuda
     cfg = scene.build_config(variant, num_envs=n, seed=7)
     o = oracle_lib.OracleEnv(cfg, threads=8)
     env = make_env(scene.build_config(variant, num_envs=n, seed=7))
     rng = np.random.default_rng(1)
     oa, ra = obs_atol(), reward_atol(cfg)
-    steps = 180 if variant == "TN" else (120 if n <= 1024 else 90)
+    steps = 180 if variant == "TN" else (120 if n <= 1024 else (90 if n <= 4096 else 60))
     resets = 0
     probe = SensitivityProbe(oracle_lib, cfg)
     log = ExclusionLog(f"gpu fused step vs oracle [{variant}, n={n}]", bound=0.005)
@@ -92,7 +93,7 @@ def test_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, variant,
         assert_close(v.rew_buf, o.rew_buf, f"rew step {t}", atol=ra)
         o = o_all
         resets += int(o.reset_buf.sum())
-    assert resets > 50   # the masked-reset path was exercised
+    assert resets > (50 if n <= 4096 else 10)   # the masked-reset path was exercised (the full-size case runs fewer steps)
     log.close()          # prints excluded count + worst retained error, asserts the bound
     env.close()
 

@@ -120,7 +120,7 @@ class DevView:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("schedule,n", [("split", 1024), ("split", 200), ("split3", 200)])
+@pytest.mark.parametrize("schedule,n", [("split", 1024), ("split", 200), ("split3", 200), ("split", 8192)])   # 8192: BASELINE config 4's per-GPU size, as named
 def test_t4_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, monkeypatch, schedule, n):
     """The three-wave kernel (arm 1 / arm 2 / ball) in both hand-off forms — the arm waves sweep the collision geometry
     (default), or the ball wave does from the published (q, qd) — vs the oracle, restarted from the oracle's state every
@@ -140,7 +140,7 @@ def test_t4_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, monke
     probe = SensitivityProbe(oracle_lib, cfg)
     resets = 0
     log = ExclusionLog(f"gpu 4-actor step vs oracle [{schedule}]", bound=0.01)
-    for t in range(160):
+    for t in range(160 if n < 4096 else 40):
         actions = rng.uniform(-1.2, 1.2, (2 * n, 7)).astype(np.float32)
         st = o.get_state()
         env.set_state(st)
@@ -150,7 +150,7 @@ def test_t4_fused_step_matches_oracle_single_steps(torch_cuda, oracle_lib, monke
         log.add(keep)
         _check_step(mask_envs(DevView(env), keep, 2), mask_envs(o, keep, 2), t, oa, ra)
         resets += int(o.reset_buf.sum())
-    assert resets > 50
+    assert resets > 50 or n >= 4096       # (the 40 steps of the full-size case end before the first episode does)
     log.close()
     # gym.refresh_* equivalents in the 4-actor layouts
     env.set_state(o.get_state())

@@ -305,6 +305,20 @@ def test_ta_chain_kernel_step_matches_oracle(oracle_lib, monkeypatch, n):
 
 
 @pytest.mark.gpu
+def test_ta_chain_kernel_step_matches_oracle_at_config_5_size(oracle_lib, monkeypatch):
+    """The same comparison at BASELINE config 5's per-GPU size as named, 4096 envs = 64 full workgroups (the runs above are 640 / 1000 / 50):
+    fewer steps (the oracle and its jitter probe cost ~0.3 s per step here), episodeLength 10 so that every env still resets twice inside them."""
+    from isaacgym_amd.tensor_api import TAEnv
+    monkeypatch.setenv("PPENV_TA_KERNEL", "chain")
+    n = 4096
+    cfg, m = scene.build_ta_scene(n), scene.build_ta_model()
+    env = TAEnv(n, device="cuda:0", seed=12, env={"episodeLength": 10}, materialize_rb=True)
+    assert env.sim.kernel == "chain"
+    run_chain_step_parity(oracle_lib, env, cfg, m, f"gpu 27-dof chain-wave step vs oracle [n={n}, config 5's size]", steps=24, min_resets_per_env=2)
+    env.close()
+
+
+@pytest.mark.gpu
 def test_ta_gravity_setter_reaches_every_kernel(oracle_lib, monkeypatch):
     """ppenv_ta_sim_set_gravity (the yaml's randomization_params.sim_params.gravity for this task, 27DOFG1.yaml:123-124): the chain-wave
     step — links through the by-value constants, ball through StepConsts in device memory — and the table-driven kernels follow the oracle
