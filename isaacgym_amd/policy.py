@@ -417,6 +417,33 @@ class NativeMLP:
                          sample["counter"], sample.get("lo", -1.0), sample.get("hi", 1.0), sample.get("neglogp"))
         return mu, value
 
+    def forward_net(self, which, obs, prepared=False, sample=None, head_out=None):
+        """ONE of the two networks (which = 0: the actor -> mu, and with `sample` the drawn actions; 1: the critic -> value) as its own launch
+        sequence of single-problem layers on the same operand images and activation buffers as forward().  For running the two networks on
+        separate streams: only the actor is in front of the env step (tools/gpu_rollout_split.py; measured, not the default)."""
+        m = obs.shape[0]
+        assert m == self._rows and not self.fuse_input
+        u, na = self.units, self.num_actions
+        cols = lambda t, n: t[:, which * n:(which + 1) * n]
+        if which == 0 and not prepared:
+            prepare_input(self.x16, obs, self.mean, self.inv_std, self.clip)
+        layer_forward(cols(self.h[0], u[0]), self.x16, self.w[0][which], self.b[0][which], elu=True, cus=self.cus)
+        for i in range(1, len(u)):
+            layer_forward(cols(self.h[i], u[i]), cols(self.h[i - 1], u[i - 1]), self.w[i][which], self.b[i][which], elu=True, cus=self.cus)
+        ho = self.head_out if head_out is None else head_out
+        ul = u[-1]
+        if which == 0:
+            x, w, b, out = cols(self.h[-1], ul), self.head_w[:na, :ul], self.head_b[:na], ho[:, :na]
+            if sample is not None:
+                heads_sample(out, x, w, b, na, sample["actions"], sample["sigma"], sample["seed"], sample["counter"], sample.get("lo", -1.0), sample.get("hi", 1.0),
+                             sample.get("neglogp"))
+            else:
+                layer_forward(out, x, w, b, elu=False)
+            return out
+        out = ho[:, na:]
+        layer_forward(out, cols(self.h[-1], ul), self.head_w[na:, ul:], self.head_b[na:], elu=False)
+        return out
+
     @staticmethod
     def flops(m, num_obs, units=UNITS, num_actions=0):
         dims = [num_obs] + list(units)
