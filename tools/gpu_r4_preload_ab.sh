@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B: HEAD's library without kernarg preload (build_variants/tt_base) against the working tree's (leading pointer arguments preloaded into SGPRs)
 set -o pipefail
+[ -f build_variants/tt_base/libppenv.so ] || { echo "build_variants/tt_base/libppenv.so is missing: build the baseline first, in the container — git stash; python -c \"from isaacgym_amd import _lib; _lib.build(out='build_variants/tt_base/libppenv.so', force=True)\"; git stash pop"; exit 2; }
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_t4_fused.py tests/test_pins_golden.py -m gpu -x -q -p no:cacheprovider > gpurun_out/pytest_pre.log 2>&1 || { tail -30 gpurun_out/pytest_pre.log; exit 1; }
 tail -1 gpurun_out/pytest_pre.log

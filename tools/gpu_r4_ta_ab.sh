@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of the 27-dof chain kernel: HEAD's library (build_variants/ta_base) against the working tree's
 set -o pipefail
+[ -f build_variants/ta_base/libppenv.so ] || { echo "build_variants/ta_base/libppenv.so is missing: build the baseline first, in the container — git stash; python -c \"from isaacgym_amd import _lib; _lib.build(out='build_variants/ta_base/libppenv.so', force=True)\"; git stash pop"; exit 2; }
 mkdir -p gpurun_out; export TMPDIR=/tmp
 for rep in 1 2; do for lib in base new; do
   if [ $lib = base ]; then export PPENV_LIB=$PWD/build_variants/ta_base/libppenv.so; else unset PPENV_LIB; fi
