@@ -363,7 +363,10 @@ class Workload:
         # obs_buf), so the rollout step has no normalise-and-pad launch; the 7-dof envs have no such output and keep the launch
         self.prepared = hasattr(self.env, "set_policy_input")
         if self.prepared:
-            self.net.attach_env(self.env)
+            try:
+                self.net.attach_env(self.env)
+            except Exception:          # a 27-dof kernel other than the chain-wave one (PPENV_TA_KERNEL): it has no such output, the launch stays
+                self.prepared = False
 
     def forward(self, counter=None):
         if counter is None:
