@@ -247,6 +247,12 @@ int ppenv_config_of(struct ppenv* env, ppenv_config* out);
  * observations (TT:770-799) — one fused kernel launch.
  * actions_dev: [A*N, 7] f32 row-major (the policy's tensor, not copied; A = 2 for PPENV_VARIANT_T4). */
 int ppenv_step(struct ppenv* env, const float* actions_dev, void* stream);
+/* `count` consecutive steps in one call, step i on actions_dev[i] (device pointers, host array): the launches of VecTask.step called `count` times
+ * (tasks/humanoid_pingpong_3_actor_tilt.py:1002-1052 per call) issued back to back from native code.  For open-loop bursts — scripted or logged actions, an
+ * action repeated over several control steps: one host call per step is host-bound at these kernel times (0.8-0.9 G env-steps/s from Python against
+ * 1.03 G for a 20-step burst at 16 384 envs); the burst runs at the rate of a captured graph of the same steps without a capture.  Each step's observations / rewards / resets are written as by
+ * ppenv_step (the last step's remain in the handle's buffers). */
+int ppenv_step_sequence(struct ppenv* env, const float* const* actions_dev, int32_t count, void* stream);
 /* The same step with its outputs redirected: obs [A*N, 80] f32 (16-byte aligned), rew [A*N] f32, reset [A*N] int64 receive this step's
  * observations, rewards and reset flags instead of the handle's obs_buf / rew_buf / reset_buf (NULL: the handle's own).  A rollout
  * collector passes the slices of its horizon-major buffers ([horizon, num_actors, ...], rl_games' experience layout), so nothing is

@@ -139,6 +139,7 @@ def load(path):
     L.ppenv_config_of.argtypes = [vp, cfgp]
     L.ppenv_step.argtypes = [vp, vp, vp]
     L.ppenv_step_into.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ppenv_step_sequence.argtypes = [vp, vp, C.c_int32, vp]
     L.ppenv_reset_all.argtypes = [vp, vp]
     L.ppenv_reduce_stats.argtypes = [vp, vp, vp]
     L.ppenv_reset_idx.argtypes = [vp, vp, C.c_int32, C.c_int, vp]

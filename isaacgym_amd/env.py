@@ -87,6 +87,15 @@ class PPEnv:
         p = lambda t: t.data_ptr() if t is not None else None
         _lib.check(self.L.ppenv_step_into(self.h, actions.data_ptr(), p(obs), p(rew), p(reset), self._stream()), self.L)
 
+    def step_sequence(self, actions_list):
+        """ppenv_step_sequence: one fused step per tensor of `actions_list` (float32 [A*N, 7], contiguous, on this device), launched back to back by one
+        native call — an open-loop burst (scripted / logged / repeated actions) without a host round trip or a graph launch per burst."""
+        import ctypes as C
+        for a in actions_list:
+            assert a.dtype == torch.float32 and a.device == self.device and a.is_contiguous() and tuple(a.shape) == (self.num_rows, scene.NUM_DOF)
+        arr = (C.c_void_p * len(actions_list))(*[a.data_ptr() for a in actions_list])
+        _lib.check(self.L.ppenv_step_sequence(self.h, arr, len(actions_list), self._stream()), self.L)
+
     def reset_all(self):
         _lib.check(self.L.ppenv_reset_all(self.h, self._stream()), self.L)
 

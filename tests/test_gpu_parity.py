@@ -276,6 +276,26 @@ def test_largest_size_is_the_same_env_by_env(torch_cuda):
     big.close(); ref.close()
 
 
+def test_step_sequence_is_the_same_steps(torch_cuda):
+    """ppenv_step_sequence: K steps launched by one native call end in the same state, bit for bit, as K ppenv_step calls on the same actions
+    (a ragged env count; also the empty sequence and a bad shape)."""
+    torch = torch_cuda
+    n = 1000
+    a_env, b_env = make_env(scene.build_config("TT", num_envs=n, seed=5)), make_env(scene.build_config("TT", num_envs=n, seed=5))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    acts = [(torch.rand(n, 7, device="cuda", generator=gen) * 2 - 1) for _ in range(37)]
+    for a in acts:
+        a_env.step(a)
+    b_env.step_sequence(acts[:20])
+    b_env.step_sequence([])
+    b_env.step_sequence(acts[20:])
+    for name in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "dof_pos", "dof_vel", "ball", "flags", "episode"):
+        assert torch.equal(getattr(a_env, name), getattr(b_env, name)), name
+    with pytest.raises(AssertionError):
+        b_env.step_sequence([acts[0][:10]])
+    a_env.close(); b_env.close()
+
+
 def test_vec_task_surface(torch_cuda):
     torch = torch_cuda
     import isaacgym_amd
